@@ -1,0 +1,94 @@
+"""Synthetic Wan2.1 DiT checkpoints and inputs (no network: no real checkpoints or prompts exist here).
+
+Tensor names and shapes follow the checkpoint layout the reference binds by name
+(reference: lightx2v/models/networks/wan/weights/transformer_weights.py:106,134-180,225-282,334-348,
+pre_weights.py:17-40, post_weights.py:17-18).  Recipe: seeded normal, std 0.02 for
+linear weights, norm weights 1 (+ small jitter so a swapped weight is detectable), biases small,
+`modulation` std 0.1.
+"""
+import math
+import torch
+
+# name -> (dim, ffn_dim, num_heads, num_layers); dims come from the Wan2.1 checkpoints' config.json
+WAN_DIMS = {
+    "wan2.1-1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, text_len=512, text_dim=4096),
+    "wan2.1-14b": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, text_len=512, text_dim=4096),
+    # miniature used by CPU tests / golden vectors (same head_dim=128 so RoPE split [22,21,21] is exercised)
+    "wan-tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_len=32, text_dim=64),
+}
+
+# BASELINE.json workloads: latent target_shape (C, T, H, W) (reference: wan_runner.py:260-280)
+WORKLOADS = {
+    "wan1.3b_256x256x17f": dict(model="wan2.1-1.3b", target_shape=(16, 5, 32, 32), frames=17),
+    "wan1.3b_480px49f": dict(model="wan2.1-1.3b", target_shape=(16, 13, 60, 104), frames=49),
+    "wan14b_720px81f": dict(model="wan2.1-14b", target_shape=(16, 21, 90, 160), frames=81),
+    "wan-tiny": dict(model="wan-tiny", target_shape=(16, 3, 8, 8), frames=9),
+}
+
+
+def seq_len_of(target_shape, patch=(1, 2, 2)):
+    _, t, h, w = target_shape
+    return (t // patch[0]) * (h // patch[1]) * (w // patch[2])
+
+
+def _randn(shape, std, gen, device, dtype):
+    if gen.device.type == "cpu":
+        t = torch.randn(shape, generator=gen, dtype=torch.float32) * std
+        return t.to(device=device, dtype=dtype)
+    return (torch.randn(shape, generator=gen, dtype=torch.float32, device=gen.device) * std).to(dtype)
+
+
+def synth_wan_weights(dims, seed=0, device="cpu", dtype=torch.bfloat16, gen_device="cpu", in_dim=16, out_dim=16, freq_dim=256):
+    """Return {checkpoint tensor name: tensor}.  gen_device="cpu" gives a device-independent stream
+    (parity tests); gen_device="cuda" fills large models directly in HBM (bench)."""
+    D, F, L = dims["dim"], dims["ffn_dim"], dims["num_layers"]
+    text_dim = dims.get("text_dim", 4096)
+    gen = torch.Generator(device=gen_device)
+    gen.manual_seed(seed)
+    wd = {}
+
+    def lin(name, n, k, std=0.02, bias_std=0.02):
+        wd[f"{name}.weight"] = _randn((n, k), std, gen, device, dtype)
+        wd[f"{name}.bias"] = _randn((n,), bias_std, gen, device, dtype)
+
+    def norm_w(name, n):
+        wd[name] = (1.0 + _randn((n,), 0.05, gen, device, torch.float32)).to(dtype)
+
+    wd["patch_embedding.weight"] = _randn((D, in_dim, 1, 2, 2), 0.05, gen, device, dtype)
+    wd["patch_embedding.bias"] = _randn((D,), 0.02, gen, device, dtype)
+    lin("text_embedding.0", D, text_dim, std=1.0 / math.sqrt(text_dim))
+    lin("text_embedding.2", D, D, std=1.0 / math.sqrt(D))
+    lin("time_embedding.0", D, freq_dim, std=1.0 / math.sqrt(freq_dim))
+    lin("time_embedding.2", D, D, std=1.0 / math.sqrt(D))
+    lin("time_projection.1", 6 * D, D, std=0.5 / math.sqrt(D))
+    for i in range(L):
+        p = f"blocks.{i}"
+        wd[f"{p}.modulation"] = _randn((1, 6, D), 0.1, gen, device, dtype)
+        for attn in ("self_attn", "cross_attn"):
+            for proj in ("q", "k", "v", "o"):
+                lin(f"{p}.{attn}.{proj}", D, D, std=1.0 / math.sqrt(D))
+            norm_w(f"{p}.{attn}.norm_q.weight", D)
+            norm_w(f"{p}.{attn}.norm_k.weight", D)
+        norm_w(f"{p}.norm3.weight", D)
+        wd[f"{p}.norm3.bias"] = _randn((D,), 0.02, gen, device, dtype)
+        lin(f"{p}.ffn.0", F, D, std=1.0 / math.sqrt(D))
+        lin(f"{p}.ffn.2", D, F, std=1.0 / math.sqrt(F))
+    lin("head.head", out_dim * 4, D, std=1.0 / math.sqrt(D))
+    wd["head.modulation"] = _randn((1, 2, D), 0.1, gen, device, dtype)
+    return wd
+
+
+def synth_inputs(dims, target_shape, seed=42, device="cpu"):
+    """Latents exactly as the reference seeds them (wan/scheduler.py:25-28,54-63: randn(target_shape),
+    fp32, seed 42) but always drawn from the CPU stream so CPU oracle and GPU path see identical noise
+    (SURVEY.md appendix A.10); context/context_null stand in for the T5 output (seeds +1/+2)."""
+    g = torch.Generator().manual_seed(seed)
+    latents = torch.randn(*target_shape, generator=g, dtype=torch.float32)
+    text_dim = dims.get("text_dim", 4096)
+    text_len = dims.get("text_len", 512)
+    n_tok = max(4, (text_len * 3) // 4)  # prompts are shorter than text_len; the rest is zero-padded by pre_infer
+    g1 = torch.Generator().manual_seed(seed + 1)
+    g2 = torch.Generator().manual_seed(seed + 2)
+    ctx = torch.randn(n_tok, text_dim, generator=g1).to(torch.bfloat16)
+    ctx_null = torch.randn(max(4, n_tok // 8), text_dim, generator=g2).to(torch.bfloat16)
+    return latents.to(device), [ctx.to(device)], [ctx_null.to(device)]

@@ -1,0 +1,94 @@
+"""Pins the oracle (oracle/wan_oracle.py) against fixtures generated FROM THE REFERENCE
+(oracle/gen_golden.py).  CPU only; bit-exact (same torch CPU kernels in the same order)."""
+import torch
+
+from lightx2v_amd import synth
+from oracle import wan_oracle as O
+
+
+def eq(a, b):
+    assert a.shape == b.shape and a.dtype == b.dtype
+    assert torch.equal(a, b), f"max diff {(a.float() - b.float()).abs().max().item()}"
+
+
+def test_ops_bit_exact(golden_ops):
+    g = golden_ops
+    eq(O.mm(g["mm_x"], g["mm_w"], g["mm_b"]), g["mm_y"])
+    eq(O.mm(g["mm_x"], g["mm_w"]), g["mm_y_nobias"])
+    eq(O.rms_norm(g["rms_x"], g["rms_w"]), g["rms_y"])
+    eq(O.layer_norm(g["ln_x"]), g["ln_y"])
+    y = O.layer_norm(g["ln_x"])
+    y.mul_(1 + g["ln_scale"].squeeze(0)).add_(g["ln_shift"].squeeze(0))
+    eq(y, g["ln_mod_y"])
+    eq(O.layer_norm(g["ln_x"], g["ln_w"], g["ln_b"]), g["ln_affine_y"])
+    f, h, w = g["rope_grid"][0].tolist()
+    fi = O.compute_freqs(64, (f, h, w), O.rope_freqs_table(128))
+    eq(O.apply_rotary_emb(g["rope_x"], fi), g["rope_y"])
+    eq(O.sdpa(g["attn_q"], g["attn_k"], g["attn_v"]), g["attn_o"])
+    eq(O.sdpa(g["attn_q"], g["xattn_k"], g["xattn_v"]), g["xattn_o"])
+    eq(O.sinusoidal_embedding_1d(256, g["sin_t"]), g["sin_y"])
+
+
+def test_fp32_legs_are_close(golden_ops):
+    """The fp32-statistics variants (what the reference's GPU wheels compute) stay within bf16 rounding
+    of the bf16-chain CPU path — this is the tolerance the HIP parity tests quote."""
+    g = golden_ops
+    y = O.rms_norm_fp32(g["rms_x"], g["rms_w"]).float()
+    r = g["rms_y"].float()
+    assert ((y - r).abs() <= 0.02 * r.abs() + 1e-2).all()
+    o = O.attention_fp32(g["attn_q"], g["attn_k"], g["attn_v"])
+    assert (o - g["attn_o"].float()).abs().max() < 2e-2
+
+
+def test_block_and_forward_bit_exact(golden_model):
+    g = golden_model
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wl = synth.WORKLOADS["wan-tiny"]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    acc = sum(wd[k].double().abs().sum() for k in sorted(wd))
+    assert abs(acc.item() - g["weights_checksum"].item()) < 1e-6 * acc.item(), "synthetic weight stream drifted"
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    eq(lat, g["latents0"])
+    t0 = g["timesteps"][0]
+    embed, grid, x, embed0, s, context = O.wan_pre_infer(wd, dims, lat.to(torch.bfloat16), t0, ctx)
+    eq(x, g["pre_x"])
+    eq(embed, g["pre_embed"])
+    eq(embed0, g["pre_embed0"])
+    eq(context, g["pre_context"])
+    tr = {}
+    xb = O.wan_block(wd, 0, dims, grid, x.clone(), embed0, O.rope_freqs_table(128), context, trace=tr)
+    eq(tr["x_after_self"], g["b0_x_after_self"])
+    eq(xb, g["b0_x_out"])
+    eq(O.wan_forward(wd, dims, lat.to(torch.bfloat16), t0, ctx), g["step0_cond"])
+
+
+def test_denoise_loop_bit_exact(golden_model):
+    g = golden_model
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wl = synth.WORKLOADS["wan-tiny"]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    sch = O.WanSchedulerOracle(4, 8.0, lat)
+    assert torch.equal(sch.timesteps, g["timesteps"])
+    assert torch.equal(sch.sigmas, g["sigmas"])
+    for i in range(4):
+        sch.step_pre(i)
+        sch.noise_pred = O.wan_model_infer(wd, dims, sch.latents, sch.timesteps[i], ctx, ctx_null, 6.0)
+        if i == 0:
+            eq(sch.noise_pred, g["step0_noise_pred"])
+        sch.step_post()
+        eq(sch.latents, g[f"latents_after_step{i}"])
+
+
+def test_scheduler_known_answers(golden_sched):
+    g = golden_sched
+    for steps, shift in ((50, 8.0), (4, 8.0), (10, 3.0)):
+        tag = f"s{steps}_sh{int(shift)}"
+        sch = O.WanSchedulerOracle(steps, shift, g[f"{tag}_lat0"])
+        assert torch.equal(sch.timesteps, g[f"{tag}_timesteps"])
+        assert torch.equal(sch.sigmas, g[f"{tag}_sigmas"])
+        for i in range(steps):
+            sch.step_pre(i)
+            sch.noise_pred = torch.sin(sch.latents.float() * 1.3 + 0.1 * i) + 0.05 * i
+            sch.step_post()
+        eq(sch.latents, g[f"{tag}_final"])
