@@ -1,0 +1,129 @@
+/*
+ * x2v.h — C-ABI of libx2v_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the LightX2V DiT
+ * denoise-step hot path.  This is the drop-in boundary: plain pointers, sizes and a
+ * hipStream_t; no torch types.  Each entry point names the reference call site it replaces
+ * (paths relative to /root/reference/lightx2v/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; bf16 tensors are passed as `const void*`/`void*`
+ *     (raw bfloat16 bits, little-endian); fp8 tensors are OCP e4m3fn bytes (gfx950 format, not fnuz)
+ *   - `ld*` / strides are in ELEMENTS; rows must be 16-byte aligned (ld % 8 == 0 for bf16)
+ *   - `stream` is a hipStream_t passed as void* (the Python shim passes
+ *     torch.cuda.current_stream().cuda_stream); every call is asynchronous, re-entrant, never
+ *     synchronises the device and keeps no mutable global state besides the thread-local error string
+ *   - return value: X2V_OK (0) or a negative X2V_E_* code; x2v_last_error() then describes it.
+ *     No exceptions or exit() cross the ABI (reference convention: Python exceptions / TORCH_CHECK →
+ *     RuntimeError, lightx2v_kernel/csrc/gemm/mxfp8_scaled_mm_kernels_sm120.cu:13-25; the shim raises
+ *     RuntimeError from the code)
+ */
+#ifndef X2V_H
+#define X2V_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X2V_OK 0
+#define X2V_E_SHAPE (-1)  /* unsupported shape / size constraint violated */
+#define X2V_E_ALIGN (-2)  /* pointer or leading dimension not 16-byte aligned */
+#define X2V_E_ARCH (-3)   /* device is not gfx950 */
+#define X2V_E_HIP (-4)    /* a HIP runtime call failed */
+#define X2V_E_ARG (-5)    /* null pointer / bad enum */
+
+/* GEMM epilogues (x2v_gemm_bf16 / x2v_gemm_fp8) */
+#define X2V_EPI_NONE 0      /* y = bf16(acc + bias) */
+#define X2V_EPI_GELU_TANH 1 /* y = bf16(gelu_tanh(bf16(acc + bias)))          (transformer_infer.py:488-492) */
+#define X2V_EPI_RESIDUAL 2  /* y = bf16(resid + bf16(bf16(acc + bias) * gate)) (transformer_infer.py:402,468,503);
+                               gate may be NULL (plain add); y may alias resid */
+#define X2V_EPI_SILU 3      /* y = bf16(silu(bf16(acc + bias)))                (pre_infer.py:74-76) */
+
+/* rounding model of the norm kernels */
+#define X2V_ROUND_FP32 0 /* fp32 statistics, one final rounding (what sgl_kernel.rmsnorm does on the reference's GPU path) */
+#define X2V_ROUND_REF 1  /* reproduce the reference's bf16 torch chain rounding for rounding (rms_norm_weight.py:111-113) */
+
+/* Library / device. x2v_init checks that `device` is gfx950 and caches its properties. */
+int x2v_init(int device);
+const char* x2v_last_error(void);
+const char* x2v_version(void);
+int x2v_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
+
+/* y[M,D] = x * rsqrt(mean(x^2) + eps) * w     — replaces RMSWeight/RMSWeightSgl.apply
+ * (common/ops/norm/rms_norm_weight.py:53-118; sgl_kernel.rmsnorm :102-108).  D % 8 == 0, D <= 16384.
+ * y may alias x. */
+int x2v_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int D, float eps, int round_mode,
+                     void* stream);
+
+/* y[M,D] = LN(x; w,b,eps) [* (1 + scale) + shift]   — replaces LNWeight.apply (layer_norm_weight.py:78-111)
+ * fused with the adaLN modulate `norm_out.mul_(1 + scale).add_(shift)` (transformer_infer.py:329-334,
+ * 481-484; post_infer.py:24-28).  w,b (affine, norm3) and scale,shift (modulate, [D] bf16) are each
+ * optional (NULL).  Rounding follows the reference chain: bf16 after LN, after the multiply, after the add. */
+int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* y, int64_t ldy,
+                       int64_t M, int D, float eps, void* stream);
+
+/* In-place q,k <- RoPE3D(RMSNorm_D(q|k)) for Wan self-attention — replaces rms_norm_weight.py apply on
+ * q and k (transformer_infer.py:341-342) + compute_freqs/apply_rotary_emb (wan/infer/utils.py:7-20,
+ * 107-115).  q,k: [S, H*128] bf16 with token stride ldq/ldk; wq,wk: [H*128] bf16 (NULL = skip the norm);
+ * rope_cs: float2 (cos,sin) table [1024][64] = the reference's `freqs` [1024,64] (pre_infer.py:12-19),
+ * columns [0,22) t-axis, [22,43) h-axis, [43,64) w-axis; token s has grid position
+ * ((s0+s) / (gh*gw), ((s0+s) / gw) % gh, (s0+s) % gw); tokens with s0+s >= gf*gh*gw are rotated by 1
+ * (compute_freqs_dist's ones padding, utils.py:78-83).  s0 = first global token of this rank's shard. */
+int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S, int H,
+                          int64_t s0, int gf, int gh, int gw, float eps, int round_mode, void* stream);
+
+/* x[M,D] = bf16(x + bf16(y * gate)) (gate [D] bf16, NULL = plain add) — replaces `x.add_(y * gate)`
+ * (transformer_infer.py:402,468,503) for callers that do not fuse it into the GEMM epilogue. */
+int x2v_gate_residual_bf16(void* x, int64_t ldx, const void* y, int64_t ldy, const void* gate, int64_t M, int D, void* stream);
+
+/* y = act(x) elementwise on [n] bf16: act 1 = gelu-tanh (transformer_infer.py:492), 3 = silu (pre_infer.py:74,76). */
+int x2v_activation_bf16(const void* x, void* y, int64_t n, int act, void* stream);
+
+/* y[M,N] = epi(x[M,K] . W[N,K]^T + bias[N])   — replaces MMWeight.apply = torch.addmm(bias, x, W.t())
+ * (common/ops/mm/mm_weight.py:70-96); W is the checkpoint's [N,K] row-major tensor (the reference's
+ * `.t()` view, :76).  bf16 in, fp32 MFMA accumulate, bf16 out.  K % 64 == 0, N % 8 == 0, any M >= 1.
+ * resid/gate only for X2V_EPI_RESIDUAL (resid [M,N] ld = ldr; gate [N] or NULL). */
+int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                  int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
+
+/* Dense non-causal attention, head_dim 128: o[Sq, H*128] = softmax(q k^T * scale) v per head —
+ * replaces FlashAttn2Weight/FlashAttn3Weight/TorchSDPAWeight.apply (common/ops/attn/attn_weight.py:71-126,
+ * 209-239) for one sequence (cu_seqlens = [0, S]).  q/k/v: token stride in elements (ldq/ldk/ldv), head h
+ * at column offset h*128; fp32 softmax, bf16 P, fp32 accumulate.  scale <= 0 selects 1/sqrt(128). */
+int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
+                      int64_t Sk, int H, int head_dim, float scale, void* stream);
+
+/* Same, selecting a kernel variant (tuning / validation hook; 0 = the default x2v_attn_fwd_bf16 uses):
+ * 1 = 4 waves x 32 queries, 2 = 8 waves x 32 queries, 3 = 4 waves with scalar LDS reads of V instead of the
+ * hardware transpose read (cross-checks ds_read_b64_tr_b16 addressing). */
+int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
+                              int64_t Sk, int H, int head_dim, float scale, int variant, void* stream);
+
+/* Per-token dynamic fp8 quantisation: s[m] = amax(|x[m,:]|)/448, xq = e4m3fn(x / s) — replaces
+ * vllm ops.scaled_fp8_quant(use_per_token_if_dynamic=True) / sgl_kernel.sgl_per_token_quant_fp8
+ * (mm_weight.py:236-245).  xq [M,K] bytes (ld = ldq), scale fp32 [M]. */
+int x2v_quant_fp8_rowwise(const void* x, int64_t ldx, void* xq, int64_t ldq, float* scale, int64_t M, int K, void* stream);
+
+/* y[M,N] = epi((xq[M,K] . wq[N,K]^T) * sx[m] * sw[n] + bias[n]) → bf16 — replaces
+ * torch.ops._C.cutlass_scaled_mm / sgl_kernel.fp8_scaled_mm (mm_weight.py:310-318,551-558,581-588).
+ * e4m3fn operands, fp32 MFMA accumulate.  K % 128 == 0, N % 8 == 0. */
+int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
+                 int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
+
+/* Timestep sinusoid: y[n, dim] bf16 = [cos(t*f_j) | sin(t*f_j)], f_j = 10000^(-j/(dim/2)) computed in
+ * float64 then rounded — replaces sinusoidal_embedding_1d (wan/infer/utils.py:161-172).  t: int64 [n]. */
+int x2v_sinusoid_embed_bf16(const int64_t* t, void* y, int n, int dim, void* stream);
+
+/* Causal Conv3d on channels-last fp32 activations — replaces CausalConv3d.forward
+ * (models/video_encoders/hf/wan/vae.py:19-44; with kt = 1 also the decoder's Conv2d, vae.py:70-118).
+ * Time axis input = [zeros(kt-1-cache_frames) | cache (cache_frames frames) | x (T frames)], output T frames;
+ * zero 'same' padding spatially (kh/2, kw/2).  fp32 in/out, fp32-input MFMA (exact fp32 fma chain).
+ * x:  [T, Hh, Ww, Cin]   cache: [cache_frames, Hh, Ww, Cin] or NULL when cache_frames == 0
+ * w:  [Cout, kt, kh, kw, Cin]   bias: [Cout] or NULL   y: [T, Hh, Ww, Cout].  Cin % 4 == 0. */
+int x2v_causal_conv3d_f32(const float* x, const float* cache, int cache_frames, const float* w, const float* bias, float* y, int T, int Hh, int Ww,
+                          int Cin, int Cout, int kt, int kh, int kw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X2V_H */

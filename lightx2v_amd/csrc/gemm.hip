@@ -1,0 +1,307 @@
+// y[M,N] = epi(x[M,K] . W[N,K]^T + bias) — bf16 (or w8a8 e4m3fn) in, fp32 MFMA accumulate, bf16 out.
+// The fp8 variant shares the whole structure: a 128-byte operand row per stage is 64 bf16 or 128 fp8 k-values;
+// it issues v_mfma_scale_f32_32x32x64_f8f6f4 with unit (2^0) block scales — the only fp8 MFMA that runs at
+// the 2x rate on gfx950 — and applies the per-token x per-channel fp32 scales in the epilogue.
+//
+// Bound: MFMA (bf16 dense peak ~2.5 PFLOP/s); algorithmic work 2*M*N*K FLOP per launch.
+//
+// Structure (v1, "128^2 tile / 2-barrier" of the CDNA4 playbook):
+//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of
+//     v_mfma_f32_32x32x16_bf16), BK = 64 (one 128-byte line per operand row per stage).
+//   * both operands are K-contiguous in HBM ([M,K] activations, [N,K] checkpoint weights), so A and B tiles
+//     are staged identically: LDS-DMA (global_load_lds, 16 B/lane, 1 KiB per wave-instruction) into a
+//     lane-linear [128 rows][128 B] image, double buffered (64 KiB -> 2 workgroups per CU).
+//   * bank conflicts: the 16-byte chunk c of row r is stored at chunk c ^ ((r>>1)&7).  The permutation is
+//     applied on the per-lane GLOBAL source address (the DMA destination is lane-linear by construction)
+//     and again on the ds_read_b128 address; with ds_read_b128's 16-lane service groups this makes every
+//     group hit 16 distinct 16-byte slots of the 256-byte bank row.
+//   * operands are passed to the MFMA swapped (W fragment as A, x fragment as B) so that each lane's
+//     accumulator registers hold 4 CONSECUTIVE output columns of one row -> 8-byte packed LDS writes in
+//     the epilogue, which goes through LDS to emit full 16-byte row-contiguous global stores (and, for the
+//     residual epilogue, 16-byte loads of the residual/gate).
+//   * 1-D grid, XCD-aware remap + grouped (8 m-tiles) ordering so the 64 tiles resident on one XCD share
+//     A/B panels through that XCD's L2.
+//   * M and N tails: source rows are clamped (loads stay in bounds), stores are masked.  K % 64 == 0.
+#include "x2v_common.h"
+
+namespace x2v {
+
+constexpr int GB_M = 128, GB_N = 128, GB_K = 64;        // GB_K counts bf16 elements; fp8 stages 128 per row
+constexpr int G_ROW_BYTES = 128;                         // operand bytes per row per stage
+constexpr int G_STAGE_BYTES = (GB_M + GB_N) * G_ROW_BYTES;  // 32 KiB
+constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;           // 64 KiB
+constexpr int G_EPI_LD = 272;                            // bytes per epilogue row (128 bf16 + 16 pad)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// swizzled byte offset of 16-byte chunk `c` of row `r` in a [rows][128 B] tile
+__device__ __forceinline__ int swz_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <bool FP8, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A, int64_t lda_bytes, const char* __restrict__ W, int64_t ldw_bytes,
+                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y, int64_t ldy, int64_t M,
+                                                      int N, int nk, const unsigned short* __restrict__ resid, int64_t ldr,
+                                                      const unsigned short* __restrict__ gate, const float* __restrict__ sx,
+                                                      const float* __restrict__ sw, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- tile coordinates (XCD chunking + grouped ordering)
+  const unsigned nblk = (unsigned)ntm * (unsigned)ntn;
+  const unsigned v = xcd_remap(blockIdx.x, nblk);
+  constexpr unsigned GM = 8;
+  const unsigned per_group = GM * (unsigned)ntn;
+  const unsigned group = v / per_group, in_g = v % per_group;
+  const unsigned first_m = group * GM;
+  const unsigned gsz = min((unsigned)ntm - first_m, GM);
+  const int tm = (int)(first_m + in_g % gsz), tn = (int)(in_g / gsz);
+  const int64_t m0 = (int64_t)tm * GB_M;
+  const int n0 = tn * GB_N;
+
+  // ---- per-lane staging source pointers: wave `wid` stages rows [wid*32, wid*32+32) of A and of B,
+  //      4 wave-instructions each; instruction i covers 8 rows x 8 chunks.
+  const int srow = lane >> 3, spos = lane & 7;
+  const char* a_src[4];
+  const char* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wid * 32 + i * 8 + srow;
+    const int c = spos ^ ((r >> 1) & 7);
+    int64_t gm = m0 + r;
+    gm = gm < M ? gm : M - 1;
+    int gn = n0 + r;
+    gn = gn < N ? gn : N - 1;
+    a_src[i] = A + gm * lda_bytes + c * 16;
+    b_src[i] = W + (int64_t)gn * ldw_bytes + c * 16;
+  }
+  auto stage = [&](int s, int kt) {
+    char* as = smem + s * G_STAGE_BYTES + wid * (32 * 128);
+    char* bs = as + GB_M * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + (int64_t)kt * G_ROW_BYTES, as + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(b_src[i] + (int64_t)kt * G_ROW_BYTES, bs + i * 1024);
+  };
+
+  // ---- MFMA fragment read offsets (bytes within a tile image); wave (wr, wc) owns rows wr*64.., cols wc*64..
+  const int wr = wid >> 1, wc = wid & 1;
+  const int fl = lane & 31, fh = lane >> 5;
+  // chunk order: bf16 step ks (K=16) reads chunk ks*2+fh; fp8 step s (K=64) reads chunks s*4+fh*2+{0,1}.
+  // In both cases A and B use the same (half-wave, element) -> k map, which is all an MFMA requires.
+  int a_off[2][4], b_off[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = FP8 ? ((ks >> 1) * 4 + fh * 2 + (ks & 1)) : (ks * 2 + fh);
+      a_off[i][ks] = swz_off(wr * 64 + i * 32 + fl, c);
+      b_off[i][ks] = swz_off(wc * 64 + i * 32 + fl, c) + GB_M * 128;
+    }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* base = smem + cur * G_STAGE_BYTES;
+    if constexpr (!FP8) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8_t xa[2], wb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          xa[i] = *reinterpret_cast<const bf16x8_t*>(base + a_off[i][ks]);
+          wb[i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i][ks]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        i32x8_t xa[2], wb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const i32x4_t a0 = *reinterpret_cast<const i32x4_t*>(base + a_off[i][s2 * 2]);
+          const i32x4_t a1 = *reinterpret_cast<const i32x4_t*>(base + a_off[i][s2 * 2 + 1]);
+          const i32x4_t b0 = *reinterpret_cast<const i32x4_t*>(base + b_off[i][s2 * 2]);
+          const i32x4_t b1 = *reinterpret_cast<const i32x4_t*>(base + b_off[i][s2 * 2 + 1]);
+          xa[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+          wb[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        constexpr int kOne = 0x7f7f7f7f;  // e8m0 2^0 block scales
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[j], xa[i], acc[i][j], 0, 0, 0, kOne, 0, kOne);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue phase 1: acc (+bias, activation) -> bf16 -> LDS [128][G_EPI_LD]
+  //      acc[i][j][r]: output row m = wr*64+i*32+fl, col n = wc*64+j*32 + (r&3) + 8*(r>>2) + 4*fh
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ml = wr * 64 + i * 32 + fl;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wc * 64 + j * 32 + 8 * g + 4 * fh;
+        float vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = acc[i][j][4 * g + e];
+        int gn = n0 + nl;
+        gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
+        if constexpr (FP8) {
+          int64_t gm = m0 + ml;
+          gm = gm < M ? gm : M - 1;
+          const float sxm = sx[gm];
+          const float4 swn = *reinterpret_cast<const float4*>(sw + gn);
+          vv[0] = vv[0] * sxm * swn.x;
+          vv[1] = vv[1] * sxm * swn.y;
+          vv[2] = vv[2] * sxm * swn.z;
+          vv[3] = vv[3] * sxm * swn.w;
+        }
+        if (bias != nullptr) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(bias + gn);
+          vv[0] += bf_lo(bb.x);
+          vv[1] += bf_hi(bb.x);
+          vv[2] += bf_lo(bb.y);
+          vv[3] += bf_hi(bb.y);
+        }
+        if (EPI == X2V_EPI_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = gelu_tanh_f(rbf(vv[e]));
+        } else if (EPI == X2V_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = silu_f(rbf(vv[e]));
+        }
+        uint2 pk;
+        pk.x = pack_bf2(vv[0], vv[1]);
+        pk.y = pack_bf2(vv[2], vv[3]);
+        *reinterpret_cast<uint2*>(smem + ml * G_EPI_LD + nl * 2) = pk;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue phase 2: 16-byte row-contiguous stores (16 lanes per 256-byte output row)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int id = it * 256 + tid;
+    const int row = id >> 4, cc = id & 15;
+    const int64_t gm = m0 + row;
+    const int gn = n0 + cc * 8;
+    if (gm < M && gn < N) {
+      uint4 o = *reinterpret_cast<const uint4*>(smem + row * G_EPI_LD + cc * 16);
+      if (EPI == X2V_EPI_RESIDUAL) {
+        float yv[8], xv[8], ov[8];
+        unpack8(o, yv);
+        unpack8(*reinterpret_cast<const uint4*>(resid + gm * ldr + gn), xv);
+        if (gate != nullptr) {
+          float gv[8];
+          unpack8(*reinterpret_cast<const uint4*>(gate + gn), gv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = xv[e] + rbf(yv[e] * gv[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = xv[e] + yv[e];
+        }
+        o = pack8(ov);
+      }
+      *reinterpret_cast<uint4*>(Y + gm * ldy + gn) = o;
+    }
+  }
+}
+
+}  // namespace x2v
+
+using namespace x2v;
+
+template <bool FP8, int EPI>
+static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
+                       const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, hipStream_t st) {
+  const int ntm = (int)((M + GB_M - 1) / GB_M), ntn = (N + GB_N - 1) / GB_N;
+  static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing threads set the same value
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)gemm_kernel<FP8, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES), "gemm attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<FP8, EPI>), dim3((unsigned)ntm * (unsigned)ntn), dim3(256), G_LDS_BYTES, st, (const char*)x, ldx_bytes, (const char*)w,
+                     ldw_bytes, (const unsigned short*)bias, (unsigned short*)y, ldy, M, N, nk, (const unsigned short*)resid, ldr,
+                     (const unsigned short*)gate, sx, sw, ntm, ntn);
+  X2V_LAUNCH_CHECK("gemm launch");
+  return X2V_OK;
+}
+
+template <bool FP8>
+static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N,
+                        int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, hipStream_t st) {
+  switch (epilogue) {
+    case X2V_EPI_NONE: return launch_gemm<FP8, X2V_EPI_NONE>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
+    case X2V_EPI_GELU_TANH: return launch_gemm<FP8, X2V_EPI_GELU_TANH>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
+    case X2V_EPI_SILU: return launch_gemm<FP8, X2V_EPI_SILU>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
+    case X2V_EPI_RESIDUAL: return launch_gemm<FP8, X2V_EPI_RESIDUAL>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, st);
+    default: set_error("gemm: unknown epilogue %d", epilogue); return X2V_E_ARG;
+  }
+}
+
+static int check_common(const char* who, const void* y, int64_t ldy, int64_t M, int N, const void* bias, int epilogue, const void* resid, int64_t ldr,
+                        const void* gate) {
+  X2V_REQUIRE(M >= 0 && N > 0, X2V_E_SHAPE, "%s: bad shape M=%lld N=%d", who, (long long)M, N);
+  X2V_REQUIRE(N % 8 == 0, X2V_E_SHAPE, "%s: N=%d must be a multiple of 8", who, N);
+  X2V_REQUIRE(ldy % 8 == 0 && ldy >= N && aligned16(y), X2V_E_ALIGN, "%s: output rows must be 16-byte aligned", who);
+  X2V_REQUIRE(bias == nullptr || ((uintptr_t)bias % 8) == 0, X2V_E_ALIGN, "%s: bias must be 8-byte aligned", who);
+  X2V_REQUIRE((M + GB_M - 1) / GB_M * (int64_t)((N + GB_N - 1) / GB_N) < (1ll << 31), X2V_E_SHAPE, "%s: too many tiles", who);
+  if (epilogue == X2V_EPI_RESIDUAL) {
+    X2V_REQUIRE(resid != nullptr, X2V_E_ARG, "%s: residual epilogue needs resid", who);
+    X2V_REQUIRE(ldr % 8 == 0 && ldr >= N && aligned16(resid) && aligned16(gate), X2V_E_ALIGN, "%s: resid/gate alignment", who);
+  }
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                             int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+  X2V_REQUIRE(x && w && y, X2V_E_ARG, "gemm_bf16: null pointer");
+  X2V_REQUIRE(K > 0 && K % GB_K == 0, X2V_E_SHAPE, "gemm_bf16: K=%d must be a positive multiple of %d", K, GB_K);
+  X2V_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && aligned16(x) && aligned16(w), X2V_E_ALIGN, "gemm_bf16: operand rows must be 16-byte aligned");
+  X2V_REQUIRE(ldx >= K && ldw >= K, X2V_E_SHAPE, "gemm_bf16: leading dimension smaller than K");
+  int rc = check_common("gemm_bf16", y, ldy, M, N, bias, epilogue, resid, ldr, gate);
+  if (rc != X2V_OK) return rc;
+  if (M == 0) return X2V_OK;
+  return dispatch_epi<false>(epilogue, x, ldx * 2, w, ldw * 2, bias, y, ldy, M, N, K / GB_K, resid, ldr, gate, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
+                            int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+  X2V_REQUIRE(xq && wq && y && sx && sw, X2V_E_ARG, "gemm_fp8: null pointer");
+  X2V_REQUIRE(K > 0 && K % 128 == 0, X2V_E_SHAPE, "gemm_fp8: K=%d must be a positive multiple of 128", K);
+  X2V_REQUIRE(ldx % 16 == 0 && ldw % 16 == 0 && aligned16(xq) && aligned16(wq) && aligned16(sw), X2V_E_ALIGN, "gemm_fp8: operand rows must be 16-byte aligned");
+  X2V_REQUIRE(ldx >= K && ldw >= K, X2V_E_SHAPE, "gemm_fp8: leading dimension smaller than K");
+  int rc = check_common("gemm_fp8", y, ldy, M, N, bias, epilogue, resid, ldr, gate);
+  if (rc != X2V_OK) return rc;
+  if (M == 0) return X2V_OK;
+  return dispatch_epi<true>(epilogue, xq, ldx, wq, ldw, bias, y, ldy, M, N, K / 128, resid, ldr, gate, sx, sw, (hipStream_t)stream);
+}

@@ -1,0 +1,426 @@
+// Row-wise HBM-bound kernels of the DiT block: RMSNorm, LayerNorm(+adaLN modulate), fused
+// RMSNorm+3-axis RoPE on q/k, gate-residual, activations, timestep sinusoid.
+//
+// Roofline: each is one read + one write of an [M,D] bf16 tensor (2*M*D*2 bytes) against ~6.3 TB/s
+// achievable HBM.  Structure: a row lives entirely in registers between its single 16-byte-vector read
+// and its single write (two-pass statistics cost no extra HBM traffic); NW waves cooperate on one row
+// (NW=4 for the model dim, NW=1 for short rows so a 256-thread block carries 4 rows).
+#include <type_traits>
+
+#include "x2v_common.h"
+
+namespace x2v {
+
+// ------------------------------------------------------------------------------------------------
+// Row holder: CH 16-byte chunks per lane, lanes of the row's NW waves interleaved chunk-wise so every
+// wave-instruction reads NW... 64 consecutive chunks (1 KiB) — fully coalesced.
+template <int CH, int NW>
+struct RowRegs {
+  float v[CH][8];
+  bool ok[CH];
+  __device__ __forceinline__ void load(const unsigned short* row, int D, int t) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int e = (c * NW * 64 + t) * 8;
+      ok[c] = e < D;
+      if (ok[c]) {
+        uint4 u = *reinterpret_cast<const uint4*>(row + e);
+        unpack8(u, v[c]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+      }
+    }
+  }
+};
+
+template <int CH, int NW, int ROUND>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ w,
+                                                      unsigned short* __restrict__ y, int64_t ldy, int64_t M, int D, float eps) {
+  __shared__ float red[4];
+  constexpr int ROWS = 4 / NW;
+  const int t = threadIdx.x % (NW * 64);
+  const int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x / (NW * 64);
+  const bool live = row < M;
+  RowRegs<CH, NW> r;
+  if (live) r.load(x + row * ldx, D, t);
+  float ss = 0.f;
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float p = r.v[c][j] * r.v[c][j];
+        ss += (ROUND == X2V_ROUND_REF) ? rbf(p) : p;  // torch: x.pow(2) is a bf16 tensor
+      }
+  }
+  ss = (NW == 1) ? wave_sum(ss) : block_sum<4>(ss, red);
+  if (!live) return;
+  float rs;
+  if (ROUND == X2V_ROUND_REF) {
+    float mean = rbf(ss / (float)D);  // .mean(-1): fp32 accumulate, bf16 result
+    float tt = rbf(mean + eps);       // + eps   → bf16
+    rs = rbf(1.0f / sqrtf(tt));       // rsqrt   → bf16
+  } else {
+    rs = 1.0f / sqrtf(ss / (float)D + eps);
+  }
+  unsigned short* yr = y + row * ldy;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!r.ok[c]) continue;
+    const int e = (c * NW * 64 + t) * 8;
+    float wv[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(w + e), wv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ROUND == X2V_ROUND_REF)
+        o[j] = rbf(r.v[c][j] * rs) * wv[j];  // (x * rstd) → bf16, then * weight → bf16 (pack8 rounds)
+      else
+        o[j] = r.v[c][j] * rs * wv[j];
+    }
+    *reinterpret_cast<uint4*>(yr + e) = pack8(o);
+  }
+}
+
+// LayerNorm (+ optional affine, + optional adaLN modulate), reference rounding chain.
+template <int CH, int NW>
+__global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ w,
+                                                        const unsigned short* __restrict__ b, const unsigned short* __restrict__ scale,
+                                                        const unsigned short* __restrict__ shift, unsigned short* __restrict__ y, int64_t ldy,
+                                                        int64_t M, int D, float eps) {
+  __shared__ float red[4];
+  constexpr int ROWS = 4 / NW;
+  const int t = threadIdx.x % (NW * 64);
+  const int64_t row = (int64_t)blockIdx.x * ROWS + threadIdx.x / (NW * 64);
+  const bool live = row < M;
+  RowRegs<CH, NW> r;
+  if (live) r.load(x + row * ldx, D, t);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += r.v[c][j];
+  s = (NW == 1) ? wave_sum(s) : block_sum<4>(s, red);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (r.ok[c]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = r.v[c][j] - mean;
+        q += d * d;
+      }
+    }
+  q = (NW == 1) ? wave_sum(q) : block_sum<4>(q, red);
+  if (!live) return;
+  const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+  unsigned short* yr = y + row * ldy;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!r.ok[c]) continue;
+    const int e = (c * NW * 64 + t) * 8;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (r.v[c][j] - mean) * rstd;
+    if (w != nullptr) {
+      float wv[8];
+      unpack8(*reinterpret_cast<const uint4*>(w + e), wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= wv[j];
+    }
+    if (b != nullptr) {
+      float bv[8];
+      unpack8(*reinterpret_cast<const uint4*>(b + e), bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += bv[j];
+    }
+    if (scale != nullptr) {  // norm_out.mul_(1 + scale).add_(shift): three bf16 roundings
+      float sc[8], sh[8];
+      unpack8(*reinterpret_cast<const uint4*>(scale + e), sc);
+      unpack8(*reinterpret_cast<const uint4*>(shift + e), sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float ln = rbf(o[j]);
+        float m = rbf(ln * rbf(1.0f + sc[j]));
+        o[j] = m + sh[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(yr + e) = pack8(o);
+  }
+}
+
+// Fused q/k RMSNorm over the full model dim + 3-axis RoPE.  blockIdx.y selects q (0) or k (1).
+// One block per token row; D = H*128 so every 16-byte chunk holds 4 (re,im) pairs of one head.
+template <int CH, int ROUND>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
+                                                           const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
+                                                           const float2* __restrict__ cs, int64_t S, int D, int64_t s0, int gf, int gh, int gw,
+                                                           float eps) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  unsigned short* base = (blockIdx.y == 0 ? q + row * ldq : k + row * ldk);
+  const unsigned short* w = blockIdx.y == 0 ? wq : wk;
+  RowRegs<CH, 4> r;
+  r.load(base, D, t);
+  float rs = 1.f;
+  if (w != nullptr) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float p = r.v[c][j] * r.v[c][j];
+        ss += (ROUND == X2V_ROUND_REF) ? rbf(p) : p;
+      }
+    ss = block_sum<4>(ss, red);
+    if (ROUND == X2V_ROUND_REF) {
+      float mean = rbf(ss / (float)D);
+      rs = rbf(1.0f / sqrtf(rbf(mean + eps)));
+    } else {
+      rs = 1.0f / sqrtf(ss / (float)D + eps);
+    }
+  }
+  // grid position of this token (global index s0+row); beyond the grid → identity rotation
+  const int64_t g = s0 + row;
+  const bool rot = g < (int64_t)gf * gh * gw;
+  const int pw = (int)(g % gw), ph = (int)((g / gw) % gh), pf = (int)(g / ((int64_t)gw * gh));
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!r.ok[c]) continue;
+    const int e = (c * 256 + t) * 8;
+    float xn[8], o[8];
+    if (w != nullptr) {
+      float wv[8];
+      unpack8(*reinterpret_cast<const uint4*>(w + e), wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (ROUND == X2V_ROUND_REF)
+          xn[j] = rbf(rbf(r.v[c][j] * rs) * wv[j]);
+        else
+          xn[j] = rbf(r.v[c][j] * rs * wv[j]);  // the norm's bf16 output feeds RoPE in the reference
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xn[j] = r.v[c][j];
+    }
+    const int pair0 = (e & 127) >> 1;  // complex index within the head: 0..63, 4 pairs per chunk
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ci = pair0 + p;
+      float co = 1.f, si = 0.f;
+      if (rot) {
+        const int pos = ci < 22 ? pf : (ci < 43 ? ph : pw);
+        const float2 f = cs[pos * 64 + ci];
+        co = f.x;
+        si = f.y;
+      }
+      const float a = xn[2 * p], bb = xn[2 * p + 1];
+      o[2 * p] = a * co - bb * si;
+      o[2 * p + 1] = a * si + bb * co;
+    }
+    *reinterpret_cast<uint4*>(base + e) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_residual_kernel(unsigned short* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ y,
+                                                            int64_t ldy, const unsigned short* __restrict__ gate, int64_t M, int D) {
+  const int cpr = D / 8;
+  const int64_t total = M * (int64_t)cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cpr;
+    const int e = (int)(i % cpr) * 8;
+    float xv[8], yv[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + row * ldx + e), xv);
+    unpack8(*reinterpret_cast<const uint4*>(y + row * ldy + e), yv);
+    if (gate != nullptr) {
+      float gv[8];
+      unpack8(*reinterpret_cast<const uint4*>(gate + e), gv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = xv[j] + rbf(yv[j] * gv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = xv[j] + yv[j];
+    }
+    *reinterpret_cast<uint4*>(x + row * ldx + e) = pack8(o);
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void activation_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int64_t n) {
+  const int64_t nv = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ACT == X2V_EPI_GELU_TANH ? gelu_tanh_f(v[j]) : silu_f(v[j]);
+    reinterpret_cast<uint4*>(y)[i] = pack8(v);
+  }
+  // tail (n % 8) handled by the first block
+  if (blockIdx.x == 0) {
+    for (int64_t i = nv * 8 + threadIdx.x; i < n; i += blockDim.x) {
+      float f = bf2f(x[i]);
+      y[i] = f2bf(ACT == X2V_EPI_GELU_TANH ? gelu_tanh_f(f) : silu_f(f));
+    }
+  }
+}
+
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, unsigned short* __restrict__ y, int n, int dim) {
+  const int half = dim / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * half; i += gridDim.x * blockDim.x) {
+    const int r = i / half, j = i % half;
+    // float64 as the reference (utils.py:165-171): pos * 10000^(-j/half)
+    const double f = pow(10000.0, -((double)j / (double)half));
+    const double a = (double)t[r] * f;
+    y[(int64_t)r * dim + j] = f2bf((float)cos(a));
+    y[(int64_t)r * dim + half + j] = f2bf((float)sin(a));
+  }
+}
+
+}  // namespace x2v
+
+using namespace x2v;
+
+namespace {
+int chunks_for(int D, int nw) { return (D / 8 + nw * 64 - 1) / (nw * 64); }
+}  // namespace
+
+// Dispatch a runtime chunk count to a compile-time CH (generic lambda receives std::integral_constant).
+template <typename F>
+static int dispatch_ch(int ch, int D, F&& f) {
+  switch (ch) {
+    case 1: f(std::integral_constant<int, 1>{}); return X2V_OK;
+    case 2: f(std::integral_constant<int, 2>{}); return X2V_OK;
+    case 3: f(std::integral_constant<int, 3>{}); return X2V_OK;
+    case 4: f(std::integral_constant<int, 4>{}); return X2V_OK;
+    case 5: case 6: case 7: case 8: f(std::integral_constant<int, 8>{}); return X2V_OK;
+    default: ::x2v::set_error("row too long: D=%d (max 16384)", D); return X2V_E_SHAPE;
+  }
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int D, float eps, int round_mode,
+                                void* stream) {
+  X2V_REQUIRE(x && w && y, X2V_E_ARG, "rmsnorm: null pointer");
+  X2V_REQUIRE(D > 0 && D % 8 == 0 && D <= 16384, X2V_E_SHAPE, "rmsnorm: D=%d must be a multiple of 8 and <= 16384", D);
+  X2V_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w), X2V_E_ALIGN, "rmsnorm: rows must be 16-byte aligned");
+  X2V_REQUIRE(round_mode == X2V_ROUND_FP32 || round_mode == X2V_ROUND_REF, X2V_E_ARG, "rmsnorm: bad round_mode %d", round_mode);
+  if (M <= 0) return X2V_OK;
+  auto xs = (const unsigned short*)x, ws = (const unsigned short*)w;
+  auto ys = (unsigned short*)y;
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 512) {  // one wave per row, 4 rows per block
+    const unsigned grid = (unsigned)((M + 3) / 4);
+    if (round_mode == X2V_ROUND_REF)
+      hipLaunchKernelGGL((rmsnorm_kernel<1, 1, X2V_ROUND_REF>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, ys, ldy, M, D, eps);
+    else
+      hipLaunchKernelGGL((rmsnorm_kernel<1, 1, X2V_ROUND_FP32>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, ys, ldy, M, D, eps);
+  } else {
+    const int ch = chunks_for(D, 4);
+    const unsigned grid = (unsigned)M;
+    int rc = dispatch_ch(ch, D, [&](auto chc) {
+      constexpr int CH = decltype(chc)::value;
+      if (round_mode == X2V_ROUND_REF)
+        hipLaunchKernelGGL((rmsnorm_kernel<CH, 4, X2V_ROUND_REF>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, ys, ldy, M, D, eps);
+      else
+        hipLaunchKernelGGL((rmsnorm_kernel<CH, 4, X2V_ROUND_FP32>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, ys, ldy, M, D, eps);
+    });
+    if (rc != X2V_OK) return rc;
+  }
+  X2V_LAUNCH_CHECK("rmsnorm launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* y,
+                                  int64_t ldy, int64_t M, int D, float eps, void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "layernorm: null pointer");
+  X2V_REQUIRE((scale == nullptr) == (shift == nullptr), X2V_E_ARG, "layernorm: scale and shift must be given together");
+  X2V_REQUIRE(D > 0 && D % 8 == 0 && D <= 16384, X2V_E_SHAPE, "layernorm: D=%d must be a multiple of 8 and <= 16384", D);
+  X2V_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w) && aligned16(b) && aligned16(scale) && aligned16(shift),
+              X2V_E_ALIGN, "layernorm: rows must be 16-byte aligned");
+  if (M <= 0) return X2V_OK;
+  auto xs = (const unsigned short*)x;
+  auto ws = (const unsigned short*)w, bs = (const unsigned short*)b, scs = (const unsigned short*)scale, shs = (const unsigned short*)shift;
+  auto ys = (unsigned short*)y;
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 512) {
+    const unsigned grid = (unsigned)((M + 3) / 4);
+    hipLaunchKernelGGL((layernorm_kernel<1, 1>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, bs, scs, shs, ys, ldy, M, D, eps);
+  } else {
+    const int ch = chunks_for(D, 4);
+    const unsigned grid = (unsigned)M;
+    int rc = dispatch_ch(ch, D, [&](auto chc) {
+      constexpr int CH = decltype(chc)::value;
+      hipLaunchKernelGGL((layernorm_kernel<CH, 4>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, bs, scs, shs, ys, ldy, M, D, eps);
+    });
+    if (rc != X2V_OK) return rc;
+  }
+  X2V_LAUNCH_CHECK("layernorm launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S,
+                                     int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode, void* stream) {
+  X2V_REQUIRE(q && k && rope_cs, X2V_E_ARG, "rmsnorm_rope: null pointer");
+  X2V_REQUIRE((wq == nullptr) == (wk == nullptr), X2V_E_ARG, "rmsnorm_rope: wq and wk must be given together");
+  const int D = H * 128;
+  X2V_REQUIRE(H > 0 && D <= 16384, X2V_E_SHAPE, "rmsnorm_rope: H=%d out of range", H);
+  X2V_REQUIRE(gf > 0 && gh > 0 && gw > 0 && gf <= 1024 && gh <= 1024 && gw <= 1024, X2V_E_SHAPE, "rmsnorm_rope: grid (%d,%d,%d) out of range", gf, gh, gw);
+  X2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && aligned16(q) && aligned16(k) && aligned16(wq) && aligned16(wk), X2V_E_ALIGN,
+              "rmsnorm_rope: rows must be 16-byte aligned");
+  X2V_REQUIRE(round_mode == X2V_ROUND_FP32 || round_mode == X2V_ROUND_REF, X2V_E_ARG, "rmsnorm_rope: bad round_mode %d", round_mode);
+  if (S <= 0) return X2V_OK;
+  const int ch = chunks_for(D, 4);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)S, 2);
+  auto qs = (unsigned short*)q, ks = (unsigned short*)k;
+  auto wqs = (const unsigned short*)wq, wks = (const unsigned short*)wk;
+  auto cs = (const float2*)rope_cs;
+  int rc = dispatch_ch(ch, D, [&](auto chc) {
+    constexpr int CH = decltype(chc)::value;
+    if (round_mode == X2V_ROUND_REF)
+      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_REF>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps);
+    else
+      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_FP32>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps);
+  });
+  if (rc != X2V_OK) return rc;
+  X2V_LAUNCH_CHECK("rmsnorm_rope launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gate_residual_bf16(void* x, int64_t ldx, const void* y, int64_t ldy, const void* gate, int64_t M, int D, void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "gate_residual: null pointer");
+  X2V_REQUIRE(D > 0 && D % 8 == 0, X2V_E_SHAPE, "gate_residual: D=%d must be a multiple of 8", D);
+  X2V_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(gate), X2V_E_ALIGN, "gate_residual: rows must be 16-byte aligned");
+  if (M <= 0) return X2V_OK;
+  const int64_t total = M * (int64_t)(D / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 2048 * 4 ? (total + 255) / 256 : 2048 * 4);
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, ldx, (const unsigned short*)y, ldy,
+                     (const unsigned short*)gate, M, D);
+  X2V_LAUNCH_CHECK("gate_residual launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_activation_bf16(const void* x, void* y, int64_t n, int act, void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "activation: null pointer");
+  X2V_REQUIRE(act == X2V_EPI_GELU_TANH || act == X2V_EPI_SILU, X2V_E_ARG, "activation: unknown act %d", act);
+  X2V_REQUIRE(aligned16(x) && aligned16(y), X2V_E_ALIGN, "activation: pointers must be 16-byte aligned");
+  if (n <= 0) return X2V_OK;
+  const int64_t nv = n / 8;
+  const unsigned grid = (unsigned)((nv + 255) / 256 < 8192 ? ((nv + 255) / 256 > 0 ? (nv + 255) / 256 : 1) : 8192);
+  if (act == X2V_EPI_GELU_TANH)
+    hipLaunchKernelGGL((activation_kernel<X2V_EPI_GELU_TANH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
+  else
+    hipLaunchKernelGGL((activation_kernel<X2V_EPI_SILU>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
+  X2V_LAUNCH_CHECK("activation launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_sinusoid_embed_bf16(const int64_t* t, void* y, int n, int dim, void* stream) {
+  X2V_REQUIRE(t && y, X2V_E_ARG, "sinusoid: null pointer");
+  X2V_REQUIRE(n > 0 && dim > 0 && dim % 2 == 0, X2V_E_SHAPE, "sinusoid: n=%d dim=%d", n, dim);
+  const int total = n * (dim / 2);
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, t, (unsigned short*)y, n, dim);
+  X2V_LAUNCH_CHECK("sinusoid launch");
+  return X2V_OK;
+}

@@ -1,0 +1,258 @@
+"""ctypes binding of the C-ABI (include/x2v.h) + thin torch-tensor wrappers.
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream; every wrapper passes
+raw `data_ptr()`s, element strides and `torch.cuda.current_stream().cuda_stream` to libx2v_hip.so.
+The library is REQUIRED: importing this module without the built .so, or calling an op on a non-gfx950
+device, raises — there is no eager/PyTorch fallback on the product path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx2v_hip.so")
+
+EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_SILU = 0, 1, 2, 3
+ROUND_FP32, ROUND_REF = 0, 1
+
+_c_void_p, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/x2v.h one to one
+PROTOTYPES = {
+    "x2v_init": [_i32],
+    "x2v_last_error": [],
+    "x2v_version": [],
+    "x2v_device_info": [_i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32],
+    "x2v_rmsnorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
+    "x2v_layernorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
+    "x2v_rmsnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
+    "x2v_gate_residual_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
+    "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
+    "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
+    "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
+    "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
+    "x2v_gemm_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "x2v_sinusoid_embed_bf16": [_c_void_p, _c_void_p, _i32, _i32, _c_void_p],
+    "x2v_causal_conv3d_f32": [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+}
+_RESTYPES = {"x2v_last_error": ctypes.c_char_p, "x2v_version": ctypes.c_char_p}
+
+
+class X2VError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise X2VError(f"{path} is missing: build it with `python -m lightx2v_amd.build` (hipcc, gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    return lib
+
+
+_lib = load_library()
+_inited = set()
+
+
+def version():
+    return _lib.x2v_version().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise X2VError(f"{what} failed ({rc}): {_lib.x2v_last_error().decode()}")
+
+
+def init(device_index=None):
+    """Verify the device is gfx950 (raises otherwise)."""
+    if not torch.cuda.is_available():
+        raise X2VError("no HIP device visible: the x2v HIP path has no CPU fallback")
+    idx = torch.cuda.current_device() if device_index is None else device_index
+    if idx not in _inited:
+        _check(_lib.x2v_init(idx), "x2v_init")
+        _inited.add(idx)
+    return idx
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _row2d(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise X2VError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    if not t.is_cuda:
+        raise X2VError(f"{name}: tensor is on {t.device}; the x2v HIP path has no CPU fallback")
+    return t
+
+
+def _bf16(t, name):
+    if t.dtype != torch.bfloat16:
+        raise X2VError(f"{name}: expected bfloat16, got {t.dtype}")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------
+def rmsnorm(x, weight, eps=1e-6, out=None, round_mode=ROUND_FP32):
+    shape = x.shape
+    x2 = _row2d(_bf16(x.reshape(-1, shape[-1]) if x.dim() != 2 else x, "x"), "x")
+    out2 = torch.empty((x2.shape[0], x2.shape[1]), dtype=torch.bfloat16, device=x.device) if out is None else _row2d(out.reshape(-1, shape[-1]) if out.dim() != 2 else out, "out")
+    init()
+    _check(_lib.x2v_rmsnorm_bf16(_p(x2), x2.stride(0), _p(_bf16(weight, "weight")), _p(out2), out2.stride(0), x2.shape[0], x2.shape[1], eps, round_mode, _stream()), "rmsnorm")
+    return out2.view(shape) if out is None else out
+
+
+def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=None):
+    """LN(x)[*w+b] then optional adaLN `* (1 + scale) + shift` (scale/shift: [D] or [1,D] bf16)."""
+    x2 = _row2d(_bf16(x, "x"), "x")
+    out2 = torch.empty_like(x2) if out is None else _row2d(out, "out")
+    if scale is not None:
+        scale, shift = scale.reshape(-1), shift.reshape(-1)
+        if not (scale.is_contiguous() and shift.is_contiguous()):
+            scale, shift = scale.contiguous(), shift.contiguous()
+    init()
+    _check(
+        _lib.x2v_layernorm_bf16(_p(x2), x2.stride(0), _p(weight), _p(bias), _p(scale), _p(shift), _p(out2), out2.stride(0), x2.shape[0], x2.shape[1], eps, _stream()),
+        "layernorm",
+    )
+    return out2
+
+
+def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_mode=ROUND_FP32):
+    """In place: q,k [S, H*128] ← RoPE3D(RMSNorm(q|k))."""
+    q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
+    if rope_cs.dtype != torch.float32 or tuple(rope_cs.shape) != (1024, 64, 2) or not rope_cs.is_contiguous():
+        raise X2VError("rope_cs must be a contiguous float32 [1024,64,2] (cos,sin) table")
+    gf, gh, gw = grid
+    init()
+    _check(
+        _lib.x2v_rmsnorm_rope_bf16(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(wq), _p(wk), _p(rope_cs), q2.shape[0], num_heads, s0, gf, gh, gw, eps, round_mode, _stream()),
+        "rmsnorm_rope",
+    )
+    return q, k
+
+
+def gate_residual_(x, y, gate=None):
+    x2, y2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(y, "y"), "y")
+    if gate is not None:
+        gate = gate.reshape(-1)
+    init()
+    _check(_lib.x2v_gate_residual_bf16(_p(x2), x2.stride(0), _p(y2), y2.stride(0), _p(gate), x2.shape[0], x2.shape[1], _stream()), "gate_residual")
+    return x
+
+
+def activation(x, act):
+    xc = _bf16(x, "x").contiguous()
+    out = torch.empty_like(xc)
+    init()
+    _check(_lib.x2v_activation_bf16(_p(xc), _p(out), xc.numel(), act, _stream()), "activation")
+    return out
+
+
+def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None):
+    """y = epi(x @ weight_nk.T + bias); weight_nk is the checkpoint's [N,K] tensor."""
+    x2, w2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(weight_nk, "weight"), "weight")
+    M, K = x2.shape
+    N = w2.shape[0]
+    if w2.shape[1] != K:
+        raise X2VError(f"gemm: x [M,{K}] vs weight [{N},{w2.shape[1]}]")
+    if epilogue == EPI_RESIDUAL:
+        if resid is None:
+            raise X2VError("gemm: residual epilogue needs resid")
+        out2 = _row2d(resid if out is None else out, "out")
+        r2 = _row2d(_bf16(resid, "resid"), "resid")
+        if gate is not None:
+            gate = gate.reshape(-1)
+    else:
+        out2 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if out is None else _row2d(out, "out")
+        r2 = None
+    init()
+    _check(
+        _lib.x2v_gemm_bf16(_p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), _stream()),
+        "gemm_bf16",
+    )
+    return out2
+
+
+def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0):
+    """q [Sq, H*d] (or [Sq,H,d]), k/v [Sk, H*d]; any token stride (fused-QKV views are fine)."""
+
+    def as2d(t, name):
+        if t.dim() == 3:
+            if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+                raise X2VError(f"attention: {name} heads must be packed (stride {t.stride()})")
+            t = t.as_strided((t.shape[0], t.shape[1] * t.shape[2]), (t.stride(0), 1))
+        return _row2d(_bf16(t, name), name)
+
+    q2, k2, v2 = as2d(q, "q"), as2d(k, "k"), as2d(v, "v")
+    Sq, Sk = q2.shape[0], k2.shape[0]
+    out2 = torch.empty((Sq, num_heads * head_dim), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(out, "out")
+    init()
+    _check(
+        _lib.x2v_attn_fwd_bf16_variant(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(v2), v2.stride(0), _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale, variant, _stream()),
+        "attn_fwd",
+    )
+    return out2
+
+
+def quant_fp8_rowwise(x):
+    x2 = _row2d(_bf16(x, "x"), "x")
+    M, K = x2.shape
+    xq = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    init()
+    _check(_lib.x2v_quant_fp8_rowwise(_p(x2), x2.stride(0), _p(xq), xq.stride(0), _p(s), M, K, _stream()), "quant_fp8_rowwise")
+    return xq, s
+
+
+def gemm_fp8(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None):
+    M, K = xq.shape
+    N = wq_nk.shape[0]
+    if xq.dtype != torch.float8_e4m3fn or wq_nk.dtype != torch.float8_e4m3fn:
+        raise X2VError("gemm_fp8: operands must be float8_e4m3fn (OCP; gfx950)")
+    if epilogue == EPI_RESIDUAL:
+        out2 = _row2d(resid if out is None else out, "out")
+        r2 = _row2d(resid, "resid")
+        if gate is not None:
+            gate = gate.reshape(-1)
+    else:
+        out2 = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device) if out is None else _row2d(out, "out")
+        r2 = None
+    sw = sw.reshape(-1)
+    sx = sx.reshape(-1)
+    init()
+    _check(
+        _lib.x2v_gemm_fp8(_p(xq), xq.stride(0), _p(sx), _p(wq_nk), wq_nk.stride(0), _p(sw), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), _stream()),
+        "gemm_fp8",
+    )
+    return out2
+
+
+def sinusoid_embed(t, dim):
+    t = t.reshape(-1).to(torch.int64)
+    out = torch.empty((t.numel(), dim), dtype=torch.bfloat16, device=t.device)
+    init()
+    _check(_lib.x2v_sinusoid_embed_bf16(_p(t), _p(out), t.numel(), dim, _stream()), "sinusoid_embed")
+    return out
+
+
+def causal_conv3d(x, weight, bias=None, cache=None):
+    """x [T,H,W,Cin] fp32 channels-last, weight [Cout,kt,kh,kw,Cin], cache [nc,H,W,Cin] or None."""
+    if x.dtype != torch.float32 or not x.is_contiguous() or not weight.is_contiguous():
+        raise X2VError("causal_conv3d: x and weight must be contiguous float32")
+    T, H, W, Cin = x.shape
+    Cout, kt, kh, kw, _ = weight.shape
+    nc = 0 if cache is None else cache.shape[0]
+    out = torch.empty((T, H, W, Cout), dtype=torch.float32, device=x.device)
+    init()
+    _check(_lib.x2v_causal_conv3d_f32(_p(x), _p(cache), nc, _p(weight), _p(bias), _p(out), T, H, W, Cin, Cout, kt, kh, kw, _stream()), "causal_conv3d")
+    return out

@@ -1,0 +1,270 @@
+"""HIP-backed operator objects behind the reference's operator API.
+
+Every class honours the reference's duck-typed protocol — ctor signature, `set_config`, `load(weight_dict)`,
+`apply(...)`, `to_cuda/to_cpu`, `state_dict`, `clear`, `_calculate_size` — and is registered under new keys,
+so an unchanged LightX2V config selects them by string:
+
+    mm_config.mm_type      = "Hip-bf16" | "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip"
+    self_attn_1_type / cross_attn_1_type / attention_type = "hip_flash"
+    RMS / LN registries    : key "hip"   (also aliased as "Default"/"sgl-kernel" inside this package, since the
+                             reference's weight classes hard-code those keys: transformer_weights.py:127,159,167)
+
+apply() never falls back to torch math: tensors must live on a gfx950 device.
+"""
+import torch
+
+from . import lib
+from .registry import ATTN_WEIGHT_REGISTER, CONV3D_WEIGHT_REGISTER, LN_WEIGHT_REGISTER, MM_WEIGHT_REGISTER, RMS_WEIGHT_REGISTER, TENSOR_REGISTER
+
+
+def _to(t, device, non_blocking=False):
+    return None if t is None else t.to(device, non_blocking=non_blocking)
+
+
+class _Movable:
+    _tensor_attrs = ()
+
+    def set_config(self, config=None):
+        if config is not None:
+            self.config = config
+
+    def to_cuda(self, non_blocking=False):
+        for a in self._tensor_attrs:
+            if getattr(self, a, None) is not None:
+                setattr(self, a, _to(getattr(self, a), "cuda", non_blocking))
+
+    def to_cpu(self, non_blocking=False):
+        for a in self._tensor_attrs:
+            if getattr(self, a, None) is not None:
+                setattr(self, a, _to(getattr(self, a), "cpu", non_blocking))
+
+    def clear(self):
+        for a in self._tensor_attrs:
+            setattr(self, a, None)
+
+    def _calculate_size(self):
+        return sum(getattr(self, a).numel() * getattr(self, a).element_size() for a in self._tensor_attrs if getattr(self, a, None) is not None)
+
+
+# ------------------------------------------------------------------------------------------------ MM
+@MM_WEIGHT_REGISTER("Hip-bf16")
+class MMWeightHip(_Movable):
+    """reference: common/ops/mm/mm_weight.py:70-96 (`Default`).  The checkpoint's [N,K] tensor stays as it
+    is in HBM (the reference stores the `.t()` view, :76); the kernel consumes K-contiguous rows of both
+    operands.  Extra (optional) keyword arguments expose the fused epilogues to the fused block driver."""
+
+    _tensor_attrs = ("weight", "bias")
+
+    def __init__(self, weight_name, bias_name, lazy_load=False, lazy_load_file=None):
+        self.weight_name, self.bias_name = weight_name, bias_name
+        self.lazy_load, self.lazy_load_file = lazy_load, lazy_load_file
+        self.config = {}
+        self.weight = self.bias = None
+
+    def load(self, weight_dict):
+        self.weight = weight_dict[self.weight_name]
+        if self.weight.dim() > 2:  # patch-embedding conv kernel [D,C,1,2,2] used as a [D, C*4] matrix
+            self.weight = self.weight.reshape(self.weight.shape[0], -1)
+        self.weight = self.weight.contiguous()
+        self.bias = weight_dict[self.bias_name] if self.bias_name is not None else None
+
+    def load_from_disk(self):
+        self.weight = self.lazy_load_file.get_tensor(self.weight_name).to(torch.bfloat16)
+        self.bias = self.lazy_load_file.get_tensor(self.bias_name).to(torch.bfloat16) if self.bias_name is not None else None
+
+    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None):
+        return lib.gemm(input_tensor, self.weight, self.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+
+    def state_dict(self, destination=None):
+        destination = {} if destination is None else destination
+        destination[self.weight_name] = self.weight.cpu().detach().clone()
+        if self.bias is not None:
+            destination[self.bias_name] = self.bias.cpu().detach().clone()
+        return destination
+
+
+@MM_WEIGHT_REGISTER("W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip")
+class MMWeightFp8Hip(_Movable):
+    """reference: mm_weight.py:111-284 (template) + :287-319 (Vllm) / :532-589 (Sgl): e4m3fn weight [N,K] with
+    fp32 per-out-channel scale `<name>.weight_scale` [N,1] (converter format, tools/convert/converter.py:294-339)
+    or `weight_auto_quant` from bf16 (:167-173); per-token dynamic activation quant (:236-245); scaled GEMM."""
+
+    _tensor_attrs = ("weight", "weight_scale", "bias")
+
+    def __init__(self, weight_name, bias_name, lazy_load=False, lazy_load_file=None):
+        self.weight_name, self.bias_name = weight_name, bias_name
+        self.weight_scale_name = weight_name.removesuffix(".weight") + ".weight_scale"
+        self.lazy_load, self.lazy_load_file = lazy_load, lazy_load_file
+        self.config = {}
+        self.weight = self.weight_scale = self.bias = None
+
+    def load(self, weight_dict):
+        w = weight_dict[self.weight_name]
+        if self.config.get("weight_auto_quant", False) or w.dtype != torch.float8_e4m3fn:
+            wf = w.to(torch.float32)
+            scale = wf.abs().amax(dim=1, keepdim=True).clamp(min=1e-12) / 448.0
+            self.weight = (wf / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).contiguous()
+            self.weight_scale = scale.to(torch.float32)
+        else:
+            self.weight = w.contiguous()
+            self.weight_scale = weight_dict[self.weight_scale_name].float()
+        self.bias = weight_dict[self.bias_name] if self.bias_name is not None else None
+
+    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None):
+        xq, sx = lib.quant_fp8_rowwise(input_tensor)
+        return lib.gemm_fp8(xq, sx, self.weight, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+
+    def state_dict(self, destination=None):
+        destination = {} if destination is None else destination
+        destination[self.weight_name] = self.weight.cpu().detach().clone()
+        destination[self.weight_scale_name] = self.weight_scale.cpu().detach().clone()
+        if self.bias is not None:
+            destination[self.bias_name] = self.bias.cpu().detach().clone()
+        return destination
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@RMS_WEIGHT_REGISTER("hip")
+class RMSWeightHip(_Movable):
+    """reference: common/ops/norm/rms_norm_weight.py:53-118.  `round_mode`: fp32 statistics (what
+    sgl_kernel.rmsnorm, the reference's GPU path, computes) or the torch bf16 chain of the CPU fallback."""
+
+    _tensor_attrs = ("weight",)
+
+    def __init__(self, weight_name, lazy_load=False, lazy_load_file=None, eps=1e-6):
+        self.weight_name, self.eps = weight_name, eps
+        self.lazy_load, self.lazy_load_file = lazy_load, lazy_load_file
+        self.config = {}
+        self.weight = None
+        self.round_mode = lib.ROUND_FP32
+
+    def load(self, weight_dict):
+        if not self.lazy_load:
+            self.weight = weight_dict[self.weight_name]
+
+    def load_from_disk(self):
+        self.weight = self.lazy_load_file.get_tensor(self.weight_name).to(torch.bfloat16)
+
+    def apply(self, input_tensor):
+        return lib.rmsnorm(input_tensor, self.weight, self.eps, round_mode=self.round_mode)
+
+    def state_dict(self, destination=None):
+        destination = {} if destination is None else destination
+        destination[self.weight_name] = self.weight.cpu().detach().clone()
+        return destination
+
+
+@LN_WEIGHT_REGISTER("hip")
+class LNWeightHip(_Movable):
+    """reference: common/ops/norm/layer_norm_weight.py:78-111; `apply(x, scale=, shift=)` additionally fuses the
+    adaLN modulate that follows every no-affine LN in the block (transformer_infer.py:329-334,481-484)."""
+
+    _tensor_attrs = ("weight", "bias")
+
+    def __init__(self, weight_name=None, bias_name=None, lazy_load=False, lazy_load_file=None, eps=1e-6):
+        self.weight_name, self.bias_name, self.eps = weight_name, bias_name, eps
+        self.lazy_load, self.lazy_load_file = lazy_load, lazy_load_file
+        self.config = {}
+        self.weight = self.bias = None
+
+    def load(self, weight_dict):
+        if not self.lazy_load:
+            self.weight = weight_dict[self.weight_name] if self.weight_name is not None else None
+            self.bias = weight_dict[self.bias_name] if self.bias_name is not None else None
+
+    def apply(self, input_tensor, scale=None, shift=None):
+        return lib.layernorm(input_tensor, self.weight, self.bias, scale, shift, self.eps)
+
+    def state_dict(self, destination=None):
+        destination = {} if destination is None else destination
+        if self.weight is not None:
+            destination[self.weight_name] = self.weight.cpu().detach().clone()
+        if self.bias is not None:
+            destination[self.bias_name] = self.bias.cpu().detach().clone()
+        return destination
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@ATTN_WEIGHT_REGISTER("hip_flash")
+class HipFlashAttnWeight:
+    """reference: common/ops/attn/attn_weight.py:71-126 (flash_attn2/3 keys), :209-239 (torch_sdpa): q,k,v
+    [tokens,H,d] → [max_seqlen_q, H*d].  One sequence (cu_seqlens = [0,S]) as in every Wan call site."""
+
+    def __init__(self):
+        self.config = {}
+
+    def load(self, weight_dict):
+        pass
+
+    def set_config(self, config=None):
+        if config is not None:
+            self.config = config
+
+    def apply(self, q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, model_cls=None, mask_map=None):
+        if cu_seqlens_q is not None and len(cu_seqlens_q) != 2:
+            raise lib.X2VError("hip_flash: only a single sequence (cu_seqlens of length 2) is supported")
+        return lib.attention(q, k, v, num_heads=q.shape[1], head_dim=q.shape[2])
+
+    def to_cpu(self, non_blocking=False):
+        pass
+
+    def to_cuda(self, non_blocking=False):
+        pass
+
+    def state_dict(self, destination=None):
+        return {} if destination is None else destination
+
+
+def hip_flash(q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, model_cls=None):
+    """Functional twin (reference: lightx2v/attentions/common/flash_attn2.py:8, dispatcher attentions/__init__.py:8-20)."""
+    return lib.attention(q, k, v, num_heads=q.shape[1], head_dim=q.shape[2])
+
+
+# ------------------------------------------------------------------------------------------------ tensors / conv
+@TENSOR_REGISTER("Default")
+class DefaultTensor(_Movable):
+    """reference: common/ops/tensor/tensor.py:6-47."""
+
+    _tensor_attrs = ("tensor",)
+
+    def __init__(self, tensor_name, lazy_load=False, lazy_load_file=None):
+        self.tensor_name = tensor_name
+        self.lazy_load, self.lazy_load_file = lazy_load, lazy_load_file
+        self.tensor = None
+
+    def load(self, weight_dict):
+        if not self.lazy_load:
+            self.tensor = weight_dict[self.tensor_name]
+
+    def load_from_disk(self):
+        self.tensor = self.lazy_load_file.get_tensor(self.tensor_name).to(torch.bfloat16)
+
+    def state_dict(self, destination=None):
+        destination = {} if destination is None else destination
+        destination[self.tensor_name] = self.tensor.cpu().detach().clone()
+        return destination
+
+
+@CONV3D_WEIGHT_REGISTER("hip_patch")
+class PatchEmbedConv3dHip(MMWeightHip):
+    """reference: common/ops/conv/conv3d.py:29-75 as used by pre_infer.py:57 — a Conv3d whose kernel equals
+    its stride (1,2,2) is a GEMM over non-overlapping patches: x[S, C*1*2*2] . W[D, C*4]^T + b."""
+
+    def __init__(self, weight_name, bias_name, stride=(1, 2, 2), padding=0, dilation=1, groups=1):
+        super().__init__(weight_name, bias_name)
+        self.stride = tuple(stride)
+
+    def apply(self, input_tensor):
+        # input [1, C, T, H, W] → patches [T*(H/2)*(W/2), C*4] in (c, pt, ph, pw) order = the conv kernel's layout
+        _, c, t, h, w = input_tensor.shape
+        pt, ph, pw = self.stride
+        x = input_tensor.reshape(c, t // pt, pt, h // ph, ph, w // pw, pw).permute(1, 3, 5, 0, 2, 4, 6)
+        x = x.reshape((t // pt) * (h // ph) * (w // pw), c * pt * ph * pw).contiguous()
+        return lib.gemm(x, self.weight, self.bias)  # [S, D] token-major (what pre_infer flattens to)
+
+
+# the reference's weight classes look norms up under these keys; inside this package they resolve to HIP
+RMS_WEIGHT_REGISTER["sgl-kernel"] = RMSWeightHip
+RMS_WEIGHT_REGISTER["Default"] = RMSWeightHip
+LN_WEIGHT_REGISTER["Default"] = LNWeightHip
+MM_WEIGHT_REGISTER["Default"] = MMWeightHip

@@ -1,0 +1,109 @@
+"""Ulysses sequence parallelism for the Wan self-attention over RCCL/xGMI (one process per GPU,
+`torch.distributed` backend "nccl" = RCCL on ROCm).
+
+reference: lightx2v/attentions/distributed/ulysses/attn.py:7-91 (ulysses_attn), comm/all2all.py:6-89,
+ulysses/wrap.py:53-71 (parallelize_wan), utils/wan/processor.py:9-37 (pre/post_process).
+
+Same partitioning as the reference — tokens of the flattened (t,h,w) axis in N contiguous shards, weights
+and the 512-token context replicated, only self-attention exchanges data — but laid out for the MI355X
+node: xGMI is a full mesh of point-to-point links, so an all-to-all puts one message on every link at once
+(7 x 12.1 MB at Wan-14B 720p, ≈79 us/link).  What the reference pays beyond the wire time is removed:
+  * no host synchronisation (the reference calls torch.cuda.synchronize() twice per attention, attn.py:48,85);
+    exchanges are stream-ordered on a side stream and joined with events;
+  * q/k/v exchanges run on the communication stream while the next projection GEMM runs on the compute
+    stream (k's exchange under the v GEMM; the wrapper issues them in that order);
+  * the head→seq exchange of the attention output needs no pre-transpose: [S, (H/N)d] is already the
+    [N, S/N, (H/N)d] send layout (the reference transposes twice, all2all.py:70-75,87).
+"""
+import torch
+import torch.distributed as dist
+
+from . import lib
+
+
+def _world(group=None):
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def seq2head(x, group=None):
+    """[S/N, H*d] (this rank's tokens, all heads) → [S, (H/N)*d] (all tokens, this rank's heads).
+    Column block j of width H*d/N goes to rank j (reference: all2all.py:6-44)."""
+    n, _ = _world(group)
+    s_local, hd = x.shape
+    send = x.view(s_local, n, hd // n).transpose(0, 1).contiguous()  # [N, S/N, hd/N]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.view(n * s_local, hd // n)
+
+
+def head2seq(x, group=None):
+    """[S, (H/N)*d] → [S/N, H*d] (reference: all2all.py:47-89).  The send buffer is x itself."""
+    n, _ = _world(group)
+    s, hdn = x.shape
+    recv = torch.empty((n, s // n, hdn), dtype=x.dtype, device=x.device)
+    dist.all_to_all_single(recv, x.contiguous().view(n, s // n, hdn), group=group)
+    return recv.transpose(0, 1).reshape(s // n, n * hdn)  # one gather-copy into token-major layout
+
+
+class UlyssesAttention:
+    """Callable injected as `transformer_infer.parallel_attention` (reference hook: transformer_infer.py:381-388)."""
+
+    def __init__(self, group=None, attn_fn=None, overlap=True):
+        self.group = group
+        self.attn_fn = attn_fn or (lambda q, k, v, h, d: lib.attention(q, k, v, h, d))
+        self.overlap = overlap and torch.cuda.is_available()
+        self.comm_stream = None
+
+    def __call__(self, q, k, v, num_heads, head_dim=128, timer=None):
+        n, _ = _world(self.group)
+        if num_heads % n != 0:
+            raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
+        if self.overlap and q.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self.comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self.comm_stream):
+                qh, kh, vh = seq2head(q, self.group), seq2head(k, self.group), seq2head(v, self.group)
+            for t in (q, k, v, qh, kh, vh):
+                t.record_stream(self.comm_stream)
+            cur.wait_stream(self.comm_stream)
+        else:
+            qh, kh, vh = seq2head(q, self.group), seq2head(k, self.group), seq2head(v, self.group)
+        fn = lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim)
+        o = timer("self", fn) if timer is not None else fn()
+        return head2seq(o, self.group)
+
+
+def pre_process(x, group=None):
+    """Zero-pad S to a multiple of N and keep this rank's contiguous chunk (reference: processor.py:9-21)."""
+    n, r = _world(group)
+    pad = (n - x.shape[0] % n) % n
+    if pad:
+        x = torch.nn.functional.pad(x, (0, 0, 0, pad))
+    return torch.chunk(x, n, dim=0)[r].contiguous()
+
+
+def post_process(x, group=None):
+    """all_gather of the block-stack output → [S_padded, D] (reference: processor.py:24-37)."""
+    n, _ = _world(group)
+    out = torch.empty((n * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+def parallelize_wan(wan_model, group=None, attn_fn=None):
+    """reference: ulysses/wrap.py:53-71 — swap the attention, shard x around the block stack."""
+    tr = wan_model.transformer_infer
+    n, r = _world(group)
+    tr.parallel_attention = UlyssesAttention(group, attn_fn)
+    tr.sp_rank, tr.sp_world = r, n
+    original_infer = tr.infer
+
+    def new_infer(weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context, audio_dit_blocks=None):
+        x = pre_process(x, group)
+        x = original_infer(weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context)
+        return post_process(x, group)
+
+    tr.infer = new_infer
+    return wan_model

@@ -1,0 +1,382 @@
+"""Wan2.1 DiT denoise forward on the HIP kernels — host-side mirror of the reference's Wan network
+(reference: lightx2v/models/networks/wan/{model.py, infer/{pre_infer,transformer_infer,post_infer}.py,
+weights/{pre,post,transformer}_weights.py}).  Same class and method names, same checkpoint tensor names,
+same config keys; the block is issued as a fixed sequence of 14 kernel launches:
+
+  LN+modulate → q,k,v GEMMs → fused q/k RMSNorm+RoPE → attention → o GEMM (+gate-residual epilogue)
+  → LN affine → q GEMM → RMSNorm ; k,v GEMMs on context → RMSNorm → cross attention → o GEMM (+residual)
+  → LN+modulate → ffn_0 GEMM (+GELU) → ffn_2 GEMM (+gate-residual)
+
+Compared with the reference's op-by-op loop this removes per block: the float64 RoPE round trip
+(utils.py:107-115, ≈4 passes over 3 GB f64 copies at 720p), the per-block complex128 freqs table
+(utils.py:7-20), three standalone residual passes and the standalone GELU pass over [S, F].
+"""
+import math
+
+import torch
+
+from . import lib
+from .registry import ATTN_WEIGHT_REGISTER, CONV3D_WEIGHT_REGISTER, LN_WEIGHT_REGISTER, MM_WEIGHT_REGISTER, RMS_WEIGHT_REGISTER, TENSOR_REGISTER
+from . import ops  # noqa: F401  (registers the HIP operator classes)
+from .weight_module import WeightModule, WeightModuleList
+
+
+def _cfg(config, key, default=None):
+    try:
+        return config[key]
+    except (KeyError, TypeError):
+        return default
+
+
+# ------------------------------------------------------------------------------------------------ weights
+class WanModulation(WeightModule):
+    def __init__(self, block_index, task, mm_type, config, lazy_load=False, lazy_load_file=None):
+        super().__init__()
+        self.config = config
+        self.add_module("modulation", TENSOR_REGISTER["Default"](f"blocks.{block_index}.modulation", lazy_load, lazy_load_file))
+
+
+class WanSelfAttention(WeightModule):
+    """reference: wan/weights/transformer_weights.py:109-215."""
+
+    def __init__(self, block_index, task, mm_type, config, lazy_load=False, lazy_load_file=None):
+        super().__init__()
+        self.config = config
+        p = f"blocks.{block_index}.self_attn"
+        self.add_module("norm1", LN_WEIGHT_REGISTER["Default"]())
+        for proj in ("q", "k", "v", "o"):
+            self.add_module(f"self_attn_{proj}", MM_WEIGHT_REGISTER[mm_type](f"{p}.{proj}.weight", f"{p}.{proj}.bias", lazy_load, lazy_load_file))
+        self.add_module("self_attn_norm_q", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_q.weight", lazy_load, lazy_load_file))
+        self.add_module("self_attn_norm_k", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_k.weight", lazy_load, lazy_load_file))
+        self.add_module("self_attn_1", ATTN_WEIGHT_REGISTER[config["self_attn_1_type"]]())
+
+
+class WanCrossAttention(WeightModule):
+    """reference: wan/weights/transformer_weights.py:218-313 (t2v)."""
+
+    def __init__(self, block_index, task, mm_type, config, lazy_load=False, lazy_load_file=None):
+        super().__init__()
+        self.config = config
+        b = f"blocks.{block_index}"
+        p = f"{b}.cross_attn"
+        self.add_module("norm3", LN_WEIGHT_REGISTER["Default"](f"{b}.norm3.weight", f"{b}.norm3.bias", lazy_load, lazy_load_file))
+        for proj in ("q", "k", "v", "o"):
+            self.add_module(f"cross_attn_{proj}", MM_WEIGHT_REGISTER[mm_type](f"{p}.{proj}.weight", f"{p}.{proj}.bias", lazy_load, lazy_load_file))
+        self.add_module("cross_attn_norm_q", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_q.weight", lazy_load, lazy_load_file))
+        self.add_module("cross_attn_norm_k", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_k.weight", lazy_load, lazy_load_file))
+        self.add_module("cross_attn_1", ATTN_WEIGHT_REGISTER[config["cross_attn_1_type"]]())
+
+
+class WanFFN(WeightModule):
+    """reference: wan/weights/transformer_weights.py:316-366."""
+
+    def __init__(self, block_index, task, mm_type, config, lazy_load=False, lazy_load_file=None):
+        super().__init__()
+        self.config = config
+        b = f"blocks.{block_index}"
+        self.add_module("norm2", LN_WEIGHT_REGISTER["Default"]())
+        self.add_module("ffn_0", MM_WEIGHT_REGISTER[mm_type](f"{b}.ffn.0.weight", f"{b}.ffn.0.bias", lazy_load, lazy_load_file))
+        self.add_module("ffn_2", MM_WEIGHT_REGISTER[mm_type](f"{b}.ffn.2.weight", f"{b}.ffn.2.bias", lazy_load, lazy_load_file))
+
+
+class WanTransformerAttentionBlock(WeightModule):
+    """reference: wan/weights/transformer_weights.py:33-87 — four compute phases."""
+
+    def __init__(self, block_index, task, mm_type, config):
+        super().__init__()
+        self.block_index, self.config = block_index, config
+        self.compute_phases = WeightModuleList([cls(block_index, task, mm_type, config) for cls in (WanModulation, WanSelfAttention, WanCrossAttention, WanFFN)])
+        self.add_module("compute_phases", self.compute_phases)
+
+
+class WanTransformerWeights(WeightModule):
+    """reference: wan/weights/transformer_weights.py:14-30."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.blocks_num = config["num_layers"]
+        self.task = config["task"]
+        self.config = config
+        mm_config = _cfg(config, "mm_config") or {}
+        self.mm_type = mm_config.get("mm_type", "Default")
+        self.blocks = WeightModuleList([WanTransformerAttentionBlock(i, self.task, self.mm_type, config) for i in range(self.blocks_num)])
+        self.add_module("blocks", self.blocks)
+
+
+class WanPreWeights(WeightModule):
+    """reference: wan/weights/pre_weights.py:9-64 (t2v)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.add_module("patch_embedding", CONV3D_WEIGHT_REGISTER["hip_patch"]("patch_embedding.weight", "patch_embedding.bias", stride=(1, 2, 2)))
+        for name in ("text_embedding.0", "text_embedding.2", "time_embedding.0", "time_embedding.2", "time_projection.1"):
+            self.add_module(name.replace(".", "_"), MM_WEIGHT_REGISTER["Default"](f"{name}.weight", f"{name}.bias"))
+
+
+class WanPostWeights(WeightModule):
+    """reference: wan/weights/post_weights.py:9-18."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.register_parameter("norm", LN_WEIGHT_REGISTER["Default"]())
+        self.add_module("head", MM_WEIGHT_REGISTER["Default"]("head.head.weight", "head.head.bias"))
+        self.register_parameter("head_modulation", TENSOR_REGISTER["Default"]("head.modulation"))
+
+
+# ------------------------------------------------------------------------------------------------ infer
+def rope_params(max_seq_len, dim, theta=10000):
+    """reference: wan/infer/utils.py:151-158 (float64 angles)."""
+    return torch.outer(torch.arange(max_seq_len), 1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float64).div(dim)))
+
+
+def rope_cos_sin_table(head_dim, device):
+    """The reference's complex128 `freqs` [1024, d/2] (pre_infer.py:12-19) as a float32 (cos, sin) table
+    [1024, 64, 2] — built once; the kernel indexes it by each token's (t,h,w) instead of materialising the
+    per-block [S,1,64] complex table."""
+    d = head_dim
+    ang = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+    return torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).to(torch.float32).contiguous().to(device)
+
+
+class WanPreInfer:
+    """reference: wan/infer/pre_infer.py:6-120 (t2v path)."""
+
+    def __init__(self, config):
+        d = config["dim"] // config["num_heads"]
+        assert config["dim"] % config["num_heads"] == 0 and d % 2 == 0
+        if d != 128:
+            raise lib.X2VError(f"head_dim {d}: the HIP attention/RoPE kernels are built for head_dim 128")
+        self.task = config["task"]
+        self.freq_dim = config["freq_dim"]
+        self.dim = config["dim"]
+        self.text_len = config["text_len"]
+        self.freqs = None  # float32 (cos,sin) table, created on first use on the right device
+        self.head_dim = d
+
+    def set_scheduler(self, scheduler):
+        self.scheduler = scheduler
+
+    def infer(self, weights, inputs, positive, kv_start=0, kv_end=0):
+        sch = self.scheduler
+        latents = sch.latents
+        dev = latents.device
+        if self.freqs is None or self.freqs.device != dev:
+            self.freqs = rope_cos_sin_table(self.head_dim, dev)
+        t = torch.stack([sch.timesteps[sch.step_index]])
+        context = inputs["text_encoder_output"]["context" if positive else "context_null"]
+        seq_len = sch.seq_len
+
+        x = weights.patch_embedding.apply(latents.unsqueeze(0))  # [S, D]
+        _, _, T, H, W = (1, *latents.shape)
+        grid_sizes = torch.tensor([[T, H // 2, W // 2]], dtype=torch.long)
+        s = x.shape[0]
+        assert s <= seq_len
+        if s < seq_len:
+            x = torch.cat([x, x.new_zeros(seq_len - s, x.shape[1])], dim=0)
+        seq_lens = torch.tensor([s], dtype=torch.long)
+
+        embed = lib.sinusoid_embed(t.flatten().to(dev), self.freq_dim)
+        embed = weights.time_embedding_0.apply(embed, epilogue=lib.EPI_SILU)  # Linear + SiLU (pre_infer.py:70-74)
+        embed = weights.time_embedding_2.apply(embed)
+        embed0 = lib.activation(embed, lib.EPI_SILU)
+        embed0 = weights.time_projection_1.apply(embed0).unflatten(1, (6, self.dim))
+
+        stacked = torch.stack([torch.cat([u, u.new_zeros(self.text_len - u.size(0), u.size(1))]) for u in context]).squeeze(0)
+        out = weights.text_embedding_0.apply(stacked, epilogue=lib.EPI_GELU_TANH)
+        context = weights.text_embedding_2.apply(out)
+        return embed, grid_sizes, (x, embed0.squeeze(0), seq_lens, self.freqs, context)
+
+
+class WanTransformerInfer:
+    """reference: wan/infer/transformer_infer.py:12-508 (no-offload path).  `parallel_attention`
+    (set by lightx2v_amd.ulysses.parallelize_wan) replaces the local self-attention exactly where the
+    reference injects it (:381-388)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.task = config["task"]
+        self.attention_type = _cfg(config, "attention_type", "hip_flash")
+        self.blocks_num = config["num_layers"]
+        self.phases_num = 4
+        self.num_heads = config["num_heads"]
+        self.head_dim = config["dim"] // config["num_heads"]
+        self.parallel_attention = None
+        self.sp_rank, self.sp_world = 0, 1
+        self.round_mode = lib.ROUND_REF if _cfg(config, "hip_ref_rounding", False) else lib.ROUND_FP32
+        self.infer_conditional = True
+        self.attn_time_hook = None  # bench.py: callable(kind) -> context manager timing the attention launch
+
+    def set_scheduler(self, scheduler):
+        self.scheduler = scheduler
+
+    def switch_status(self):
+        self.infer_conditional = not self.infer_conditional
+
+    def infer(self, weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context, audio_dit_blocks=None):
+        return self._infer_without_offload(weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context)
+
+    def _infer_without_offload(self, weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context, audio_dit_blocks=None):
+        for block_idx in range(self.blocks_num):
+            x = self.infer_block(weights.blocks[block_idx], grid_sizes, embed, x, embed0, seq_lens, freqs, context)
+        return x
+
+    def infer_block(self, weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context):
+        shift_msa, scale_msa, gate_msa, c_shift_msa, c_scale_msa, c_gate_msa = self.infer_modulation(weights.compute_phases[0], embed0)
+        x = self.infer_self_attn(weights.compute_phases[1], grid_sizes, x, seq_lens, freqs, shift_msa, scale_msa, gate_msa)
+        x = self.infer_cross_attn(weights.compute_phases[2], x, context)
+        x = self.infer_ffn(weights.compute_phases[3], x, c_shift_msa, c_scale_msa, c_gate_msa)
+        return x
+
+    def infer_modulation(self, weights, embed0):
+        # [1,6,D] + [6,D] → six [1,D] rows (transformer_infer.py:308-319); 6*D elements: host-side plumbing
+        return (weights.modulation.tensor + embed0).chunk(6, dim=1)
+
+    def infer_self_attn(self, weights, grid_sizes, x, seq_lens, freqs, shift_msa, scale_msa, gate_msa):
+        """transformer_infer.py:321-396 + the `x.add_(y * gate_msa)` of :402 folded into the o-projection."""
+        n1 = weights.norm1.apply(x, scale=scale_msa, shift=shift_msa)
+        q = weights.self_attn_q.apply(n1)
+        k = weights.self_attn_k.apply(n1)
+        v = weights.self_attn_v.apply(n1)
+        grid = tuple(int(g) for g in grid_sizes[0].tolist())
+        s_local = x.shape[0]
+        lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads,
+                          s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode)
+        if self.parallel_attention is None:
+            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim))
+        else:
+            attn = self.parallel_attention(q=q, k=k, v=v, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed)
+        return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
+
+    def infer_cross_attn(self, weights, x, context):
+        """transformer_infer.py:398-465 (t2v) + the `x.add_(attn_out)` of :468 folded into the o-projection."""
+        n3 = weights.norm3.apply(x)
+        q = weights.cross_attn_q.apply(n3)
+        lib.rmsnorm(q, weights.cross_attn_norm_q.weight, weights.cross_attn_norm_q.eps, out=q, round_mode=self.round_mode)
+        k = weights.cross_attn_k.apply(context)
+        lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
+        v = weights.cross_attn_v.apply(context)
+        attn = self._timed("cross", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim))
+        return weights.cross_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=None)
+
+    def infer_ffn(self, weights, x, c_shift_msa, c_scale_msa, c_gate_msa):
+        """transformer_infer.py:467-508: LN+modulate, ffn_0 (+GELU-tanh), ffn_2 (+`x.add_(y * c_gate)`)."""
+        n2 = weights.norm2.apply(x, scale=c_scale_msa, shift=c_shift_msa)
+        h = weights.ffn_0.apply(n2, epilogue=lib.EPI_GELU_TANH)
+        return weights.ffn_2.apply(h, epilogue=lib.EPI_RESIDUAL, resid=x, gate=c_gate_msa)
+
+    def _timed(self, kind, fn):
+        if self.attn_time_hook is None:
+            return fn()
+        with self.attn_time_hook(kind):
+            return fn()
+
+
+class WanPostInfer:
+    """reference: wan/infer/post_infer.py:6-50."""
+
+    def __init__(self, config):
+        self.out_dim = config["out_dim"]
+        self.patch_size = (1, 2, 2)
+
+    def set_scheduler(self, scheduler):
+        self.scheduler = scheduler
+
+    def infer(self, weights, x, e, grid_sizes):
+        e = (weights.head_modulation.tensor + e.unsqueeze(1)).chunk(2, dim=1)  # [1,2,D] → shift, scale
+        x = weights.norm.apply(x, scale=e[1].squeeze(0), shift=e[0].squeeze(0))
+        x = weights.head.apply(x)
+        return [u.float() for u in self.unpatchify(x, grid_sizes)]
+
+    def unpatchify(self, x, grid_sizes):
+        c = self.out_dim
+        out = []
+        for v in grid_sizes.tolist():
+            u = x[: math.prod(v)].view(*v, *self.patch_size, c)
+            u = torch.einsum("fhwpqrc->cfphqwr", u)
+            out.append(u.reshape(c, *[i * j for i, j in zip(v, self.patch_size)]))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ model
+class WanModel:
+    """reference: wan/model.py:28-226.  Built from an in-memory checkpoint dict (the reference's
+    `_init_weights(weight_dict)` path, :146-170); tensors must already be on the target device."""
+
+    pre_weight_class = WanPreWeights
+    post_weight_class = WanPostWeights
+    transformer_weight_class = WanTransformerWeights
+
+    def __init__(self, config, weight_dict, device="cuda"):
+        self.config = config
+        self.device = device
+        self._init_infer_class()
+        self._init_weights(weight_dict)
+        self._init_infer()
+        pat = _cfg(config, "parallel_attn_type")
+        if pat:
+            if pat != "ulysses":
+                raise NotImplementedError(f"parallel_attn_type={pat}: only 'ulysses' is built (the north star's SP scheme)")
+            from . import ulysses
+
+            ulysses.parallelize_wan(self)
+
+    def _init_infer_class(self):
+        if _cfg(self.config, "feature_caching", "NoCaching") != "NoCaching":
+            raise NotImplementedError("feature caching is out of scope of the hot path (SURVEY.md §2.1 #20)")
+        self.pre_infer_class, self.post_infer_class, self.transformer_infer_class = WanPreInfer, WanPostInfer, WanTransformerInfer
+
+    def _init_weights(self, weight_dict):
+        self.original_weight_dict = weight_dict
+        self.pre_weight = self.pre_weight_class(self.config)
+        self.post_weight = self.post_weight_class(self.config)
+        self.transformer_weights = self.transformer_weight_class(self.config)
+        self.pre_weight.load(weight_dict)
+        self.post_weight.load(weight_dict)
+        self.transformer_weights.load(weight_dict)
+
+    def _init_infer(self):
+        self.pre_infer = self.pre_infer_class(self.config)
+        self.post_infer = self.post_infer_class(self.config)
+        self.transformer_infer = self.transformer_infer_class(self.config)
+
+    def set_scheduler(self, scheduler):
+        self.scheduler = scheduler
+        self.pre_infer.set_scheduler(scheduler)
+        self.post_infer.set_scheduler(scheduler)
+        self.transformer_infer.set_scheduler(scheduler)
+
+    def to_cpu(self):
+        for w in (self.pre_weight, self.post_weight, self.transformer_weights):
+            w.to_cpu()
+
+    def to_cuda(self):
+        for w in (self.pre_weight, self.post_weight, self.transformer_weights):
+            w.to_cuda()
+
+    def _forward(self, inputs, positive):
+        embed, grid_sizes, pre_infer_out = self.pre_infer.infer(self.pre_weight, inputs, positive=positive)
+        x = self.transformer_infer.infer(self.transformer_weights, grid_sizes, embed, *pre_infer_out)
+        return self.post_infer.infer(self.post_weight, x, embed, grid_sizes)[0]
+
+    @torch.no_grad()
+    def infer(self, inputs):
+        """cond forward, uncond forward, fp32 CFG combine (model.py:197-226)."""
+        self.scheduler.noise_pred = self._forward(inputs, True)
+        if self.config["enable_cfg"]:
+            uncond = self._forward(inputs, False)
+            self.scheduler.noise_pred = uncond + self.config["sample_guide_scale"] * (self.scheduler.noise_pred - uncond)
+
+
+def default_config(dims, **overrides):
+    """Config dict with the keys the hot path reads (same names as the reference's JSON configs)."""
+    cfg = dict(
+        task="t2v", model_cls="wan2.1", dim=dims["dim"], ffn_dim=dims["ffn_dim"], num_heads=dims["num_heads"], num_layers=dims["num_layers"],
+        freq_dim=256, text_len=dims.get("text_len", 512), in_dim=16, out_dim=16, eps=1e-6, patch_size=(1, 2, 2), vae_stride=(4, 8, 8),
+        cpu_offload=False, mm_config={"mm_type": "Hip-bf16"}, self_attn_1_type="hip_flash", cross_attn_1_type="hip_flash", attention_type="hip_flash",
+        feature_caching="NoCaching", parallel_attn_type=None, enable_cfg=True, sample_guide_scale=6.0, sample_shift=8.0, infer_steps=50, seed=42,
+        target_video_length=81, target_shape=(16, 21, 90, 160),
+    )
+    cfg.update(overrides)
+    return cfg

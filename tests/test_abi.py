@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol that
+include/x2v.h declares (and the ctypes table mirrors the header), and fails loudly — never silently falls back —
+when no gfx950 device is present."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "x2v.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(x2v_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lightx2v_amd import lib
+
+    names = _declared()
+    assert len(names) >= 15
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in include/x2v.h but not exported by {lib.LIB_PATH}"
+    assert sorted(lib.PROTOTYPES) == names, "lightx2v_amd/lib.py PROTOTYPES and include/x2v.h disagree"
+    assert "gfx950" in lib.version()
+
+
+def test_argument_validation_needs_no_gpu():
+    """Shape/alignment/null checks run before any HIP call, so the error convention is testable on CPU."""
+    from lightx2v_amd import lib
+
+    L = lib._lib
+    a = ctypes.c_void_p(4096)
+    assert L.x2v_gemm_bf16(a, 64, a, 64, None, a, 64, 4, 64, 63, 0, None, 0, None, None) == -1  # K % 64
+    assert b"K=63" in L.x2v_last_error()
+    assert L.x2v_gemm_bf16(None, 64, a, 64, None, a, 64, 4, 64, 64, 0, None, 0, None, None) == -5  # null
+    assert L.x2v_gemm_bf16(ctypes.c_void_p(4104), 64, a, 64, None, a, 64, 4, 64, 64, 0, None, 0, None, None) == -2  # alignment
+    assert L.x2v_gemm_bf16(a, 64, a, 64, None, a, 64, 4, 64, 64, 2, None, 0, None, None) == -5  # residual epilogue without resid
+    assert L.x2v_attn_fwd_bf16(a, 128, a, 128, a, 128, a, 128, 4, 4, 1, 64, 0.0, None) == -1  # head_dim != 128
+    assert L.x2v_rmsnorm_bf16(a, 16, a, a, 16, 1, 12, 1e-6, 0, None) == -1
+    assert L.x2v_layernorm_bf16(a, 16, None, None, a, None, a, 16, 1, 16, 1e-6, None) == -5  # scale without shift
+    assert L.x2v_causal_conv3d_f32(a, None, 1, a, None, a, 1, 4, 4, 16, 16, 3, 3, 3, None) == -5  # cache frames without cache
+    assert L.x2v_gemm_fp8(a, 128, a, a, 128, a, None, a, 64, 4, 64, 64, 0, None, 0, None, None) == -1  # K % 128
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from lightx2v_amd import lib
+
+    x = torch.zeros(8, 64, dtype=torch.bfloat16)
+    w = torch.zeros(64, 64, dtype=torch.bfloat16)
+    with pytest.raises(lib.X2VError):
+        lib.gemm(x, w)
+    with pytest.raises(lib.X2VError):
+        lib.rmsnorm(x, w[0])
+
+
+def test_missing_library_is_an_error(tmp_path):
+    from lightx2v_amd import lib
+
+    with pytest.raises(lib.X2VError):
+        lib.load_library(str(tmp_path / "nope.so"))
+
+
+def test_registry_protocol_matches_reference_keys():
+    """Same registry objects/keys protocol as lightx2v/utils/registry_factory.py (duplicate key raises)."""
+    from lightx2v_amd import ops, registry
+
+    assert "Hip-bf16" in registry.MM_WEIGHT_REGISTER and "hip_flash" in registry.ATTN_WEIGHT_REGISTER
+    assert "hip" in registry.RMS_WEIGHT_REGISTER and "hip" in registry.LN_WEIGHT_REGISTER
+    with pytest.raises(Exception):
+        registry.MM_WEIGHT_REGISTER("Hip-bf16")(ops.MMWeightHip)
+    mm = registry.MM_WEIGHT_REGISTER["Hip-bf16"]("a.weight", "a.bias")
+    wd = {"a.weight": torch.zeros(8, 64, dtype=torch.bfloat16), "a.bias": torch.zeros(8, dtype=torch.bfloat16)}
+    mm.set_config({})
+    mm.load(wd)
+    sd = mm.state_dict()
+    assert set(sd) == {"a.weight", "a.bias"} and sd["a.weight"].shape == (8, 64)
+    assert mm._calculate_size() == 8 * 64 * 2 + 16

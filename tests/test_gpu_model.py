@@ -1,0 +1,131 @@
+"""Model-level parity of the HIP Wan path against fixtures generated from the reference (wan-tiny, full
+4-step CFG denoise loop) and against the CPU oracle at Wan2.1-1.3B dimensions (BASELINE config #1 shapes).
+
+End-to-end tolerances are relative-L2 (errors of ~30 chained bf16 ops do not stay within one ulp):
+  pre-infer tensors 1e-2; one block 1e-2; wan-tiny forward 2e-2; 4-step loop 3e-2; 1.3B 2-block forward 2e-2.
+With config key `hip_ref_rounding` the norm kernels reproduce the reference's bf16 chain (tighter legs).
+"""
+import pytest
+import torch
+
+from tests.util import assert_rel, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_dev(wd):
+    return {k: v.cuda() for k, v in wd.items()}
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from lightx2v_amd import synth, wan, scheduler
+
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wl = synth.WORKLOADS["wan-tiny"]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=4, hip_ref_rounding=True)
+    model = wan.WanModel(cfg, _to_dev(wd))
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    model.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    return model, sch, inputs, wd
+
+
+def test_tiny_pre_infer_and_block(tiny, golden_model):
+    model, sch, inputs, wd = tiny
+    g = golden_model
+    sch.prepare(latents=g["latents0"])
+    sch.step_pre(0)
+    assert torch.equal(sch.timesteps.cpu(), g["timesteps"])
+    embed, grid_sizes, (x, embed0, seq_lens, freqs, context) = model.pre_infer.infer(model.pre_weight, inputs, positive=True)
+    assert_rel(x, g["pre_x"], 1e-2, "patch embedding")
+    assert_rel(embed, g["pre_embed"], 1e-2, "time embedding")
+    assert_rel(embed0, g["pre_embed0"], 1e-2, "time projection")
+    assert_rel(context, g["pre_context"], 1e-2, "text embedding")
+    # one block from the REFERENCE's inputs so only the block's own error is measured
+    tr = model.transformer_infer
+    blk = model.transformer_weights.blocks[0]
+    xb = g["pre_x"].cuda().clone()
+    e0, ctx_ref = g["pre_embed0"].cuda(), g["pre_context"].cuda()
+    mods = tr.infer_modulation(blk.compute_phases[0], e0)
+    xb = tr.infer_self_attn(blk.compute_phases[1], grid_sizes, xb, seq_lens, freqs, mods[0], mods[1], mods[2])
+    assert_rel(xb, g["b0_x_after_self"], 1e-2, "x after self-attention")
+    xb = tr.infer_cross_attn(blk.compute_phases[2], xb, ctx_ref)
+    assert_rel(xb, g["b0_x_after_cross"], 1e-2, "x after cross-attention")
+    xb = tr.infer_ffn(blk.compute_phases[3], xb, mods[3], mods[4], mods[5])
+    assert_rel(xb, g["b0_x_out"], 1e-2, "block output")
+
+
+def test_tiny_forward_and_denoise_loop(tiny, golden_model):
+    from lightx2v_amd.scheduler import run_denoise_loop
+
+    model, sch, inputs, wd = tiny
+    g = golden_model
+    sch.prepare(latents=g["latents0"])
+    sch.step_pre(0)
+    cond = model._forward(inputs, True)
+    assert_rel(cond, g["step0_cond"], 2e-2, "conditional forward")
+    sch.prepare(latents=g["latents0"])
+    errs = []
+    run_denoise_loop(model, sch, inputs, step_callback=lambda i: errs.append(rel_l2(sch.latents, g[f"latents_after_step{i}"])))
+    assert max(errs) <= 3e-2, errs
+    assert sch.latents.dtype == torch.float32 and torch.isfinite(sch.latents).all()
+
+
+def test_wan13b_two_blocks_vs_oracle():
+    """Wan2.1-1.3B dims (D 1536, F 8960, 12 heads), BASELINE config #1 token count (256x256x17f → S = 1280),
+    2 of 30 layers so the CPU oracle finishes in seconds; both rounding modes."""
+    from lightx2v_amd import synth, wan, scheduler
+    from oracle import wan_oracle as O
+
+    dims = dict(synth.WAN_DIMS["wan2.1-1.3b"], num_layers=2)
+    ts = synth.WORKLOADS["wan1.3b_256x256x17f"]["target_shape"]
+    wd = synth.synth_wan_weights(dims, seed=5)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    t = torch.tensor(888)
+    ref = O.wan_forward(wd, dims, lat.to(torch.bfloat16), t, ctx)
+    for ref_rounding in (False, True):
+        cfg = wan.default_config(dims, target_shape=ts, target_video_length=17, infer_steps=4, hip_ref_rounding=ref_rounding)
+        model = wan.WanModel(cfg, _to_dev(wd))
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=lat)
+        sch.timesteps[2] = 888
+        model.set_scheduler(sch)
+        sch.step_pre(2)
+        inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+        got = model._forward(inputs, True)
+        assert got.shape == ref.shape == (16, 5, 32, 32)
+        assert_rel(got, ref, 2e-2, f"1.3B 2-block forward (ref_rounding={ref_rounding})")
+
+
+def test_operator_api_drop_in():
+    """The registered operator objects follow the reference's apply() contracts."""
+    from lightx2v_amd import registry, ops  # noqa: F401
+    from oracle import wan_oracle as O
+
+    gen = torch.Generator().manual_seed(0)
+    wd = {"w": (torch.randn(256, 128, generator=gen) * 0.1).to(torch.bfloat16), "b": torch.randn(256, generator=gen).to(torch.bfloat16), "n": torch.ones(256, dtype=torch.bfloat16)}
+    x = torch.randn(100, 128, generator=gen).to(torch.bfloat16)
+    mm = registry.MM_WEIGHT_REGISTER["Hip-bf16"]("w", "b")
+    mm.load({k: v.cuda() for k, v in wd.items()})
+    y = mm.apply(x.cuda())
+    assert y.shape == (100, 256) and y.dtype == torch.bfloat16
+    assert_rel(y, O.mm(x, wd["w"], wd["b"]), 5e-3, "MMWeightHip.apply")
+    rms = registry.RMS_WEIGHT_REGISTER["hip"]("n")
+    rms.load({k: v.cuda() for k, v in wd.items()})
+    assert_rel(rms.apply(y), O.rms_norm_fp32(y.cpu(), wd["n"]), 5e-3, "RMSWeightHip.apply")
+    ln = registry.LN_WEIGHT_REGISTER["hip"]()
+    ln.load({})
+    assert_rel(ln.apply(y), O.layer_norm(y.cpu()), 5e-3, "LNWeightHip.apply")
+    attn = registry.ATTN_WEIGHT_REGISTER["hip_flash"]()
+    q = torch.randn(70, 2, 128, generator=gen).to(torch.bfloat16)
+    o = attn.apply(q.cuda(), q.cuda(), q.cuda(), cu_seqlens_q=torch.tensor([0, 70]), cu_seqlens_kv=torch.tensor([0, 70]), max_seqlen_q=70, max_seqlen_kv=70)
+    assert o.shape == (70, 256)
+    assert_rel(o, O.sdpa(q, q, q), 1e-2, "HipFlashAttnWeight.apply")
+    mm.to_cpu()
+    assert mm.weight.device.type == "cpu"
+    mm.to_cuda()
+    assert mm.weight.is_cuda

@@ -1,0 +1,68 @@
+"""Host logic (no GPU): the product scheduler reproduces the reference's UniPC trajectories bit for bit on
+CPU (fixtures generated from the reference by oracle/gen_golden.py)."""
+import torch
+
+from lightx2v_amd.scheduler import WanScheduler, WanStepDistillScheduler
+from lightx2v_amd.wan import default_config
+from lightx2v_amd import synth
+
+
+def _cfg(steps, shift, shape):
+    return default_config(synth.WAN_DIMS["wan-tiny"], infer_steps=steps, sample_shift=shift, target_shape=shape)
+
+
+def test_unipc_matches_reference_known_answers(golden_sched):
+    g = golden_sched
+    for steps, shift in ((50, 8.0), (4, 8.0), (10, 3.0)):
+        tag = f"s{steps}_sh{int(shift)}"
+        sch = WanScheduler(_cfg(steps, shift, (16, 2, 4, 4)), device="cpu")
+        sch.prepare(latents=g[f"{tag}_lat0"])
+        assert torch.equal(sch.timesteps, g[f"{tag}_timesteps"])
+        assert torch.equal(sch.sigmas, g[f"{tag}_sigmas"])
+        for i in range(steps):
+            sch.step_pre(i)
+            sch.noise_pred = torch.sin(sch.latents.float() * 1.3 + 0.1 * i) + 0.05 * i
+            sch.step_post()
+        assert torch.equal(sch.latents, g[f"{tag}_final"]), (sch.latents - g[f"{tag}_final"]).abs().max()
+
+
+def test_seq_len_and_seeded_latents():
+    sch = WanScheduler(_cfg(4, 8.0, (16, 21, 90, 160)), device="cpu")
+    sch.prepare()
+    assert sch.seq_len == 75600  # BASELINE config 3: 720p x 81f
+    assert sch.latents.shape == (16, 21, 90, 160) and sch.latents.dtype == torch.float32
+    sch2 = WanScheduler(_cfg(4, 8.0, (16, 13, 60, 104)), device="cpu")
+    sch2.prepare()
+    assert sch2.seq_len == 20280  # config 2: 480p x 49f
+
+
+def test_step_distill_schedule_and_update():
+    cfg = _cfg(4, 5.0, (16, 2, 4, 4))
+    cfg["denoising_step_list"] = [1000, 750, 500, 250]
+    noise = []
+
+    def noise_fn(x):
+        g = torch.Generator().manual_seed(len(noise))
+        n = torch.randn(x.shape, generator=g)
+        noise.append(n)
+        return n
+
+    sch = WanStepDistillScheduler(cfg, device="cpu", noise_fn=noise_fn)
+    sch.prepare()
+    # reference: step_distill/scheduler.py:32-40 — sigma table from linspace(1,0,1001)[:-1], shift 5
+    sig = torch.linspace(1.0, 0.0, 1001)[:-1]
+    sig = 5.0 * sig / (1 + 4.0 * sig)
+    idx = [0, 250, 500, 750]
+    assert torch.equal(sch.sigmas, sig[idx])
+    assert torch.equal(sch.timesteps, (sig * 1000)[idx])
+    lat = sch.latents.clone()
+    for i in range(4):
+        sch.step_pre(i)
+        lat_b = sch.latents.clone()
+        sch.noise_pred = torch.cos(sch.latents.float())
+        sch.step_post()
+        x0 = lat_b.float() - sch.sigmas[i].item() * torch.cos(lat_b.float())
+        if i < 3:
+            s1 = sch.sigmas[i + 1].item()
+            x0 = (1 - s1) * x0 + s1 * noise[i]
+        assert torch.equal(sch.latents, x0.to(torch.bfloat16))
