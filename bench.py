@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""bench.py — denoise-step latency and video frames/sec of the Wan2.1 DiT hot path on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W                     (1 GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+                                                                     (Ulysses sequence parallel over RCCL/xGMI)
+
+A "step" = one full denoise step of the reference loop (default_runner.py:97-114): scheduler.step_pre →
+WanModel.infer (conditional + unconditional forward, fp32 CFG combine) → scheduler.step_post, on synthetic
+latents/context of the BASELINE shape with seeded random weights of the named architecture (no checkpoints or
+prompts exist offline).  Everything is resident in HBM before the timed region.
+
+Workload (config.workload): "wan14b_720px81f" = Wan2.1-T2V-14B bf16, 720p x 81 frames — the configuration
+BASELINE.json's metric is quoted on; it fits one 288 GB MI355X (28 GB weights + <10 GB activations).
+N > 1 shards the SAME video across ranks (strong scaling).
+
+Output: ONE JSON line on rank 0.  value = video frames/sec = frames / (infer_steps x step latency), denoise
+loop only (VAE decode excluded).  `roofline` is for the dominant kernel (self-attention forward:
+72 % of the step's FLOPs at 720p); `cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on
+a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="wan14b_720px81f")
+    ap.add_argument("--infer-steps", type=int, default=50, help="length of the full denoise schedule (frames/sec denominator)")
+    ap.add_argument("--no-cfg", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
+    return ap.parse_args()
+
+
+def step_flops(dims, S, text_len, cfg_forwards):
+    """Algorithmic FLOPs of one denoise step: per block GEMM = 12 S D^2 + 4 Lc D^2 + 4 S D F,
+    ATTN = 4 S^2 D + 4 S Lc D."""
+    D, F, L = dims["dim"], dims["ffn_dim"], dims["num_layers"]
+    gemm = 12 * S * D * D + 4 * text_len * D * D + 4 * S * D * F
+    attn = 4 * S * S * D + 4 * S * text_len * D
+    return L * (gemm + attn) * cfg_forwards, L * attn * cfg_forwards
+
+
+class AttnTimer:
+    """HIP-event timing of every self-attention launch on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, kind):
+        if not self.enabled or kind != "self":
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.pairs.append((a, b))
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+
+def cpu_baseline(dims, S_full, text_len, frames, infer_steps, cfg_forwards, budget_s):
+    """Times the CPU oracle (oracle/wan_oracle.py, a port of the reference's CPU path: torch bf16 addmm + torch_sdpa)
+    on a bounded sample: ONE transformer block of the workload's architecture at S_sample tokens, repeated for about
+    `budget_s` seconds; scaled to a full step by algorithmic FLOPs.  Baseline only — never the thing shipped."""
+    from lightx2v_amd import synth
+    from oracle import wan_oracle as O
+
+    threads = torch.get_num_threads()
+    d1 = dict(dims, num_layers=1)
+    wd = synth.synth_wan_weights(d1, seed=1)
+    S_s = 1024
+    grid = (4, 16, 16)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(S_s, dims["dim"], generator=g).to(torch.bfloat16)
+    embed0 = (torch.randn(6, dims["dim"], generator=g) * 0.1).to(torch.bfloat16)
+    context = torch.randn(text_len, dims["dim"], generator=g).to(torch.bfloat16)
+    freqs = O.rope_freqs_table(128)
+    O.wan_block(wd, 0, d1, grid, x.clone(), embed0, freqs, context)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.wan_block(wd, 0, d1, grid, x.clone(), embed0, freqs, context)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200:
+            break
+    sec_per_block = el / n
+    flop_sample, _ = step_flops(d1, S_s, text_len, 1)
+    flop_step, _ = step_flops(dims, S_full, text_len, cfg_forwards)
+    est_step_s = sec_per_block * flop_step / flop_sample
+    return {
+        "value": frames / (infer_steps * est_step_s),
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "ms_per_step_est": est_step_s * 1e3,
+        "sample": f"oracle wan_block (reference CPU path restated: torch bf16 addmm + torch_sdpa), 1 block of {dims['dim']}d/{dims['num_heads']}h at S={S_s}, "
+        f"{n} reps in {el:.1f}s ({sec_per_block * 1e3:.0f} ms/block, {flop_sample / sec_per_block / 1e12:.2f} TFLOP/s); scaled to the full step by algorithmic FLOPs "
+        f"(x{flop_step / flop_sample:.0f}; attention is quadratic in S so this UNDER-estimates the real CPU time)",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lightx2v_amd import lib, scheduler, synth, wan
+
+    lib.init(local_rank)
+    wl = synth.WORKLOADS[args.workload]
+    dims = synth.WAN_DIMS[wl["model"]]
+    ts = wl["target_shape"]
+    S = synth.seq_len_of(ts)
+    enable_cfg = not args.no_cfg
+    cfg = wan.default_config(
+        dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
+        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding,
+    )
+    if world > 1 and dims["num_heads"] % world != 0:
+        raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
+
+    # identical weights/inputs on every rank: seeded device generator (weights are replicated under Ulysses)
+    wd = synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda")
+    model = wan.WanModel(cfg, wd)
+    del wd
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    model.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    timer = AttnTimer()
+    model.transformer_infer.attn_time_hook = timer
+
+    def one_step(i):
+        sch.step_pre(i)
+        model.infer(inputs)
+        sch.step_post()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    assert torch.isfinite(sch.latents).all(), "non-finite latents"
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    fps = wl["frames"] / (args.infer_steps * ms_per_step * 1e-3)
+    fwd = 2 if enable_cfg else 1
+    flop_step, flop_attn = step_flops(dims, S, dims["text_len"], fwd)
+    # dominant kernel: self-attention forward; algorithmic FLOPs per launch = 4 * Sq * Sk * (H/N) * 128
+    heads_local = dims["num_heads"] // world
+    flop_launch = 4.0 * S * S * heads_local * 128
+    attn_ms = timer.mean_ms()
+    achieved = flop_launch / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+    out = {
+        "metric": "denoise-step latency (ms) + video frames/sec, Wan2.1-14B 720p 81f @1/8 GPU",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": args.workload,
+            "arch": wl["model"],
+            "tokens": S,
+            "latent_shape": list(ts),
+            "frames": wl["frames"],
+            "infer_steps": args.infer_steps,
+            "cfg_forwards_per_step": fwd,
+            "parallelism": f"ulysses-sp{world}" if world > 1 else "single",
+            "fps_definition": "frames / (infer_steps * ms_per_step), denoise loop only (no text encoder / VAE)",
+            "step_tflop": flop_step / 1e12,
+            "step_tflops_per_s_per_gpu": flop_step / (ms_per_step * 1e-3) / 1e12 / world,
+            "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
+        },
+        "roofline": {
+            "kernel": "attn_fwd_kernel (self-attention, head_dim 128)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches_timed": len(timer.pairs),
+            "avg_launch_ms": attn_ms,
+            "flop_per_launch": flop_launch,
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, S, dims["text_len"], wl["frames"], args.infer_steps, fwd, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
