@@ -34,7 +34,7 @@ for st in $STAGES; do
       timeout 1200 python bench.py --steps ${B14_STEPS:-1} --warmup ${B14_WARMUP:-1} > "$OUT/bench14.json" 2> "$OUT/bench14.err"; echo "bench14 rc=$?" | tee -a "$OUT/summary.txt"
       cat "$OUT/bench14.json" >> "$OUT/summary.txt" ;;
     prof)
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --workload ${PROF_WL:-wan1.3b_480px49f} --steps 1 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err"); echo "prof rc=$?" | tee -a "$OUT/summary.txt"
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --workload ${PROF_WL:-wan1.3b_480px49f} --steps 1 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err"); echo "prof rc=$?" | tee -a "$OUT/summary.txt"
       f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" >> "$OUT/summary.txt"
       # keep only the small summaries (the raw trace can be large)
       find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete ;;
