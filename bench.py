@@ -59,25 +59,30 @@ def step_flops(dims, S, text_len, cfg_forwards):
 
 
 class AttnTimer:
-    """HIP-event timing of every self-attention launch on the stream it is launched on (torch's current stream)."""
+    """HIP-event timing of every attention-kernel launch (self and cross attention run the SAME kernel, so the
+    per-kernel average matches what `rocprofv3 --kernel-trace --stats` reports for it), on the stream the kernel
+    is launched on (torch's current stream)."""
 
     def __init__(self):
-        self.pairs = []
+        self.pairs = {"self": [], "cross": []}
         self.enabled = False
 
     @contextlib.contextmanager
     def __call__(self, kind):
-        if not self.enabled or kind != "self":
+        if not self.enabled:
             yield
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         yield
         b.record()
-        self.pairs.append((a, b))
+        self.pairs[kind].append((a, b))
 
-    def mean_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+    def total_ms(self, kind):
+        return sum(a.elapsed_time(b) for a, b in self.pairs[kind])
+
+    def count(self, kind):
+        return len(self.pairs[kind])
 
 
 def cpu_baseline(dims, S_full, text_len, frames, infer_steps, cfg_forwards, budget_s):
@@ -194,10 +199,18 @@ def main():
     fps = wl["frames"] / (args.infer_steps * ms_per_step * 1e-3)
     fwd = 2 if enable_cfg else 1
     flop_step, flop_attn = step_flops(dims, S, dims["text_len"], fwd)
-    # dominant kernel: self-attention forward; algorithmic FLOPs per launch = 4 * Sq * Sk * (H/N) * 128
+    # dominant kernel: the attention forward kernel (self-attention launches carry 99 % of its FLOPs).
+    # Algorithmic FLOPs per launch = 4 * Sq * Sk * heads * 128: self Sk = S with H/N heads under
+    # Ulysses (all S queries), cross Sk = text_len with all H heads on this rank's S/N queries.
     heads_local = dims["num_heads"] // world
-    flop_launch = 4.0 * S * S * heads_local * 128
-    attn_ms = timer.mean_ms()
+    s_local = -(-S // world)
+    flop_self = 4.0 * S * S * heads_local * 128
+    flop_cross = 4.0 * s_local * dims["text_len"] * dims["num_heads"] * 128
+    n_self, n_cross = timer.count("self"), timer.count("cross")
+    ms_self, ms_cross = timer.total_ms("self"), timer.total_ms("cross")
+    n_all = max(n_self + n_cross, 1)
+    attn_ms = (ms_self + ms_cross) / n_all
+    flop_launch = (flop_self * n_self + flop_cross * n_cross) / n_all
     achieved = flop_launch / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     out = {
         "metric": "denoise-step latency (ms) + video frames/sec, Wan2.1-14B 720p 81f @1/8 GPU",
@@ -227,16 +240,19 @@ def main():
             "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
         },
         "roofline": {
-            "kernel": "attn_fwd_kernel (self-attention, head_dim 128)",
+            "kernel": "x2v::attn_fwd_pipe_kernel<8, 8> (all launches: self + cross attention)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": BF16_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
             "traffic": None,
-            "launches_timed": len(timer.pairs),
+            "launches_timed": n_self + n_cross,
             "avg_launch_ms": attn_ms,
             "flop_per_launch": flop_launch,
+            "self_attention": {"launches": n_self, "avg_ms": ms_self / max(n_self, 1), "tflops": flop_self * n_self / max(ms_self, 1e-9) / 1e9},
+            "cross_attention": {"launches": n_cross, "avg_ms": ms_cross / max(n_cross, 1), "tflops": flop_cross * n_cross / max(ms_cross, 1e-9) / 1e9},
+            "traffic_note": "PMC passes (FETCH_SIZE/WRITE_SIZE, separate runs) are summarised in profiles/ and DESIGN.md",
         },
     }
     if rank == 0:

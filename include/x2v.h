@@ -93,9 +93,11 @@ int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
 int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                       int64_t Sk, int H, int head_dim, float scale, void* stream);
 
-/* Same, selecting a kernel variant (tuning / validation hook; 0 = the default x2v_attn_fwd_bf16 uses):
- * 1 = 4 waves x 32 queries, 2 = 8 waves x 32 queries, 3 = 4 waves with scalar LDS reads of V instead of the
- * hardware transpose read (cross-checks ds_read_b64_tr_b16 addressing). */
+/* Same, selecting a kernel variant (tuning / validation hook; 0 = the default x2v_attn_fwd_bf16 uses = 6):
+ * v1: 1 = 4 waves x 32 queries, 2 = 8 waves x 32 queries, 3 = 4 waves with scalar LDS reads of V instead of the
+ * hardware transpose read (cross-checks ds_read_b64_tr_b16 addressing);
+ * v2 (software-pipelined, LDS-DMA K, buffer loads): 4 = eager rescale, 5/6 = lazy rescale (threshold 4 / 8 in
+ * base-2 units), 7 = 4-wave workgroups. */
 int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                               int64_t Sk, int H, int head_dim, float scale, int variant, void* stream);
 

@@ -42,6 +42,18 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8_t, c);
 }
 
+// single-instruction max helpers: hipcc otherwise inserts canonicalising v_max before fmaxf on MFMA outputs
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // key index (within a 32-key MFMA tile) held in accumulator register r of half-wave `hi`
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -71,6 +83,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const unsigned sho
     const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // Make the Q loads land HERE: otherwise hipcc keeps their vmcnt waits inside the tile loop, where the
+    // in-order counter also drains the K/V prefetch issued at the top of every iteration (vmcnt(0) mid-QK^T).
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
 
   // ---- staging assignment: chunk id = i*NT + tid -> key = id/16, c = id%16.  Staging registers are
@@ -241,8 +257,241 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const unsigned sho
 #undef AT_ISSUE_LOADS
 #undef AT_WRITE_STAGE
 
-}  // namespace x2v
+// ------------------------------------------------------------------------------------------------
+// v2: software-pipelined variant.  PMC on v1 showed per-wave VALU-active ~= MFMA-busy (1142 vs 1024 cycles per
+// tile) and a per-SIMD tile time equal to their SUM over the two co-resident waves: the waves run the same
+// phase in lock-step (barrier per tile), so the matrix pipe idles during everyone's softmax.  Here every wave
+// interleaves the two itself: while the softmax of tile t runs on the VALU, the QK^T MFMAs of tile t+1
+// (independent accumulators) are in flight; then the O rescale of dv-tile T+1 runs under the PV MFMAs of T.
+//   * K is staged by LDS-DMA (global_load_lds, swizzle applied on the per-lane source address) two tiles
+//     ahead, V by registers one tile ahead; both target buffers are free for the whole iteration.
+//   * the half-wave max exchange uses v_permlane32_swap (VALU) instead of ds_bpermute (LDS round trip).
+//   * RESCALE_THR > 0: skip the O rescale while the running max grows by <= THR (base-2 domain): P stays
+//     <= 2^THR, exact in the final O/l normalisation; the branch is wave-uniform.
+typedef __attribute__((address_space(3))) void* at_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* at_gbl_ptr_t;
 
+template <int NW, int RESCALE_THR>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
+                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                                   const unsigned short* __restrict__ Vp, int64_t ldv, unsigned short* __restrict__ O,
+                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
+                                                                   unsigned v_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CPT = (AT_KV * 16) / NT;   // V chunks per thread per tile
+  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
+  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
+  const unsigned short* Vh = Vp + (int64_t)head * AT_D;
+
+  bf16x8_t qf[8];
+  {
+    int64_t qr = q0 + fl;
+    qr = qr < Sq ? qr : Sq - 1;
+    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // K by LDS-DMA, V to registers, both through raw buffer loads: per-lane byte offsets are loop-invariant, the
+  // tile offset travels in an SGPR (soffset), and rows past Sk read as zero (hardware bounds check) — no
+  // per-tile 64-bit address VALU, no clamping.  Descriptors are wave-uniform (kernel arguments + blockIdx).
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), v_tile_bytes = (unsigned)(AT_KV * ldv * 2);
+  unsigned k_voff[KDMA];
+#pragma unroll
+  for (int j = 0; j < KDMA; ++j) {
+    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
+    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
+  }
+#define AT_DMA_K(T_, BUF_)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
+  i32x4_t vst[CPT];
+  int v_wr[CPT];
+  unsigned v_voff[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int id = i * NT + tid;
+    const int key = id >> 4, c = id & 15;
+    v_wr[i] = V_OFF + (c >> 1) * AT_VSUB + key * 32 + (c & 1) * 16;
+    v_voff[i] = (unsigned)(key * ldv * 2) + (unsigned)(c << 4);
+  }
+#define AT_LOAD_V(T_) \
+  _Pragma("unroll") for (int i = 0; i < CPT; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[i], (unsigned)(T_) * v_tile_bytes, 0);
+#define AT_WRITE_V(BUF_)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < CPT; ++i) *reinterpret_cast<i32x4_t*>(smem + (BUF_) * AT_V_BYTES + v_wr[i]) = vst[i];
+
+  // K fragment offsets: row (u*32+fl)*256 + ((ks*2+hi) ^ (fl&15))*16 = kaddr[ks] + u*8192 (+ buffer offset, immediate)
+  int kaddr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = fl * 256 + (((hi ^ (fl & 15)) << 4) ^ (ks << 5));
+  const int L = lane & 15;
+  const int v_rd_base = ((fl >> 4) * 4) * AT_VSUB + (4 * hi + (L >> 2)) * 32 + (L & 3) * 8;
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int T = 0; T < 4; ++T)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+
+#define AT_QK(DST_, BUF_)                                                                                     \
+  {                                                                                                            \
+    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
+      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
+    }                                                                                                          \
+  }
+
+  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
+  AT_DMA_K(0, 0)
+  if (nt > 1) {
+    AT_DMA_K(1, 1)
+  }
+  AT_LOAD_V(0)
+  AT_WRITE_V(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t sc[2];
+  AT_QK(sc, 0)
+
+  // One tile, written as an explicit 32-slot software pipeline (the compiler's own interleave of two
+  // independent streams proved unreliable): every slot = {fragment read for the NEXT slot, one MFMA, a fixed
+  // chunk of VALU work}, pinned by sched_barrier(0).
+  //   slots  0..15 (phase 1): MFMA = S(t+1) += K(t+1) Q^T;  VALU = softmax of S(t): 4 slots of row-max, 1 slot of
+  //                           max exchange + the lazy-rescale decision, 11 slots of exp2 + bf16 pack
+  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T;     VALU = row-sum adds
+  // SC_/SN_ are the two score buffers (they ping-pong: the loop is unrolled x2, nothing is copied), KN_/VB_ the
+  // compile-time LDS buffer indices of K(t+1) / V(t) (every LDS address = loop-invariant VGPR + immediate).
+  // LAST_ = true (peeled final tile): key masking, no next-tile MFMAs, no prefetch.
+#define AT_SB() __builtin_amdgcn_sched_barrier(0)
+#define AT_TILE(LAST_, SC_, SN_, KN_, VB_)                                                                     \
+  {                                                                                                            \
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  \
+    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
+      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
+        if (u * 32 + acc_row(r, hi) >= left) SC_[u][r] = -1e30f;                                               \
+    }                                                                                                          \
+    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
+    bf16x8_t kf_n = *reinterpret_cast<const bf16x8_t*>(kb_ + kaddr[0]);                                        \
+    float pm[4];                                                                                               \
+    unsigned pw[16];                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
+      const int ks = i >> 1, u = i & 1;                                                                        \
+      if (!(LAST_)) {                                                                                          \
+        const bf16x8_t kf_c = kf_n;                                                                            \
+        if (i < 15) kf_n = *reinterpret_cast<const bf16x8_t*>(kb_ + ((i + 1) & 1) * 8192 + kaddr[(i + 1) >> 1]); \
+        SN_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_c, qf[ks], ks == 0 ? zero16 : SN_[u], 0, 0, 0);    \
+      }                                                                                                        \
+      if (i < 4) { /* row max of 8 scores: 3 v_max3 + 1 v_max */                                               \
+        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
+        float m_ = vmax3(SC_[uu][r0], SC_[uu][r0 + 1], SC_[uu][r0 + 2]);                                       \
+        m_ = vmax3(m_, SC_[uu][r0 + 3], SC_[uu][r0 + 4]);                                                      \
+        m_ = vmax3(m_, SC_[uu][r0 + 5], SC_[uu][r0 + 6]);                                                      \
+        pm[i] = vmax2(m_, SC_[uu][r0 + 7]);                                                                    \
+      } else if (i == 4) {                                                                                     \
+        float mx = vmax2(vmax3(pm[0], pm[1], pm[2]), pm[3]);                                                   \
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
+        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
+        const float ms = mx * scale_log2e;                                                                     \
+        if (RESCALE_THR < 0 || __any(ms - m_run > (float)RESCALE_THR)) {                                       \
+          /* lazy rescale: taken only when some row's max grew by more than THR (base-2); otherwise the old    \
+             max is kept (P <= 2^THR, exact after the final O/l) and O is not touched this tile */             \
+          const float m_new = fmaxf(m_run, ms);                                                                \
+          const float al = __builtin_amdgcn_exp2f(m_run - m_new);                                              \
+          m_run = m_new;                                                                                       \
+          l_run *= al;                                                                                         \
+          _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
+        }                                                                                                      \
+      } else { /* slots 5..15: 3 (last: 2) elements of exp2, packed to bf16 pairs as they complete */          \
+        const int e0 = (i - 5) * 3, e1 = (e0 + 3 < 32) ? e0 + 3 : 32;                                          \
+        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
+          SC_[e >> 4][e & 15] = __builtin_amdgcn_exp2f(SC_[e >> 4][e & 15] * scale_log2e - m_run);             \
+          if (e & 1) pw[e >> 1] = pack_bf2(SC_[e >> 4][(e & 15) - 1], SC_[e >> 4][e & 15]);                    \
+        }                                                                                                      \
+      }                                                                                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+    const char* vb = smem + V_OFF + (VB_) * AT_V_BYTES + v_rd_base;                                            \
+    bf16x8_t vf_n = tr_frag(vb, vb + 8 * 32);                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
+      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
+      const bf16x8_t vf_c = vf_n;                                                                              \
+      if (j < 15) {                                                                                            \
+        const char* p0 = vb + ((j + 1) >> 2) * AT_VSUB + (((j + 1) & 3) * 16) * 32;                            \
+        vf_n = tr_frag(p0, p0 + 8 * 32);                                                                       \
+      }                                                                                                        \
+      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
+      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_c, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      l_run += SC_[j >> 3][(j & 7) * 2] + SC_[j >> 3][(j & 7) * 2 + 1];                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+  }
+  // (a x2 ping-pong unroll with compile-time buffer indices was tried: it removes the score copy below and the
+  //  LDS address adds, but hipcc then spills ~80 registers in the loop — net loss; kept single-bodied.)
+  f32x16_t sd[2];
+  int t = 0;
+  for (; t < nt - 1; ++t) {
+    if (t + 2 < nt) {
+      AT_DMA_K(t + 2, t & 1)
+    }
+    AT_LOAD_V(t + 1)
+    AT_SB();
+    AT_TILE(false, sc, sd, (t + 1) & 1, t & 1)
+    AT_WRITE_V((t + 1) & 1)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sc[u] = sd[u];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  AT_TILE(true, sc, sd, (t + 1) & 1, t & 1)
+#undef AT_TILE
+#undef AT_SB
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + fl;
+  if (qrow < Sq) {
+    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 8 * g + 4 * hi;
+        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
+        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dv) = pk;
+      }
+  }
+#endif
+}
+#undef AT_DMA_K
+#undef AT_LOAD_V
+#undef AT_WRITE_V
+#undef AT_QK
+
+
+
+}  // namespace x2v
 using namespace x2v;
 
 template <int NW, bool SAFE_V>
@@ -262,7 +511,29 @@ static int launch_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, c
   return X2V_OK;
 }
 
-// variant: 0 = default, 1 = NW=4 tr-read, 2 = NW=8 tr-read, 3 = NW=4 scalar-V (validation path for the transpose read)
+template <int NW, int THR>
+static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
+                            int64_t Sk, int H, float scale, hipStream_t st) {
+  // buffer descriptors address 32 bits: the per-head K/V views must stay below 4 GiB
+  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (Sk - 1) * ldv * 2 + AT_D * 2;
+  X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32) - (int64_t)AT_KV * ldv * 2, X2V_E_SHAPE,
+              "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<NW, THR>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  const int QB = NW * 32;
+  dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<NW, THR>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
+                     (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
+  X2V_LAUNCH_CHECK("attn launch");
+  return X2V_OK;
+}
+
+// variant: 0 = default (= 6); v1 kernels: 1 = 4 waves, 2 = 8 waves, 3 = 4 waves + scalar-V validation path for the transpose read;
+// v2 software-pipelined kernels: 4 = 8 waves eager rescale, 5 = lazy rescale THR 4, 6 = lazy THR 8, 7 = 4 waves lazy THR 4
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                                          int64_t Sk, int H, int head_dim, float scale, int variant, void* stream) {
   X2V_REQUIRE(q && k && v && o, X2V_E_ARG, "attn: null pointer");
@@ -276,9 +547,13 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(
   hipStream_t st = (hipStream_t)stream;
   switch (variant) {
     case 0:
+    case 6: return launch_attn_pipe<8, 8>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 2: return launch_attn<8, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 1: return launch_attn<4, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 3: return launch_attn<4, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 4: return launch_attn_pipe<8, -1>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 5: return launch_attn_pipe<8, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 7: return launch_attn_pipe<4, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     default: set_error("attn: unknown variant %d", variant); return X2V_E_ARG;
   }
 }

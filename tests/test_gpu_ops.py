@@ -92,7 +92,7 @@ def test_rope_golden(lib, golden_ops):
 
 def test_attention_golden(lib, golden_ops):
     g = golden_ops
-    for variant in (0, 1, 2, 3):
+    for variant in range(8):
         o = lib.attention(dev(g["attn_q"]), dev(g["attn_k"]), dev(g["attn_v"]), 2, variant=variant)
         assert_bf16_close(o, g["attn_o"], ulps=0.128, atol=4e-3, name=f"self attention variant {variant}")
         o = lib.attention(dev(g["attn_q"]), dev(g["xattn_k"]), dev(g["xattn_v"]), 2, variant=variant)

@@ -575,7 +575,7 @@ static void run_attn() {
     DevBuf<uint16_t> dq(q), dk(k), dv(v), dout((size_t)sh.Sq * sh.H * 128);
     std::vector<float> ref;
     ref_attn(q, k, v, sh.Sq, sh.Sk, sh.H, ref);
-    for (int variant = 1; variant <= 3; ++variant) {
+    for (int variant = 0; variant <= 7; ++variant) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       X2V_OKAY(x2v_attn_fwd_bf16_variant(dq.p, sh.H * 128, dk.p, sh.H * 128, dv.p, sh.H * 128, dout.p, sh.H * 128, sh.Sq, sh.Sk, sh.H, 128, 0.f, variant,
                                          nullptr));
@@ -803,7 +803,7 @@ static void run_bench(bool big) {
     fill_random(q, rng, 1.f);
     fill_random(k, rng, 1.f);
     fill_random(v, rng, 1.f);
-    for (int variant = 1; variant <= 2; ++variant) {
+    for (int variant : {2, 4, 6}) {
       const double flop = 4.0 * a.Sq * a.Sk * a.H * 128;
       const int iters = flop > 2e13 ? 1 : 5;
       double ms = time_ms(iters, [&] {
@@ -834,8 +834,41 @@ static void run_bench(bool big) {
   }
 }
 
+// single-kernel loops for rocprofv3 --pmc passes: `x2v_check pattn <variant> <S> <H> [iters]`, `x2v_check pgemm <M> <N> <K> [iters]`
+static void run_single(int argc, char** argv) {
+  Rng rng(31);
+  const std::string mode = argv[1];
+  if (mode == "pattn") {
+    const int variant = atoi(argv[2]);
+    const int64_t S = atoll(argv[3]);
+    const int H = atoi(argv[4]);
+    const int iters = argc > 5 ? atoi(argv[5]) : 3;
+    DevBuf<uint16_t> q((size_t)S * H * 128), k((size_t)S * H * 128), v((size_t)S * H * 128), o((size_t)S * H * 128);
+    fill_random(q, rng, 1.f);
+    fill_random(k, rng, 1.f);
+    fill_random(v, rng, 1.f);
+    double ms = time_ms(iters, [&] { X2V_OKAY(x2v_attn_fwd_bf16_variant(q.p, H * 128, k.p, H * 128, v.p, H * 128, o.p, H * 128, S, S, H, 128, 0.f, variant, nullptr)); });
+    printf("pattn variant=%d S=%lld H=%d: %.3f ms %.1f TFLOP/s\n", variant, (long long)S, H, ms, 4.0 * S * S * H * 128 / ms / 1e9);
+  } else {
+    const int64_t M = atoll(argv[2]);
+    const int N = atoi(argv[3]), K = atoi(argv[4]);
+    const int iters = argc > 5 ? atoi(argv[5]) : 3;
+    DevBuf<uint16_t> x((size_t)M * K), w((size_t)N * K), b(N), y((size_t)M * N);
+    fill_random(x, rng, 1.f);
+    fill_random(w, rng, 0.02f);
+    fill_random(b, rng, 0.02f);
+    double ms = time_ms(iters, [&] { X2V_OKAY(x2v_gemm_bf16(x.p, K, w.p, K, b.p, y.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, nullptr)); });
+    printf("pgemm M=%lld N=%d K=%d: %.3f ms %.1f TFLOP/s\n", (long long)M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
+  }
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "all";
+  if (mode == "pattn" || mode == "pgemm") {
+    X2V_OKAY(x2v_init(0));
+    run_single(argc, argv);
+    return 0;
+  }
   X2V_OKAY(x2v_init(0));
   char arch[64];
   int cus = 0, lds = 0;
