@@ -206,6 +206,7 @@ class WanTransformerInfer:
         self.sp_rank, self.sp_world = 0, 1
         self.round_mode = lib.ROUND_REF if _cfg(config, "hip_ref_rounding", False) else lib.ROUND_FP32
         self.infer_conditional = True
+        self._rope_cs = None
         self.attn_time_hook = None  # bench.py: callable(kind) -> context manager timing the attention launch
 
     def set_scheduler(self, scheduler):
@@ -235,12 +236,16 @@ class WanTransformerInfer:
 
     def infer_self_attn(self, weights, grid_sizes, x, seq_lens, freqs, shift_msa, scale_msa, gate_msa):
         """transformer_infer.py:321-396 + the `x.add_(y * gate_msa)` of :402 folded into the o-projection."""
-        n1 = weights.norm1.apply(x, scale=scale_msa, shift=shift_msa)
+        n1 = lib.layernorm(x, scale=scale_msa, shift=shift_msa, eps=weights.norm1.eps)  # norm1 has no affine (transformer_weights.py:127-129)
         q = weights.self_attn_q.apply(n1)
         k = weights.self_attn_k.apply(n1)
         v = weights.self_attn_v.apply(n1)
         grid = tuple(int(g) for g in grid_sizes[0].tolist())
         s_local = x.shape[0]
+        if freqs.is_complex():  # driven by the reference's WanPreInfer: complex128 [1024, 64] (pre_infer.py:12-19)
+            if self._rope_cs is None or self._rope_cs.device != x.device:
+                self._rope_cs = torch.stack([freqs.real, freqs.imag], dim=-1).to(torch.float32).contiguous().to(x.device)
+            freqs = self._rope_cs
         lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads,
                           s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode)
         if self.parallel_attention is None:
@@ -251,7 +256,7 @@ class WanTransformerInfer:
 
     def infer_cross_attn(self, weights, x, context):
         """transformer_infer.py:398-465 (t2v) + the `x.add_(attn_out)` of :468 folded into the o-projection."""
-        n3 = weights.norm3.apply(x)
+        n3 = lib.layernorm(x, weights.norm3.weight, weights.norm3.bias, eps=weights.norm3.eps)
         q = weights.cross_attn_q.apply(n3)
         lib.rmsnorm(q, weights.cross_attn_norm_q.weight, weights.cross_attn_norm_q.eps, out=q, round_mode=self.round_mode)
         k = weights.cross_attn_k.apply(context)
@@ -262,7 +267,7 @@ class WanTransformerInfer:
 
     def infer_ffn(self, weights, x, c_shift_msa, c_scale_msa, c_gate_msa):
         """transformer_infer.py:467-508: LN+modulate, ffn_0 (+GELU-tanh), ffn_2 (+`x.add_(y * c_gate)`)."""
-        n2 = weights.norm2.apply(x, scale=c_scale_msa, shift=c_shift_msa)
+        n2 = lib.layernorm(x, scale=c_scale_msa, shift=c_shift_msa, eps=weights.norm2.eps)
         h = weights.ffn_0.apply(n2, epilogue=lib.EPI_GELU_TANH)
         return weights.ffn_2.apply(h, epilogue=lib.EPI_RESIDUAL, resid=x, gate=c_gate_msa)
 
@@ -285,7 +290,7 @@ class WanPostInfer:
 
     def infer(self, weights, x, e, grid_sizes):
         e = (weights.head_modulation.tensor + e.unsqueeze(1)).chunk(2, dim=1)  # [1,2,D] → shift, scale
-        x = weights.norm.apply(x, scale=e[1].squeeze(0), shift=e[0].squeeze(0))
+        x = lib.layernorm(x, scale=e[1].squeeze(0), shift=e[0].squeeze(0), eps=weights.norm.eps)
         x = weights.head.apply(x)
         return [u.float() for u in self.unpatchify(x, grid_sizes)]
 
