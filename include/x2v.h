@@ -86,6 +86,13 @@ int x2v_activation_bf16(const void* x, void* y, int64_t n, int act, void* stream
 int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                   int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
 
+/* Same, selecting the kernel (tuning / validation hook).  variant & 0xff: 0 = by shape (what x2v_gemm_bf16 does:
+ * the 256x256-tile ping-pong kernel of gemm256.hip when the grid fills the chip, else the 128x128 kernel of
+ * gemm.hip), 1 = 128x128 kernel, 2 = 256x256 kernel; variant >> 8 = m-tiles per scheduling group of the
+ * 256x256 kernel (0 = default). */
+int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                          int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream);
+
 /* Dense non-causal attention, head_dim 128: o[Sq, H*128] = softmax(q k^T * scale) v per head —
  * replaces FlashAttn2Weight/FlashAttn3Weight/TorchSDPAWeight.apply (common/ops/attn/attn_weight.py:71-126,
  * 209-239) for one sequence (cu_seqlens = [0, S]).  q/k/v: token stride in elements (ldq/ldk/ldv), head h
@@ -111,6 +118,11 @@ int x2v_quant_fp8_rowwise(const void* x, int64_t ldx, void* xq, int64_t ldq, flo
  * e4m3fn operands, fp32 MFMA accumulate.  K % 128 == 0, N % 8 == 0. */
 int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                  int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
+
+/* Same with the kernel selector of x2v_gemm_bf16_variant. */
+int x2v_gemm_fp8_variant(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
+                         int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, int variant,
+                         void* stream);
 
 /* Timestep sinusoid: y[n, dim] bf16 = [cos(t*f_j) | sin(t*f_j)], f_j = 10000^(-j/(dim/2)) computed in
  * float64 then rounded — replaces sinusoidal_embedding_1d (wan/infer/utils.py:161-172).  t: int64 [n]. */

@@ -370,6 +370,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
   __syncthreads();
   f32x16_t sc[2];
   AT_QK(sc, 0)
+  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
+  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
+  __syncthreads();
 
   // One tile, written as an explicit 32-slot software pipeline (the compiler's own interleave of two
   // independent streams proved unreliable): every slot = {fragment read for the NEXT slot, one MFMA, a fixed

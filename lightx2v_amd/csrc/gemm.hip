@@ -161,6 +161,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A
 
   // ---- epilogue phase 1: acc (+bias, activation) -> bf16 -> LDS [128][G_EPI_LD]
   //      acc[i][j][r]: output row m = wr*64+i*32+fl, col n = wc*64+j*32 + (r&3) + 8*(r>>2) + 4*fh
+  //      per-column operands (bias, fp8 channel scales) are fetched up front in one batch: one L2 round trip
+  uint2 bv[2][4];
+  float4 swv[2][4];
+  float sxv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int gn = n0 + wc * 64 + j * 32 + 8 * g + 4 * fh;
+      gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
+      bv[j][g] = make_uint2(0u, 0u);
+      if (bias != nullptr) bv[j][g] = *reinterpret_cast<const uint2*>(bias + gn);
+      if constexpr (FP8) swv[j][g] = *reinterpret_cast<const float4*>(sw + gn);
+    }
+  if constexpr (FP8) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t gm = m0 + wr * 64 + i * 32 + fl;
+      gm = gm < M ? gm : M - 1;
+      sxv[i] = sx[gm];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ml = wr * 64 + i * 32 + fl;
@@ -172,25 +194,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A
         float vv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) vv[e] = acc[i][j][4 * g + e];
-        int gn = n0 + nl;
-        gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
         if constexpr (FP8) {
-          int64_t gm = m0 + ml;
-          gm = gm < M ? gm : M - 1;
-          const float sxm = sx[gm];
-          const float4 swn = *reinterpret_cast<const float4*>(sw + gn);
-          vv[0] = vv[0] * sxm * swn.x;
-          vv[1] = vv[1] * sxm * swn.y;
-          vv[2] = vv[2] * sxm * swn.z;
-          vv[3] = vv[3] * sxm * swn.w;
+          vv[0] = vv[0] * sxv[i] * swv[j][g].x;
+          vv[1] = vv[1] * sxv[i] * swv[j][g].y;
+          vv[2] = vv[2] * sxv[i] * swv[j][g].z;
+          vv[3] = vv[3] * sxv[i] * swv[j][g].w;
         }
-        if (bias != nullptr) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(bias + gn);
-          vv[0] += bf_lo(bb.x);
-          vv[1] += bf_hi(bb.x);
-          vv[2] += bf_lo(bb.y);
-          vv[3] += bf_hi(bb.y);
-        }
+        vv[0] += bf_lo(bv[j][g].x);
+        vv[1] += bf_hi(bv[j][g].x);
+        vv[2] += bf_lo(bv[j][g].y);
+        vv[3] += bf_hi(bv[j][g].y);
         if (EPI == X2V_EPI_GELU_TANH) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] = gelu_tanh_f(rbf(vv[e]));
@@ -237,6 +250,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A
 
 }  // namespace x2v
 
+namespace x2v {
+// gemm256.hip: the 256x256-tile ping-pong kernel for large shapes
+template <bool FP8>
+int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
+                     const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st);
+}  // namespace x2v
+
 using namespace x2v;
 
 template <bool FP8, int EPI>
@@ -256,9 +276,24 @@ static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t 
   return X2V_OK;
 }
 
+// variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel; bits 8..15 = m-tiles per scheduling
+// group of the 256x256 kernel (0 = default), bits 16.. = its schedule selector (tuning hook)
 template <bool FP8>
 static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N,
-                        int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, hipStream_t st) {
+                        int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int variant, hipStream_t st) {
+  const int kind = variant & 0xff;
+  int gm_tiles = variant >> 8;
+  const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
+  // the 256^2 kernel wants at least ~one full round of tiles (256 CUs) and a K loop longer than its pipeline
+  const int64_t tiles256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
+  const bool big = tiles256 >= 192 && nk >= 8;
+  if (kind == 2 && !fits256) {
+    set_error("gemm: leading dimension too large for the 256x256 kernel");
+    return X2V_E_SHAPE;
+  }
+  if (kind == 2 || (kind == 0 && fits256 && big)) {
+    return gemm256_dispatch<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
+  }
   switch (epilogue) {
     case X2V_EPI_NONE: return launch_gemm<FP8, X2V_EPI_NONE>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
     case X2V_EPI_GELU_TANH: return launch_gemm<FP8, X2V_EPI_GELU_TANH>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
@@ -282,8 +317,8 @@ static int check_common(const char* who, const void* y, int64_t ldy, int64_t M, 
   return X2V_OK;
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
-                             int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                             int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream) {
   X2V_REQUIRE(x && w && y, X2V_E_ARG, "gemm_bf16: null pointer");
   X2V_REQUIRE(K > 0 && K % GB_K == 0, X2V_E_SHAPE, "gemm_bf16: K=%d must be a positive multiple of %d", K, GB_K);
   X2V_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && aligned16(x) && aligned16(w), X2V_E_ALIGN, "gemm_bf16: operand rows must be 16-byte aligned");
@@ -291,11 +326,16 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16(const void* 
   int rc = check_common("gemm_bf16", y, ldy, M, N, bias, epilogue, resid, ldr, gate);
   if (rc != X2V_OK) return rc;
   if (M == 0) return X2V_OK;
-  return dispatch_epi<false>(epilogue, x, ldx * 2, w, ldw * 2, bias, y, ldy, M, N, K / GB_K, resid, ldr, gate, nullptr, nullptr, (hipStream_t)stream);
+  return dispatch_epi<false>(epilogue, x, ldx * 2, w, ldw * 2, bias, y, ldy, M, N, K / GB_K, resid, ldr, gate, nullptr, nullptr, variant, (hipStream_t)stream);
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
-                            int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
+                             int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+  return x2v_gemm_bf16_variant(x, ldx, w, ldw, bias, y, ldy, M, N, K, epilogue, resid, ldr, gate, 0, stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8_variant(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
+                            int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream) {
   X2V_REQUIRE(xq && wq && y && sx && sw, X2V_E_ARG, "gemm_fp8: null pointer");
   X2V_REQUIRE(K > 0 && K % 128 == 0, X2V_E_SHAPE, "gemm_fp8: K=%d must be a positive multiple of 128", K);
   X2V_REQUIRE(ldx % 16 == 0 && ldw % 16 == 0 && aligned16(xq) && aligned16(wq) && aligned16(sw), X2V_E_ALIGN, "gemm_fp8: operand rows must be 16-byte aligned");
@@ -303,5 +343,10 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* x
   int rc = check_common("gemm_fp8", y, ldy, M, N, bias, epilogue, resid, ldr, gate);
   if (rc != X2V_OK) return rc;
   if (M == 0) return X2V_OK;
-  return dispatch_epi<true>(epilogue, xq, ldx, wq, ldw, bias, y, ldy, M, N, K / 128, resid, ldr, gate, sx, sw, (hipStream_t)stream);
+  return dispatch_epi<true>(epilogue, xq, ldx, wq, ldw, bias, y, ldy, M, N, K / 128, resid, ldr, gate, sx, sw, variant, (hipStream_t)stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
+                            int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+  return x2v_gemm_fp8_variant(xq, ldx, sx, wq, ldw, sw, bias, y, ldy, M, N, K, epilogue, resid, ldr, gate, 0, stream);
 }

@@ -30,10 +30,12 @@ PROTOTYPES = {
     "x2v_gate_residual_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "x2v_gemm_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
     "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
     "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "x2v_gemm_fp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
     "x2v_sinusoid_embed_bf16": [_c_void_p, _c_void_p, _i32, _i32, _c_void_p],
     "x2v_causal_conv3d_f32": [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
 }
@@ -158,8 +160,8 @@ def activation(x, act):
     return out
 
 
-def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None):
-    """y = epi(x @ weight_nk.T + bias); weight_nk is the checkpoint's [N,K] tensor."""
+def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None, variant=0):
+    """y = epi(x @ weight_nk.T + bias); weight_nk is the checkpoint's [N,K] tensor.  variant: see x2v_gemm_bf16_variant."""
     x2, w2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(weight_nk, "weight"), "weight")
     M, K = x2.shape
     N = w2.shape[0]
@@ -177,7 +179,7 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
         r2 = None
     init()
     _check(
-        _lib.x2v_gemm_bf16(_p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), _stream()),
+        _lib.x2v_gemm_bf16_variant(_p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), variant, _stream()),
         "gemm_bf16",
     )
     return out2
@@ -214,7 +216,7 @@ def quant_fp8_rowwise(x):
     return xq, s
 
 
-def gemm_fp8(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None):
+def gemm_fp8(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None, variant=0):
     M, K = xq.shape
     N = wq_nk.shape[0]
     if xq.dtype != torch.float8_e4m3fn or wq_nk.dtype != torch.float8_e4m3fn:
@@ -231,7 +233,7 @@ def gemm_fp8(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, resid=None, gate=N
     sx = sx.reshape(-1)
     init()
     _check(
-        _lib.x2v_gemm_fp8(_p(xq), xq.stride(0), _p(sx), _p(wq_nk), wq_nk.stride(0), _p(sw), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), _stream()),
+        _lib.x2v_gemm_fp8_variant(_p(xq), xq.stride(0), _p(sx), _p(wq_nk), wq_nk.stride(0), _p(sw), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), variant, _stream()),
         "gemm_fp8",
     )
     return out2

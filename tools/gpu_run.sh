@@ -12,7 +12,7 @@ for st in $STAGES; do
   t0=$(date +%s)
   case $st in
     check)
-      for m in probe misc norm rope gemm attn fp8 conv; do
+      for m in ${CHECKS:-probe misc norm rope gemm attn fp8 conv}; do
         timeout 180 tools/x2v_check $m > "$OUT/check_$m.log" 2>&1; echo "check $m rc=$?" | tee -a "$OUT/summary.txt"
         tail -1 "$OUT/check_$m.log" >> "$OUT/summary.txt"
       done ;;
@@ -45,8 +45,9 @@ for st in $STAGES; do
                  "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD" \
                  "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
         i=$((i+1))
-        for target in "${PMC_ATTN:-pattn 0 20280 12 2}" "${PMC_GEMM:-pgemm 20280 8960 1536 2}"; do
-          tag=$(echo $target | cut -d" " -f1)
+        IFS=';' read -ra TARGETS <<< "${PMC_TARGETS:-pattn 0 20280 12 2;pgemm 20280 8960 1536 2}"
+        for target in "${TARGETS[@]}"; do
+          tag=$(echo $target | tr ' ' '_')
           (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/pmc/${tag}_set$i" -o pmc -- "$GRAFT_REPO_ROOT/tools/x2v_check" $target > "$GRAFT_REPO_ROOT/$OUT/pmc_${tag}_set$i.log" 2>&1)
         done
       done

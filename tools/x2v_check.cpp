@@ -185,7 +185,49 @@ __global__ void probe_glds(const int* src, int* out) {
   for (int i = threadIdx.x; i < 512; i += 64) out[i] = lds[i];
 }
 
+// raw buffer loads: which offsets take part in the hardware bounds check?  src holds 64 ints = 256 B = num_records.
+// out[0] in-range load, out[1] voffset past the end, out[2] voffset in range + soffset past the end,
+// out[3] as [2] through the LDS-DMA form (LDS word preset to -7), out[4] voffset past the end through LDS-DMA.
+__global__ void probe_buffer_bounds(const int* src, int* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) int lds[64 * 2];
+  lds[threadIdx.x] = -7;
+  lds[64 + threadIdx.x] = -7;
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 256, 0x00020000);
+  const int a = __builtin_amdgcn_raw_buffer_load_b32(r, 16, 0, 0);
+  const int b = __builtin_amdgcn_raw_buffer_load_b32(r, 256 + 16, 0, 0);
+  const int c = __builtin_amdgcn_raw_buffer_load_b32(r, 16, 256, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 4, 16, 256, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + 64), 4, 256 + 16, 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = a;
+    out[1] = b;
+    out[2] = c;
+    out[3] = lds[0];
+    out[4] = lds[64];
+  }
+#endif
+}
+
 static void run_probe() {
+  {
+    // 128 ints allocated, descriptor covers the first 64: in-range word 4 = 104, the word soffset reaches = 168
+    std::vector<int> src(128);
+    for (int i = 0; i < 128; ++i) src[i] = 100 + i;
+    DevBuf<int> s(src), out(8);
+    hipLaunchKernelGGL(probe_buffer_bounds, dim3(1), dim3(64), 0, 0, s.p, out.p);
+    HIP_OK(hipDeviceSynchronize());
+    auto h = out.host();
+    printf("probe raw buffer bounds: in-range=%d (want 104); voffset OOB -> %d (want 0); soffset OOB -> %d (0 = soffset IS bounds-checked, 168 = it is NOT);\n"
+           "      LDS-DMA soffset OOB -> %d (-7 = no write, 0 = zero written, 168 = not checked); LDS-DMA voffset OOB -> %d\n",
+           h[0], h[1], h[2], h[3], h[4]);
+    if (h[0] != 104 || h[1] != 0) g_fail++;
+    // the kernels rely on: voffset OOB reads return 0 and LDS-DMA voffset OOB writes 0 (M/N/Sk tails)
+    if (h[4] != 0) g_fail++;
+  }
   {
     DevBuf<float> out(16 * 64 * 16);
     hipLaunchKernelGGL(probe_mfma32, dim3(1), dim3(64), 0, 0, out.p);
@@ -488,7 +530,8 @@ static void run_gemm() {
   struct Shape {
     int64_t M;
     int N, K;
-  } shapes[] = {{128, 128, 64}, {256, 256, 512}, {200, 384, 256}, {1, 1536, 256}, {77, 64, 1536}, {515, 136, 192}, {300, 1536, 1536}};
+  } shapes[] = {{128, 128, 64}, {256, 256, 512}, {200, 384, 256}, {1, 1536, 256}, {77, 64, 1536}, {515, 136, 192}, {300, 1536, 1536}, {700, 520, 128}};
+  for (int variant : {1, 2})
   for (auto sh : shapes) {
     auto x = rand_bf((size_t)sh.M * sh.K, rng, 1.0f), w = rand_bf((size_t)sh.N * sh.K, rng, 1.0f / sqrtf((float)sh.K));
     auto b = rand_bf(sh.N, rng, 0.2f), res = rand_bf((size_t)sh.M * sh.N, rng, 1.0f), g = rand_bf(sh.N, rng, 0.5f);
@@ -499,19 +542,19 @@ static void run_gemm() {
     const char* en[] = {"none", "gelu", "silu", "residual+gate"};
     for (int e = 0; e < 4; ++e) {
       DevBuf<uint16_t> dres(res);
-      X2V_OKAY(x2v_gemm_bf16(dx.p, sh.K, dw.p, sh.K, db.p, epis[e] == X2V_EPI_RESIDUAL ? dres.p : dy.p, sh.N, sh.M, sh.N, sh.K, epis[e], dres.p, sh.N,
-                             dg.p, nullptr));
+      X2V_OKAY(x2v_gemm_bf16_variant(dx.p, sh.K, dw.p, sh.K, db.p, epis[e] == X2V_EPI_RESIDUAL ? dres.p : dy.p, sh.N, sh.M, sh.N, sh.K, epis[e], dres.p, sh.N,
+                                     dg.p, variant, nullptr));
       HIP_OK(hipDeviceSynchronize());
       ref_gemm(x, w, b.data(), sh.M, sh.N, sh.K, epis[e], res.data(), g.data(), ref);
-      snprintf(name, sizeof name, "gemm_bf16 M=%lld N=%d K=%d epi=%s", (long long)sh.M, sh.N, sh.K, en[e]);
+      snprintf(name, sizeof name, "gemm_bf16 v%d M=%lld N=%d K=%d epi=%s", variant, (long long)sh.M, sh.N, sh.K, en[e]);
       auto got = to_f(epis[e] == X2V_EPI_RESIDUAL ? dres.host() : dy.host());
       report(name, compare(got, ref, 2e-3, 0.0079), 0.002);
     }
     // no-bias
-    X2V_OKAY(x2v_gemm_bf16(dx.p, sh.K, dw.p, sh.K, nullptr, dy.p, sh.N, sh.M, sh.N, sh.K, X2V_EPI_NONE, nullptr, 0, nullptr, nullptr));
+    X2V_OKAY(x2v_gemm_bf16_variant(dx.p, sh.K, dw.p, sh.K, nullptr, dy.p, sh.N, sh.M, sh.N, sh.K, X2V_EPI_NONE, nullptr, 0, nullptr, variant, nullptr));
     HIP_OK(hipDeviceSynchronize());
     ref_gemm(x, w, nullptr, sh.M, sh.N, sh.K, X2V_EPI_NONE, nullptr, nullptr, ref);
-    snprintf(name, sizeof name, "gemm_bf16 M=%lld N=%d K=%d nobias", (long long)sh.M, sh.N, sh.K);
+    snprintf(name, sizeof name, "gemm_bf16 v%d M=%lld N=%d K=%d nobias", variant, (long long)sh.M, sh.N, sh.K);
     report(name, compare(to_f(dy.host()), ref, 2e-3, 0.0079), 0.002);
   }
   // transposition / layout check with asymmetric integer data: exact result required
@@ -524,11 +567,38 @@ static void run_gemm() {
     for (int n = 0; n < N; ++n)
       for (int k = 0; k < K; ++k) w[(size_t)n * K + k] = f2bf((float)((n + 2 * k) % 7 - 3));
     DevBuf<uint16_t> dx(x), dw(w), dy((size_t)M * N);
-    X2V_OKAY(x2v_gemm_bf16(dx.p, K, dw.p, K, nullptr, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, nullptr));
-    HIP_OK(hipDeviceSynchronize());
     std::vector<float> ref;
     ref_gemm(x, w, nullptr, M, N, K, X2V_EPI_NONE, nullptr, nullptr, ref);
-    report("gemm_bf16 asymmetric integer data (exact)", compare(to_f(dy.host()), ref, 0, 0));
+    for (int variant : {1, 2}) {
+      X2V_OKAY(x2v_gemm_bf16_variant(dx.p, K, dw.p, K, nullptr, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, variant, nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      report(variant == 1 ? "gemm_bf16 v1 asymmetric integer data (exact)" : "gemm_bf16 v2 asymmetric integer data (exact)", compare(to_f(dy.host()), ref, 0, 0));
+    }
+  }
+  // race screen for the 256x256 ping-pong pipeline: a long-K integer problem (exact in fp32) repeated, every run bit-identical
+  // to the first and equal to the CPU result
+  {
+    const int64_t M = 1100;
+    const int N = 1304, K = 2048;
+    std::vector<uint16_t> x((size_t)M * K), w((size_t)N * K);
+    for (int64_t m = 0; m < M; ++m)
+      for (int k = 0; k < K; ++k) x[m * K + k] = f2bf((float)(((m * 7 + k * 3) % 9) - 4));
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) w[(size_t)n * K + k] = f2bf((float)(((n * 5 + 2 * k) % 7) - 3) * 0.5f);
+    DevBuf<uint16_t> dx(x), dw(w), dy((size_t)M * N);
+    std::vector<float> ref;
+    ref_gemm(x, w, nullptr, M, N, K, X2V_EPI_NONE, nullptr, nullptr, ref);
+    int bad_runs = 0;
+    ErrStat worst{};
+    for (int run = 0; run < 20; ++run) {
+      X2V_OKAY(x2v_gemm_bf16_variant(dx.p, K, dw.p, K, nullptr, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, 2 | ((1 + run % 4) << 8) | ((run & 4) << 14), nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      ErrStat e = compare(to_f(dy.host()), ref, 0, 0);
+      if (e.bad) { ++bad_runs; worst = e; }
+    }
+    ErrStat e = worst;
+    if (!bad_runs) e = compare(to_f(dy.host()), ref, 0, 0);
+    report("gemm_bf16 v2 race screen: 20 runs of M=1100 N=1304 K=2048 integer data (exact)", e);
   }
 }
 
@@ -660,8 +730,6 @@ static void run_fp8() {
   DevBuf<uint8_t> dwq(wq);
   DevBuf<float> dsw(sw);
   DevBuf<uint16_t> db(bias), dy((size_t)M * N);
-  X2V_OKAY(x2v_gemm_fp8(dq.p, K, ds.p, dwq.p, K, dsw.p, db.p, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, nullptr));
-  HIP_OK(hipDeviceSynchronize());
   std::vector<float> yref((size_t)M * N);
   for (int64_t m = 0; m < M; ++m)
     for (int n = 0; n < N; ++n) {
@@ -669,7 +737,12 @@ static void run_fp8() {
       for (int k = 0; k < K; ++k) acc += (double)e4m3_to_f(hq[m * K + k]) * e4m3_to_f(wq[(size_t)n * K + k]);
       yref[m * N + n] = rbf((float)(acc * hs[m] * sw[n]) + bf2f(bias[n]));
     }
-  report("gemm_fp8 (MX-scaled MFMA, unit block scales) vs fp64", compare(to_f(dy.host()), yref, 2e-3, 0.0079), 0.002);
+  for (int variant : {1, 2}) {
+    X2V_OKAY(x2v_gemm_fp8_variant(dq.p, K, ds.p, dwq.p, K, dsw.p, db.p, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, variant, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    report(variant == 1 ? "gemm_fp8 v1 (MX-scaled MFMA, unit block scales) vs fp64" : "gemm_fp8 v2 (256x256 kernel) vs fp64",
+           compare(to_f(dy.host()), yref, 2e-3, 0.0079), 0.002);
+  }
 }
 
 // ---------------------------------------------------------------- conv
@@ -780,12 +853,14 @@ static void run_bench(bool big) {
     fill_random(gate, rng, 0.5f);
     fill_random(y, rng, 1.f);
     const int iters = g.M * (double)g.N * g.K > 1e13 ? 3 : 10;
-    double ms = time_ms(iters, [&] {
-      X2V_OKAY(x2v_gemm_bf16(x.p, g.K, w.p, g.K, b.p, y.p, g.N, g.M, g.N, g.K, g.epi, g.epi == X2V_EPI_RESIDUAL ? y.p : nullptr, g.N,
-                             g.epi == X2V_EPI_RESIDUAL ? gate.p : nullptr, nullptr));
-    });
-    const double tf = 2.0 * g.M * g.N * g.K / (ms * 1e-3) / 1e12;
-    printf("BENCH gemm_bf16 %-42s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)\n", g.name, ms, tf, tf / 25.0);
+    for (int variant : {1, 2 | (4 << 8) | (1 << 16), 2 | (4 << 8), 2 | (8 << 8)}) {
+      double ms = time_ms(iters, [&] {
+        X2V_OKAY(x2v_gemm_bf16_variant(x.p, g.K, w.p, g.K, b.p, y.p, g.N, g.M, g.N, g.K, g.epi, g.epi == X2V_EPI_RESIDUAL ? y.p : nullptr, g.N,
+                                       g.epi == X2V_EPI_RESIDUAL ? gate.p : nullptr, variant, nullptr));
+      });
+      const double tf = 2.0 * g.M * g.N * g.K / (ms * 1e-3) / 1e12;
+      printf("BENCH gemm_bf16 v=%d gm=%d sched=%d %-42s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)\n", variant & 255, (variant >> 8) & 255, variant >> 16, g.name, ms, tf, tf / 25.0);
+    }
   }
   struct A {
     const char* name;
@@ -857,8 +932,9 @@ static void run_single(int argc, char** argv) {
     fill_random(x, rng, 1.f);
     fill_random(w, rng, 0.02f);
     fill_random(b, rng, 0.02f);
-    double ms = time_ms(iters, [&] { X2V_OKAY(x2v_gemm_bf16(x.p, K, w.p, K, b.p, y.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, nullptr)); });
-    printf("pgemm M=%lld N=%d K=%d: %.3f ms %.1f TFLOP/s\n", (long long)M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
+    const int variant = argc > 6 ? atoi(argv[6]) : 0;
+    double ms = time_ms(iters, [&] { X2V_OKAY(x2v_gemm_bf16_variant(x.p, K, w.p, K, b.p, y.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, variant, nullptr)); });
+    printf("pgemm variant=%d M=%lld N=%d K=%d: %.3f ms %.1f TFLOP/s\n", variant, (long long)M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
   }
 }
 
