@@ -1,0 +1,19 @@
+"""Ulysses path on the GPU: two ranks share cuda:0 (one-GPU box), gloo process group with host-staged collectives
+(test-only shim in tests/_dist_gpu_worker.py); the sharded HIP forward must match the single-GPU HIP forward."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_ulysses_world2_on_one_gpu():
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "DIST_GPU_OK" in p.stdout
