@@ -137,6 +137,34 @@ int x2v_sinusoid_embed_bf16(const int64_t* t, void* y, int n, int dim, void* str
 int x2v_causal_conv3d_f32(const float* x, const float* cache, int cache_frames, const float* w, const float* bias, float* y, int T, int Hh, int Ww,
                           int Cin, int Cout, int kt, int kh, int kw, void* stream);
 
+/* ---- Wan VAE decoder (models/video_encoders/hf/wan/vae.py), fp32, channels-last --------------------------------
+ * Convolution inputs live in zero-bordered buffers [lead + T][H + 2*ph][W + 2*pw][C] whose `lead` = kt-1 leading
+ * frames are the reference's per-conv feature cache (CACHE_T = 2, vae.py:16); see lightx2v_amd/csrc/vae.hip. */
+
+#define X2V_VCONV_CLAMP 1  /* clamp the result to [-1, 1] (WanVAE.decode: .clamp_(-1, 1), vae.py:951-955) */
+#define X2V_VCONV_TSPLIT 2 /* Cout = 2C: channel block j of frame t goes to frame 2t + j (Resample upsample3d, vae.py:136-138) */
+
+/* y[t,h,w,co] = bias[co] + resid[t,h,w,co] + sum_{dt,dh,dw,c} xp[(t+dt)*fs + (h+dh)*rs + (w+dw)*ps + c] * w[co*wrs + ((dt*kh+dh)*kw+dw)*Cin + c]
+ * — replaces CausalConv3d.forward (vae.py:19-44), the decoder's nn.Conv2d (vae.py:87-95) and, with kt=kh=kw=1, its
+ * 1x1 convolutions and the attention block's GEMMs (vae.py:226-262).  `xp` points at the element tap (0,0,0) of output
+ * pixel (0,0,0) reads (strides in floats; borders must be zero).  fp32 in/out on the fp32-input MFMA.
+ * Cin % 16 == 0; strides % 4 == 0; bias/resid optional; resid has y's layout; y is [T,H,W,Cout] (or [2T,H,W,Cout/2]
+ * with X2V_VCONV_TSPLIT). */
+int x2v_vae_conv_f32(const float* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const float* w, int64_t w_row_stride,
+                     const float* bias, const float* resid, float* y, int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags,
+                     void* stream);
+
+/* Pixel-wise producer of conv input buffers — replaces RMS_norm (vae.py:47-59) + nn.SiLU (ResidualBlock, head),
+ * Upsample nearest-exact x2 (vae.py:62-67) and the latent un-normalisation z / scale[1] + scale[0] (vae.py:716-719):
+ *   v = x[t,h,w,:];  gamma != NULL: v = v / max(||v||_2, 1e-12) * sqrt(C) * gamma;  else v = v / a + b (a, b optional);
+ *   silu: v *= sigmoid(v);  written to y + t*y_frame_stride + h*y_row_stride + w*C (2x2 replicated when upsample). */
+int x2v_vae_prep_f32(const float* x, float* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a, const float* b, int silu, int upsample,
+                     int64_t y_frame_stride, int64_t y_row_stride, void* stream);
+
+/* In-place s[M,N] = softmax(scale * s) rows, fp32 — the softmax of F.scaled_dot_product_attention in the VAE
+ * AttentionBlock (vae.py:249-253).  N % 4 == 0. */
+int x2v_softmax_rows_f32(float* s, int64_t ld, int64_t M, int N, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

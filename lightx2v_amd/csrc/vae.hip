@@ -1,0 +1,377 @@
+// Wan VAE decoder kernels (fp32, channels-last): implicit-GEMM convolution over a zero-bordered input buffer on the
+// fp32-input MFMA, the pixel-wise RMS_norm + SiLU (+ nearest 2x upsample, + per-channel affine) producer that writes
+// such buffers, and the row softmax of the decoder's single-head attention block.
+//
+// reference: models/video_encoders/hf/wan/vae.py — CausalConv3d :19-44, RMS_norm :47-59, Upsample :62-67,
+// Resample :70-159, ResidualBlock :185-223, AttentionBlock :226-262, Decoder3d :377-489, WanVAE_.decode :713-738.
+// The reference decodes in fp32 (vae.py:794); v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain at the fp32 vector
+// rate (157 TFLOP/s dense peak), so the reduction runs on the matrix pipe without changing the numerics class.
+//
+// Data layout (MI355X-first, 288 GB): every convolution input lives in its own persistent buffer
+//   [lead + T frames][H + 2*ph][W + 2*pw][C]  fp32, channels-last, borders zero,
+// where the `lead` = kt-1 leading frames ARE the reference's per-conv feature cache (CACHE_T = 2 frames, vae.py:16;
+// the cache update rule "last two frames of [cache | x]" is a 2-frame move inside the buffer).  With the halo
+// materialised, the input address of (output pixel, tap, channel) is  pixel_base + tap_offset + channel: the first
+// term is a loop-invariant per-lane VGPR, the rest is wave-uniform and travels in the buffer-load soffset — the K
+// loop issues LDS-DMA with zero address arithmetic and needs no border predicates.
+//
+// conv kernel: workgroup = 4 waves = 256 output pixels (consecutive in h*W+w order of one frame) x 32*NF output
+// channels; wave = 64 pixels x 32*NF channels = 2 x NF MFMA tiles (acc 32*NF VGPRs); K loop over (tap, KC-channel
+// slab): A slab [256 px][KC] and B slab [32*NF couts][KC] staged by LDS-DMA, double buffered, 16-byte chunks
+// XOR-swizzled on the source offset and on the ds_read_b128 address (same involution as gemm256.hip).  One
+// ds_read_b128 feeds 4 MFMAs (lane (fl, fh) holds k = 8j + 4fh + e for MFMA e), so LDS traffic is negligible; a
+// K step carries 32*NF fp32 MFMAs of 64 cycles per wave, which hides the next slab's DMA behind one barrier.
+// Bound: MFMA fp32 (157 TFLOP/s); algorithmic work 2 * T*H*W * Cout * Cin * taps FLOP per launch.
+#include <algorithm>
+
+#include "x2v_common.h"
+
+namespace x2v {
+
+typedef __attribute__((address_space(3))) void* v_lds_ptr_t;
+
+constexpr int VC_PIX = 256;
+constexpr unsigned VC_OOB = 0x80000000u;  // voffset of a masked row: beyond any descriptor range we build (< 2 GiB)
+
+// flags of x2v_vae_conv_f32
+constexpr int VCF_CLAMP = 1;   // clamp the result to [-1, 1] (WanVAE.decode, vae.py:951-955)
+constexpr int VCF_TSPLIT = 2;  // Cout = 2C: channel block j of frame t -> frame 2t + j (Resample upsample3d, vae.py:136-138)
+
+template <int NF, int KC>
+__global__ __launch_bounds__(256) void vae_conv_kernel(const float* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
+                                                       const float* __restrict__ w, int64_t w_row_stride, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ y, int T, int Hh, int Ww, int Cin, int Cout,
+                                                       int kt, int kh, int kw, int flags, int ncol) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = KC * 4;                   // bytes per staged row
+  constexpr int CPR = KC / 4;                    // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;                  // rows per wave-instruction
+  constexpr int BN = 32 * NF;
+  constexpr int A_BYTES = VC_PIX * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = 64 / RPI;              // DMA instructions per wave for its 64 A rows
+  constexpr int B_INSTR = (BN / 4 + RPI - 1) / RPI;  // ... for its BN/4 B rows (rounded up; extra rows masked)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, fh = lane >> 5;
+  const int HW = Hh * Ww;
+  const int tiles_per_frame = (HW + VC_PIX - 1) / VC_PIX;
+  const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+  const int ptile = (int)(v / (unsigned)ncol), ctile = (int)(v % (unsigned)ncol);
+  const int frame = ptile / tiles_per_frame;
+  const int p0 = (ptile % tiles_per_frame) * VC_PIX;
+  const int co0 = ctile * BN;
+  const int taps = kt * kh * kw;
+
+  // descriptors: input = kt frames starting at this output frame; weights = rows co0 .. Cout
+  const int64_t fbytes = x_frame_stride * 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xp + (int64_t)frame * x_frame_stride), 0, (unsigned)(fbytes * kt), 0x00020000);
+  const int wrows = min(BN, Cout - co0);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(w + (int64_t)co0 * w_row_stride), 0, (unsigned)(((int64_t)(wrows - 1) * w_row_stride + (int64_t)taps * Cin) * 4), 0x00020000);
+
+  // per-lane DMA source offsets (bytes): A rows = this wave's 64 pixels, B rows = this wave's quarter of the couts
+  constexpr int swz_shift = (KC == 32) ? 1 : 2;  // rows sharing one 256-byte bank row
+  unsigned a_voff[A_INSTR], b_voff[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int r = wid * 64 + i * RPI + lane / CPR;  // tile row = pixel
+    const int c = (lane % CPR) ^ ((r >> swz_shift) & (CPR - 1));
+    const int p = p0 + r;
+    const int ph = p / Ww, pw = p - ph * Ww;
+    a_voff[i] = p < HW ? (unsigned)(((int64_t)ph * x_row_stride + (int64_t)pw * x_px_stride) * 4) + (unsigned)(c << 4) : VC_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int rl = i * RPI + lane / CPR;            // row within this wave's share
+    const int r = wid * (BN / 4) + rl;
+    const int c = (lane % CPR) ^ ((r >> swz_shift) & (CPR - 1));
+    b_voff[i] = (rl < BN / 4 && r < wrows) ? (unsigned)((int64_t)r * w_row_stride * 4) + (unsigned)(c << 4) : VC_OOB;
+  }
+  const int kchunks = Cin / KC;
+  const int nsteps = taps * kchunks;
+  auto stage = [&](int s, int step) {
+    const int tap = step / kchunks, kc = step - tap * kchunks;
+    const int dt = tap / (kh * kw), dh = (tap / kw) % kh, dw = tap % kw;
+    const unsigned xso = (unsigned)(((int64_t)dt * x_frame_stride + (int64_t)dh * x_row_stride + (int64_t)dw * x_px_stride + (int64_t)kc * KC) * 4);
+    const unsigned wso = (unsigned)(((int64_t)tap * Cin + (int64_t)kc * KC) * 4);
+    char* as = smem + s * STAGE + wid * (64 * ROWB);
+    char* bs = smem + s * STAGE + A_BYTES + wid * ((BN / 4) * ROWB);
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (v_lds_ptr_t)(as + i * 1024), 16, a_voff[i], xso, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      if ((i + 1) * RPI <= BN / 4 || lane / CPR + i * RPI < BN / 4)  // the last instruction may cover fewer rows
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (v_lds_ptr_t)(bs + i * 1024), 16, b_voff[i], wso, 0, 0);
+  };
+
+  // fragment read offsets: row (32-row block + fl), chunk (j*2 + fh) ^ swizzle
+  int rd[KC / 8];
+#pragma unroll
+  for (int j = 0; j < KC / 8; ++j) rd[j] = fl * ROWB + ((((j << 1) | fh) ^ ((fl >> swz_shift) & (CPR - 1))) << 4);
+
+  f32x16_t acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps) stage(cur ^ 1, step + 1);
+    const char* ab = smem + cur * STAGE + wid * (64 * ROWB);
+    const char* bb = smem + cur * STAGE + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < KC / 8; ++j) {
+      f32x4_t xa[2], wb[NF];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xa[i] = *reinterpret_cast<const f32x4_t*>(ab + i * 32 * ROWB + rd[j]);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) wb[n] = *reinterpret_cast<const f32x4_t*>(bb + n * 32 * ROWB + rd[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[n][e], xa[i][e], acc[i][n], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[i][n][r]: pixel p0 + wid*64 + i*32 + fl, cout co0 + n*32 + (r&3) + 8*(r>>2) + 4*fh
+  const bool vec_ok = (Cout & 3) == 0;
+  const int csplit = (flags & VCF_TSPLIT) ? Cout / 2 : Cout;  // channels per output pixel
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = p0 + wid * 64 + i * 32 + fl;
+    if (p >= HW) continue;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + n * 32 + 8 * g + 4 * fh;
+        if (co >= Cout) continue;
+        float vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = acc[i][n][4 * g + e];
+        int64_t oidx;
+        if (flags & VCF_TSPLIT) {
+          const int hi = co >= csplit ? 1 : 0;
+          oidx = ((int64_t)(2 * frame + hi) * HW + p) * csplit + (co - hi * csplit);
+        } else {
+          oidx = ((int64_t)frame * HW + p) * Cout + co;
+        }
+        if (vec_ok) {
+          if (bias != nullptr) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + co);
+            vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w;
+          }
+          if (resid != nullptr) {
+            const float4 r4 = *reinterpret_cast<const float4*>(resid + oidx);
+            vv[0] += r4.x; vv[1] += r4.y; vv[2] += r4.z; vv[3] += r4.w;
+          }
+          if (flags & VCF_CLAMP) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = fminf(fmaxf(vv[e], -1.f), 1.f);
+          }
+          *reinterpret_cast<float4*>(y + oidx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < Cout) {
+              float o = vv[e] + (bias != nullptr ? bias[co + e] : 0.f) + (resid != nullptr ? resid[oidx + e] : 0.f);
+              if (flags & VCF_CLAMP) o = fminf(fmaxf(o, -1.f), 1.f);
+              y[oidx + e] = o;
+            }
+        }
+      }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pixel-wise producer of convolution input buffers:
+//   v = x[t,h,w,:];  norm: v = v / max(||v||_2, 1e-12) * sqrt(C) * gamma   (RMS_norm, vae.py:47-59: F.normalize * scale * gamma)
+//   else affine: v = v / a + b (per channel, either may be NULL)                 (z un-normalisation, vae.py:716-719)
+//   silu: v = v * sigmoid(v)                                                     (nn.SiLU in ResidualBlock / head)
+//   up: the result is written to the 2x2 output pixels (2h+{0,1}, 2w+{0,1})       (Upsample nearest-exact x2, vae.py:62-67,87-95)
+// Output addressing: y + t*y_frame_stride + h*y_row_stride + w*C (the caller passes y already offset to the
+// interior origin of a zero-bordered buffer).  One group of LPP lanes per pixel, 16-byte accesses.
+template <int LPP>
+__global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ a, const float* __restrict__ b,
+                                                       int silu, int up, int64_t y_frame_stride, int64_t y_row_stride) {
+  constexpr int GPB = 256 / LPP;  // pixel groups per block
+  const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+  const int nch = C / 4;
+  const float rms_scale = sqrtf((float)C);
+  for (int64_t pix = (int64_t)blockIdx.x * GPB + g; pix < npix; pix += (int64_t)gridDim.x * GPB) {
+    const float* xr = x + pix * C;
+    float4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = l + k * LPP;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < nch) {
+        v[k] = *reinterpret_cast<const float4*>(xr + c4 * 4);
+        ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+      }
+    }
+    float inv = 1.f;
+    if (gamma != nullptr) {
+#pragma unroll
+      for (int o = LPP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      inv = rms_scale / fmaxf(sqrtf(ss), 1e-12f);
+    }
+    const int64_t t = pix / ((int64_t)Hh * Ww);
+    const int rem = (int)(pix - t * (int64_t)Hh * Ww);
+    const int h = rem / Ww, wq = rem - h * Ww;
+    float* yb = y + t * y_frame_stride + (int64_t)(up ? 2 * h : h) * y_row_stride + (int64_t)(up ? 2 * wq : wq) * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = l + k * LPP;
+      if (c4 >= nch) continue;
+      float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      if (gamma != nullptr) {
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+        o[0] = o[0] * inv * gm.x; o[1] = o[1] * inv * gm.y; o[2] = o[2] * inv * gm.z; o[3] = o[3] * inv * gm.w;
+      } else {
+        if (a != nullptr) {
+          const float4 av = *reinterpret_cast<const float4*>(a + c4 * 4);
+          o[0] /= av.x; o[1] /= av.y; o[2] /= av.z; o[3] /= av.w;
+        }
+        if (b != nullptr) {
+          const float4 bv = *reinterpret_cast<const float4*>(b + c4 * 4);
+          o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+        }
+      }
+      if (silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] / (1.f + __expf(-o[e]));
+      }
+      const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(yb + c4 * 4) = ov;
+      if (up) {
+        *reinterpret_cast<float4*>(yb + C + c4 * 4) = ov;
+        *reinterpret_cast<float4*>(yb + y_row_stride + c4 * 4) = ov;
+        *reinterpret_cast<float4*>(yb + y_row_stride + C + c4 * 4) = ov;
+      }
+    }
+  }
+}
+
+// In-place row softmax of s[M][N] fp32 with a pre-scale: s = softmax(scale * s) — the attention block's
+// F.scaled_dot_product_attention (vae.py:249-253) split as GEMM / softmax / GEMM.  One 256-thread block per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int64_t lds_, int64_t M, int N, float scale) {
+  __shared__ float red[4];
+  float* row = s + (int64_t)blockIdx.x * lds_;
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  mx = block_max<4>(mx, red) * scale;
+  float sum = 0.f;
+  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+    float4 v = *reinterpret_cast<const float4*>(row + i);
+    v.x = __expf(v.x * scale - mx); v.y = __expf(v.y * scale - mx); v.z = __expf(v.z * scale - mx); v.w = __expf(v.w * scale - mx);
+    sum += (v.x + v.y) + (v.z + v.w);
+    *reinterpret_cast<float4*>(row + i) = v;
+  }
+  sum = block_sum<4>(sum, red);
+  const float inv = 1.f / sum;
+  for (int i = threadIdx.x * 4; i < N; i += 1024) {
+    float4 v = *reinterpret_cast<const float4*>(row + i);
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    *reinterpret_cast<float4*>(row + i) = v;
+  }
+}
+
+}  // namespace x2v
+
+using namespace x2v;
+
+template <int NF, int KC>
+static int launch_vconv(const float* xp, int64_t fs, int64_t rs, int64_t ps, const float* w, int64_t wrs, const float* bias, const float* resid, float* y,
+                        int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, hipStream_t st) {
+  constexpr int lds = 2 * (VC_PIX + 32 * NF) * KC * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)vae_conv_kernel<NF, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "vae conv attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  const int64_t ptiles = (int64_t)T * (((int64_t)Hh * Ww + VC_PIX - 1) / VC_PIX);
+  const int ncol = (Cout + 32 * NF - 1) / (32 * NF);
+  X2V_REQUIRE(ptiles * ncol < (1ll << 31), X2V_E_SHAPE, "vae_conv: too many tiles");
+  hipLaunchKernelGGL((vae_conv_kernel<NF, KC>), dim3((unsigned)(ptiles * ncol)), dim3(256), lds, st, xp, fs, rs, ps, w, wrs, bias, resid, y, T, Hh, Ww, Cin, Cout,
+                     kt, kh, kw, flags, ncol);
+  X2V_LAUNCH_CHECK("vae_conv launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f32(const float* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
+                                                                       const float* w, int64_t w_row_stride, const float* bias, const float* resid, float* y,
+                                                                       int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags,
+                                                                       void* stream) {
+  X2V_REQUIRE(xp && w && y, X2V_E_ARG, "vae_conv: null pointer");
+  X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && Cin > 0 && Cout > 0, X2V_E_SHAPE, "vae_conv: bad shape");
+  X2V_REQUIRE(kt >= 1 && kt <= 3 && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3, X2V_E_SHAPE, "vae_conv: kernel %dx%dx%d unsupported", kt, kh, kw);
+  X2V_REQUIRE(Cin % 16 == 0, X2V_E_SHAPE, "vae_conv: Cin=%d must be a multiple of 16", Cin);
+  X2V_REQUIRE(x_px_stride % 4 == 0 && x_row_stride % 4 == 0 && x_frame_stride % 4 == 0 && w_row_stride % 4 == 0 && x_px_stride >= Cin &&
+                  w_row_stride >= (int64_t)kt * kh * kw * Cin,
+              X2V_E_ALIGN, "vae_conv: strides must be multiples of 4 floats and cover the extents");
+  X2V_REQUIRE(aligned16(xp) && aligned16(w) && aligned16(y) && aligned16(resid) && aligned16(bias), X2V_E_ALIGN, "vae_conv: pointers must be 16-byte aligned");
+  X2V_REQUIRE(x_frame_stride * 4 * kt < (1ll << 31) && w_row_stride * 4 * 128 < (1ll << 31), X2V_E_SHAPE,
+              "vae_conv: a kt-frame input window / 128 weight rows must stay below 2 GiB (32-bit buffer offsets)");
+  X2V_REQUIRE(!(flags & VCF_TSPLIT) || (Cout % 8 == 0 && resid == nullptr), X2V_E_ARG, "vae_conv: time-split output needs Cout %% 8 == 0 and no residual");
+  hipStream_t st = (hipStream_t)stream;
+#define X2V_VC(NF_, KC_) return launch_vconv<NF_, KC_>(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, kh, kw, flags, st)
+  const bool k32 = Cin % 32 == 0;
+  if (Cout <= 32) {
+    if (k32) X2V_VC(1, 32); else X2V_VC(1, 16);
+  } else if (Cout % 128 != 0 && Cout % 96 == 0) {
+    if (k32) X2V_VC(3, 32); else X2V_VC(3, 16);
+  } else if (Cout <= 64) {
+    if (k32) X2V_VC(2, 32); else X2V_VC(2, 16);
+  } else {
+    if (k32) X2V_VC(4, 32); else X2V_VC(4, 16);
+  }
+#undef X2V_VC
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_f32(const float* x, float* y, int T, int Hh, int Ww, int C, const float* gamma,
+                                                                       const float* a, const float* b, int silu, int upsample, int64_t y_frame_stride,
+                                                                       int64_t y_row_stride, void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "vae_prep: null pointer");
+  X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 4 == 0 && C <= 1024, X2V_E_SHAPE, "vae_prep: bad shape (C %% 4 == 0, C <= 1024)");
+  X2V_REQUIRE(y_frame_stride % 4 == 0 && y_row_stride % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(a) && aligned16(b), X2V_E_ALIGN,
+              "vae_prep: 16-byte alignment");
+  const int64_t npix = (int64_t)T * Hh * Ww;
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 128) {
+    const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride);
+  } else {
+    const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride);
+  }
+  X2V_LAUNCH_CHECK("vae_prep launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_softmax_rows_f32(float* s, int64_t ld, int64_t M, int N, float scale, void* stream) {
+  X2V_REQUIRE(s, X2V_E_ARG, "softmax_rows: null pointer");
+  X2V_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ld >= N && M < (1ll << 31), X2V_E_SHAPE, "softmax_rows: bad shape (N %% 4 == 0)");
+  X2V_REQUIRE(aligned16(s), X2V_E_ALIGN, "softmax_rows: 16-byte alignment");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, s, ld, M, N, scale);
+  X2V_LAUNCH_CHECK("softmax_rows launch");
+  return X2V_OK;
+}

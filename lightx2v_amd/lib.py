@@ -38,6 +38,9 @@ PROTOTYPES = {
     "x2v_gemm_fp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
     "x2v_sinusoid_embed_bf16": [_c_void_p, _c_void_p, _i32, _i32, _c_void_p],
     "x2v_causal_conv3d_f32": [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+    "x2v_vae_conv_f32": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+    "x2v_vae_prep_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _c_void_p],
+    "x2v_softmax_rows_f32": [_c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
 }
 _RESTYPES = {"x2v_last_error": ctypes.c_char_p, "x2v_version": ctypes.c_char_p}
 
@@ -258,3 +261,45 @@ def causal_conv3d(x, weight, bias=None, cache=None):
     init()
     _check(_lib.x2v_causal_conv3d_f32(_p(x), _p(cache), nc, _p(weight), _p(bias), _p(out), T, H, W, Cin, Cout, kt, kh, kw, _stream()), "causal_conv3d")
     return out
+
+
+VCONV_CLAMP, VCONV_TSPLIT = 1, 2
+
+
+def _f32c(t, name):
+    if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+        raise X2VError(f"{name}: expected a float32 device tensor")
+    return t
+
+
+def vae_conv(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0, w_row_stride=None, cin=None):
+    """Implicit-GEMM convolution over a zero-bordered buffer (x2v_vae_conv_f32).  `xp`: tensor VIEW whose first element is
+    what tap (0,0,0) of output pixel (0,0,0) reads; strides = (frame, row, pixel) in floats; weight [Cout,kt,kh,kw,Cin]
+    (or [Cout, K] with kt=kh=kw=1); out [T,H,W,Cout] (preallocated, contiguous)."""
+    _f32c(xp, "vae_conv x"), _f32c(weight, "vae_conv weight"), _f32c(out, "vae_conv out")
+    if weight.dim() == 5:
+        Cout, kt, kh, kw, Cin = weight.shape
+    else:
+        Cout, kt, kh, kw = weight.shape[0], 1, 1, 1
+        Cin = weight.shape[1] if cin is None else cin
+    wrs = weight.stride(0) if w_row_stride is None else w_row_stride
+    fs, rs, ps = strides
+    init()
+    _check(_lib.x2v_vae_conv_f32(_p(xp), fs, rs, ps, _p(weight), wrs, _p(bias), _p(resid), _p(out), T, H, W, Cin, Cout, kt, kh, kw, flags, _stream()), "vae_conv")
+    return out
+
+
+def vae_prep(x, y_view, y_strides, gamma=None, a=None, b=None, silu=False, upsample=False):
+    """x [T,H,W,C] contiguous fp32 -> y_view (first element = destination of pixel (0,0,0)); y_strides = (frame, row) in floats."""
+    _f32c(x, "vae_prep x"), _f32c(y_view, "vae_prep y")
+    T, H, W, C = x.shape
+    init()
+    _check(_lib.x2v_vae_prep_f32(_p(x), _p(y_view), T, H, W, C, _p(gamma), _p(a), _p(b), int(silu), int(upsample), y_strides[0], y_strides[1], _stream()), "vae_prep")
+
+
+def softmax_rows_(s, scale):
+    _f32c(s, "softmax_rows")
+    M, N = s.shape
+    init()
+    _check(_lib.x2v_softmax_rows_f32(_p(s), s.stride(0), M, N, float(scale), _stream()), "softmax_rows")
+    return s

@@ -92,3 +92,70 @@ def synth_inputs(dims, target_shape, seed=42, device="cpu"):
     ctx = torch.randn(n_tok, text_dim, generator=g1).to(torch.bfloat16)
     ctx_null = torch.randn(max(4, n_tok // 8), text_dim, generator=g2).to(torch.bfloat16)
     return latents.to(device), [ctx.to(device)], [ctx_null.to(device)]
+
+
+# Wan2.1 VAE latent statistics (model constants of the released VAE: vae.py:804-839)
+WAN_VAE_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+WAN_VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+def wan_vae_decoder_plan(dim=96, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_upsample=(True, True, False)):
+    """Decoder3d.__init__ (vae.py:377-434): channel plan and the `upsamples` Sequential as (index, kind, in_dim, out_dim)."""
+    dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+    plan, idx = [], 0
+    for i, (in_dim, out_dim) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            in_dim = in_dim // 2
+        for _ in range(num_res_blocks + 1):
+            plan.append((idx, "res", in_dim, out_dim))
+            idx += 1
+            in_dim = out_dim
+        if i != len(dim_mult) - 1:
+            plan.append((idx, "upsample3d" if temperal_upsample[i] else "upsample2d", out_dim, out_dim // 2))
+            idx += 1
+    return dims, plan
+
+
+def synth_wan_vae_weights(dim=96, z_dim=16, seed=0, device="cpu"):
+    """Seeded fp32 weights of the Wan VAE *decoder* under the reference's state-dict names (`decoder.*`, `conv2.*`;
+    WanVAE_ / Decoder3d module tree, vae.py:377-434,640-676).  Convs are scaled ~1/sqrt(fan_in) so activations stay O(1)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, *k, gain=1.0):
+        fan = cin
+        for kk in k:
+            fan *= kk
+        sd[f"{name}.weight"] = (torch.randn((cout, cin, *k), generator=gen) * (gain / math.sqrt(fan))).to(device)
+        sd[f"{name}.bias"] = (torch.randn((cout,), generator=gen) * 0.05).to(device)
+
+    def gamma(name, c, *ones):
+        sd[name] = (1.0 + 0.1 * torch.randn((c, *ones), generator=gen)).to(device)
+
+    def res(p, cin, cout):
+        gamma(p + "residual.0.gamma", cin, 1, 1, 1)
+        conv(p + "residual.2", cout, cin, 3, 3, 3, gain=1.4)
+        gamma(p + "residual.3.gamma", cout, 1, 1, 1)
+        conv(p + "residual.6", cout, cout, 3, 3, 3, gain=1.4)
+        if cin != cout:
+            conv(p + "shortcut", cout, cin, 1, 1, 1)
+
+    dims, plan = wan_vae_decoder_plan(dim)
+    conv("conv2", z_dim, z_dim, 1, 1, 1)
+    conv("decoder.conv1", dims[0], z_dim, 3, 3, 3)
+    res("decoder.middle.0.", dims[0], dims[0])
+    gamma("decoder.middle.1.norm.gamma", dims[0], 1, 1)
+    conv("decoder.middle.1.to_qkv", dims[0] * 3, dims[0], 1, 1)
+    conv("decoder.middle.1.proj", dims[0], dims[0], 1, 1)
+    res("decoder.middle.2.", dims[0], dims[0])
+    for idx, kind, cin, cout in plan:
+        p = f"decoder.upsamples.{idx}."
+        if kind == "res":
+            res(p, cin, cout)
+        else:
+            conv(p + "resample.1", cin // 2, cin, 3, 3)
+            if kind == "upsample3d":
+                conv(p + "time_conv", cin * 2, cin, 3, 1, 1)
+    gamma("decoder.head.0.gamma", dims[-1], 1, 1, 1)
+    conv("decoder.head.2", 3, dims[-1], 3, 3, 3, gain=0.5)
+    return sd

@@ -1,0 +1,207 @@
+"""Wan VAE decode on the HIP kernels of csrc/vae.hip — host-side mirror of the reference's decode path.
+
+reference: lightx2v/models/video_encoders/hf/wan/vae.py — WanVAE.decode :931-957 → WanVAE_.decode :713-738 →
+Decoder3d.forward :436-489 → ResidualBlock :185-223 / AttentionBlock :226-262 / Resample :70-159 / CausalConv3d :19-44.
+Same class and method names, same state-dict tensor names (`decoder.*`, `conv2.*`), same chunking (one latent frame
+at a time through a decoder that carries a 2-frame cache per causal conv), fp32 like the reference (vae.py:794).
+
+What is laid out differently for the MI355X (288 GB HBM, fp32-input MFMA):
+  * activations are channels-last [T, H, W, C] so both implicit-GEMM operands are K-contiguous;
+  * every 3x3(x3) convolution reads a persistent zero-bordered buffer [2 + T][H+2][W+2][C]; its two leading frames
+    ARE the reference's feat_cache entry (update rule "last two frames of [cache | x]" = one 2-frame move), so there
+    is no torch.cat / F.pad / clone per conv per chunk (vae.py:36-41,199-214);
+  * RMS_norm + SiLU (and the nearest-exact 2x upsample, and the latent un-normalisation) are one pixel-wise kernel
+    that writes straight into the next convolution's buffer; residual adds, the final clamp and the upsample3d
+    channel→frame interleave (vae.py:136-138) are convolution epilogues;
+  * the single-head attention block is GEMM (QK^T) → row softmax → GEMM (PV) on the same fp32 MFMA convolution
+    kernel (1x1 taps), per frame.
+Torch is used for allocation, 2-frame cache moves (copy_), the V transpose and the boundary layout changes
+([C,T,H,W] ↔ channels-last) — memory plumbing, no arithmetic.
+"""
+import torch
+
+from . import lib, synth
+
+
+class _ConvInput:
+    """Zero-bordered, cache-carrying input buffer of one convolution: [lead + t_max][H + 2p][W + 2p][C]."""
+
+    def __init__(self, t_max, h, w, c, kt, pad, device):
+        self.lead, self.pad, self.h, self.w, self.c = kt - 1, pad, h, w, c
+        self.hp, self.wp = h + 2 * pad, w + 2 * pad
+        self.buf = torch.zeros((self.lead + t_max, self.hp, self.wp, c), dtype=torch.float32, device=device)
+        self.strides = (self.hp * self.wp * c, self.wp * c, c)  # frame, row, pixel (floats)
+
+    def interior(self):
+        """View whose first element is where pixel (t=0, h=0, w=0) of the new frames goes."""
+        return self.buf[self.lead :, self.pad :, self.pad :, :]
+
+    def roll(self, t):
+        """Cache update (vae.py:199-214): keep the last `lead` frames of [cache | x]."""
+        if self.lead == 0:
+            return
+        if t >= self.lead:
+            self.buf[: self.lead].copy_(self.buf[t : t + self.lead])
+        else:  # overlapping move: frame by frame, front to back
+            for i in range(self.lead):
+                self.buf[i].copy_(self.buf[i + t])
+
+    def reset(self):
+        if self.lead:
+            self.buf[: self.lead].zero_()
+
+
+def _cl(weight):
+    """[Cout, Cin, (kt,) kh, kw] → [Cout, kt, kh, kw, Cin] contiguous (load-time layout change)."""
+    if weight.dim() == 4:
+        weight = weight.unsqueeze(2)
+    return weight.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class Decoder3d:
+    """reference: vae.py:377-489."""
+
+    def __init__(self, sd, dim, latent_hw, device):
+        self.device = device
+        self.dims, self.plan = synth.wan_vae_decoder_plan(dim)
+        self.w = {}
+        for k, v in sd.items():
+            if not k.startswith("decoder."):
+                continue
+            v = v.to(device=device, dtype=torch.float32)
+            self.w[k] = _cl(v) if (k.endswith(".weight") and v.dim() >= 4) else v.reshape(-1).contiguous()
+        self.h0, self.w0 = latent_hw
+        self._bufs = {}
+        self._rep = {}  # upsample3d time-conv state: False until the first chunk has passed (the reference's "Rep", vae.py:113-115)
+
+    # ---- buffers ------------------------------------------------------------------------------------------------------
+    def _input(self, key, t, h, w, c, kt, pad):
+        b = self._bufs.get(key)
+        if b is None or b.buf.shape[0] < b.lead + t:
+            nb = _ConvInput(max(t, 4 if kt == 3 else t), h, w, c, kt, pad, self.device)
+            if b is not None and b.lead:
+                nb.buf[: b.lead].copy_(b.buf[: b.lead])
+            self._bufs[key] = b = nb
+        return b
+
+    def clear_cache(self):
+        """reference: WanVAE_.clear_cache (vae.py:752-760)."""
+        for b in self._bufs.values():
+            b.reset()
+        self._rep = {}
+
+    # ---- layers -------------------------------------------------------------------------------------------------------
+    def _conv_cached(self, key, name, x, gamma=None, silu=False, resid=None, flags=0, upsample=False, kt=3):
+        """[RMS_norm → SiLU →] (cached, zero-padded) conv `name` on plain x [T,H,W,C]; returns plain [T',H',W',Cout]."""
+        t, h, w, c = x.shape
+        wt = self.w[name + ".weight"]
+        cout, wkt, kh, kw, _ = wt.shape
+        ho, wo = (2 * h, 2 * w) if upsample else (h, w)
+        b = self._input(key, t, ho, wo, c, wkt, kh // 2)
+        lib.vae_prep(x, b.interior(), b.strides[:2], gamma=gamma, silu=silu, upsample=upsample)
+        if flags & lib.VCONV_TSPLIT:
+            out = torch.empty((2 * t, ho, wo, cout // 2), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((t, ho, wo, cout), dtype=torch.float32, device=x.device)
+        lib.vae_conv(b.buf, b.strides, wt, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
+        b.roll(t)
+        return out
+
+    def _conv1x1(self, name, x, resid=None):
+        t, h, w, c = x.shape
+        wt = self.w[name + ".weight"]
+        out = torch.empty((t, h, w, wt.shape[0]), dtype=torch.float32, device=x.device)
+        lib.vae_conv(x, (h * w * c, w * c, c), wt, out, t, h, w, bias=self.w[name + ".bias"], resid=resid)
+        return out
+
+    def residual_block(self, p, x):
+        """reference: ResidualBlock.forward (vae.py:185-223)."""
+        h = self._conv1x1(p + "shortcut", x) if (p + "shortcut.weight") in self.w else x
+        y = self._conv_cached(p + "c1", p + "residual.2", x, gamma=self.w[p + "residual.0.gamma"], silu=True)
+        return self._conv_cached(p + "c2", p + "residual.6", y, gamma=self.w[p + "residual.3.gamma"], silu=True, resid=h)
+
+    def attention_block(self, p, x):
+        """reference: AttentionBlock.forward (vae.py:226-262) — per frame, one head of dim C over h*w tokens."""
+        t, h, w, c = x.shape
+        n = h * w
+        if n % 16:
+            raise lib.X2VError(f"VAE attention: h*w = {n} must be a multiple of 16 (the PV GEMM reduces over tokens)")
+        xn = torch.empty_like(x)
+        lib.vae_prep(x, xn, (n * c, w * c), gamma=self.w[p + "norm.gamma"])
+        qkv = self._conv1x1(p + "to_qkv", xn)  # [t, h, w, 3C]
+        out = torch.empty_like(x)
+        scores = torch.empty((n, n), dtype=torch.float32, device=x.device)
+        o = torch.empty((1, 1, n, c), dtype=torch.float32, device=x.device)
+        for f in range(t):
+            q = qkv[f].reshape(n, 3 * c)
+            k = q[:, c : 2 * c]
+            vt = q[:, 2 * c :].t().contiguous()  # [C, n]: the PV GEMM wants the reduction index contiguous
+            # S = Q K^T: "pixels" = query tokens (stride 3C), "weights" = key rows (stride 3C)
+            lib.vae_conv(q, (n * 3 * c, n * 3 * c, 3 * c), k, scores, 1, 1, n, w_row_stride=3 * c, cin=c)
+            lib.softmax_rows_(scores, 1.0 / (c**0.5))
+            lib.vae_conv(scores, (n * n, n * n, n), vt, o, 1, 1, n)
+            lib.vae_conv(o, (n * c, w * c, c), self.w[p + "proj.weight"], out[f : f + 1], 1, h, w, bias=self.w[p + "proj.bias"], resid=x[f : f + 1])
+        return out
+
+    def resample(self, p, x, mode):
+        """reference: Resample.forward, upsample2d / upsample3d (vae.py:108-143)."""
+        if mode == "upsample3d":
+            if not self._rep.get(p, False):
+                self._rep[p] = True  # first chunk: no temporal upsampling, nothing cached
+            else:
+                x = self._conv_cached(p + "time", p + "time_conv", x, flags=lib.VCONV_TSPLIT)
+        return self._conv_cached(p + "sp", p + "resample.1", x, upsample=True)
+
+    def forward(self, x):
+        """One chunk: x [T, h, w, z] (output of conv2) → [T', 8h, 8w, 3], clamped (the reference clamps after the
+        concat of all chunks, vae.py:951-955 — elementwise, so per chunk is the same)."""
+        x = self._conv_cached("conv1", "decoder.conv1", x)
+        x = self.residual_block("decoder.middle.0.", x)
+        x = self.attention_block("decoder.middle.1.", x)
+        x = self.residual_block("decoder.middle.2.", x)
+        for idx, kind, _, _ in self.plan:
+            p = f"decoder.upsamples.{idx}."
+            x = self.residual_block(p, x) if kind == "res" else self.resample(p, x, kind)
+        return self._conv_cached("head", "decoder.head.2", x, gamma=self.w["decoder.head.0.gamma"], silu=True, flags=lib.VCONV_CLAMP)
+
+
+class WanVAE_:
+    """reference: vae.py:640-760 (decode side)."""
+
+    def __init__(self, sd, dim=96, z_dim=16, device="cuda"):
+        self.dim, self.z_dim, self.device = dim, z_dim, device
+        self.sd = sd
+        self.conv2_w = sd["conv2.weight"].to(device=device, dtype=torch.float32).reshape(z_dim, z_dim).contiguous()
+        self.conv2_b = sd["conv2.bias"].to(device=device, dtype=torch.float32).contiguous()
+        self.decoder = None
+
+    def decode(self, z, scale):
+        """z [1, 16, T, h, w] fp32; scale = [mean, inv_std] → [1, 3, 1 + 4 (T-1), 8h, 8w], clamped to [-1, 1]."""
+        zc, t, h, w = z.shape[1:]
+        if self.decoder is None or (self.decoder.h0, self.decoder.w0) != (h, w):
+            self.decoder = Decoder3d(self.sd, self.dim, (h, w), self.device)
+        self.decoder.clear_cache()
+        zl = z[0].permute(1, 2, 3, 0).contiguous().float()  # [T, h, w, 16]
+        zn = torch.empty_like(zl)
+        lib.vae_prep(zl, zn, (h * w * zc, w * zc), a=scale[1].float().contiguous(), b=scale[0].float().contiguous())
+        x = torch.empty_like(zn)
+        lib.vae_conv(zn, (h * w * zc, w * zc, zc), self.conv2_w, x, t, h, w, bias=self.conv2_b)
+        outs = [self.decoder.forward(x[i : i + 1]) for i in range(t)]
+        self.decoder.clear_cache()
+        video = torch.cat(outs, dim=0)  # [T_out, H, W, 3]
+        return video.permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+
+
+class WanVAE:
+    """reference: vae.py:789-957 (decode side; `parallel` / `use_tiling` variants are not built)."""
+
+    def __init__(self, sd, z_dim=16, dim=96, device="cuda"):
+        self.device = device
+        self.mean = torch.tensor(synth.WAN_VAE_MEAN, dtype=torch.float32, device=device)
+        self.inv_std = 1.0 / torch.tensor(synth.WAN_VAE_STD, dtype=torch.float32, device=device)
+        self.scale = [self.mean, self.inv_std]
+        self.model = WanVAE_(sd, dim=dim, z_dim=z_dim, device=device)
+
+    def decode(self, zs, generator=None, config=None):
+        """zs [16, T, h, w] → images [1, 3, T_out, 8h, 8w] fp32 in [-1, 1] (vae.py:931-957, non-parallel branch)."""
+        return self.model.decode(zs.unsqueeze(0).to(self.device), self.scale)

@@ -203,9 +203,37 @@ def gen_scheduler_only():
     print("scheduler.safetensors:", len(out), "tensors")
 
 
+def gen_vae(dim=32, seed=1):
+    """Wan VAE decode fixture: the reference's WanVAE_ (vae.py:640-738) at a reduced channel width (dim 32 →
+    128/128/128/64/32 channels; same depth, same cache logic) decoding z [16,3,8,8] → [3,9,64,64] one latent frame
+    at a time, followed by WanVAE.decode's clamp (vae.py:951-955)."""
+    ref_import.patch_and_import()
+    from lightx2v.models.video_encoders.hf.wan.vae import WanVAE_
+
+    sd = synth.synth_wan_vae_weights(dim=dim, seed=seed)
+    m = WanVAE_(dim=dim, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[], temperal_downsample=[False, True, True], dropout=0.0).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if k.startswith(("decoder", "conv2"))], (missing, unexpected)
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(16, 3, 8, 8, generator=g)
+    mean, inv_std = torch.tensor(synth.WAN_VAE_MEAN), 1.0 / torch.tensor(synth.WAN_VAE_STD)
+    with torch.no_grad():
+        raw = m.decode(z.unsqueeze(0), [mean, inv_std])[0]
+    out = dict(z=z, mean=mean, inv_std=inv_std, decoded_raw=raw.clone(), decoded=raw.float().clamp_(-1, 1), dim=torch.tensor([dim]), seed=torch.tensor([seed]),
+               weights_checksum=weights_checksum(sd))
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
+    print("wan_vae_tiny.safetensors:", len(out), "tensors")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    gen_ops()
-    gen_model()
-    gen_scheduler_only()
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae"]
+    if "ops" in which:
+        gen_ops()
+    if "model" in which:
+        gen_model()
+    if "sched" in which:
+        gen_scheduler_only()
+    if "vae" in which:
+        gen_vae()

@@ -92,3 +92,23 @@ def test_scheduler_known_answers(golden_sched):
             sch.noise_pred = torch.sin(sch.latents.float() * 1.3 + 0.1 * i) + 0.05 * i
             sch.step_post()
         eq(sch.latents, g[f"{tag}_final"])
+
+
+def test_vae_decode_oracle_bit_exact():
+    """oracle/wan_vae_oracle.py reproduces the reference's WanVAE_.decode fixture (same torch CPU ops, same order)."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import synth
+    from oracle import wan_vae_oracle as V
+
+    gld = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wan_vae_tiny.safetensors"))
+    sd = synth.synth_wan_vae_weights(dim=int(gld["dim"]), seed=int(gld["seed"]))
+    chk = sum(v.double().abs().sum() for _, v in sorted(sd.items()))
+    assert torch.allclose(chk.reshape(1), gld["weights_checksum"], rtol=1e-12), "synthetic VAE weights drifted from the fixture's"
+    with torch.no_grad():
+        raw = V.wan_vae_decode(sd, gld["z"], gld["mean"], gld["inv_std"], dim=int(gld["dim"]), clamp=False)
+        out = V.wan_vae_decode(sd, gld["z"], gld["mean"], gld["inv_std"], dim=int(gld["dim"]))
+    assert torch.equal(raw, gld["decoded_raw"])
+    assert torch.equal(out, gld["decoded"])
