@@ -72,6 +72,14 @@ int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b,
 int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S, int H,
                           int64_t s0, int gf, int gh, int gw, float eps, int round_mode, void* stream);
 
+/* In-place per-head RMSNorm (d = 128) of q and k [L, H*128] (token strides ldq/ldk, e.g. the column blocks of a fused
+ * QKV GEMM output), followed for tokens < l_rope by the real-valued RoPE x*cos + rotate_half(x)*sin with bf16 tables
+ * cos/sin [l_rope, 128] — replaces RMSWeightSgl.apply on [L,H,128] (rms_norm_weight.py:102-113; hunyuan
+ * transformer_infer.py:271-272,289-290,338-339) + hunyuan/infer/utils_bf16.apply_rotary_emb (:5-31).
+ * wq/wk [128] bf16 (NULL = no norm); tokens >= l_rope (the text tokens) are only normalised. */
+int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab, const void* sin_tab, int64_t L,
+                           int H, int64_t l_rope, float eps, int round_mode, void* stream);
+
 /* x[M,D] = bf16(x + bf16(y * gate)) (gate [D] bf16, NULL = plain add) — replaces `x.add_(y * gate)`
  * (transformer_infer.py:402,468,503) for callers that do not fuse it into the GEMM epilogue. */
 int x2v_gate_residual_bf16(void* x, int64_t ldx, const void* y, int64_t ldy, const void* gate, int64_t M, int D, void* stream);

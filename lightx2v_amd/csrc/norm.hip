@@ -278,6 +278,64 @@ __global__ void sinusoid_kernel(const int64_t* __restrict__ t, unsigned short* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// HunyuanVideo q/k path: per-head RMSNorm over d = 128 followed (for the first `l_rope` tokens = the image
+// tokens) by the real-valued RoPE  x*cos + rotate_half(x)*sin  with bf16 cos/sin tables [l_rope, 128] —
+// replaces RMSWeightSgl.apply on [L,H,128] (rms_norm_weight.py:102-113) + utils_bf16.apply_rotary_emb
+// (hunyuan/infer/utils_bf16.py:5-31), in place on the q and k column blocks of the fused QKV GEMM output.
+// 16 lanes x 16 bytes per (token, head) row, 16 rows per 256-thread block; blockIdx.y selects q / k.
+// Rounding: X2V_ROUND_REF reproduces the reference's bf16 chain (pow, mean, +eps, rsqrt, *rstd, *w; then the
+// three roundings of the rotary form); X2V_ROUND_FP32 keeps fp32 through the norm (sgl_kernel.rmsnorm) and
+// rounds once before the (always bf16-chained) rotary step.
+template <int ROUND>
+__global__ __launch_bounds__(256) void headnorm_rope_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
+                                                            const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
+                                                            const unsigned short* __restrict__ cosb, const unsigned short* __restrict__ sinb, int64_t L,
+                                                            int H, int64_t l_rope, float eps) {
+  const int sub = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= L * H) return;  // whole 16-lane groups leave together; the shuffles below stay inside a group
+  const int64_t tok = row / H;
+  const int head = (int)(row - tok * H);
+  unsigned short* base = blockIdx.y == 0 ? q + tok * ldq : k + tok * ldk;
+  const unsigned short* w = blockIdx.y == 0 ? wq : wk;
+  unsigned short* p = base + head * 128 + sub * 8;
+  float v[8], wv[8];
+  unpack8(*reinterpret_cast<const uint4*>(p), v);
+  if (w != nullptr) {
+    unpack8(*reinterpret_cast<const uint4*>(w + sub * 8), wv);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float pw = v[j] * v[j];
+      ss += (ROUND == X2V_ROUND_REF) ? rbf(pw) : pw;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    float rs;
+    if (ROUND == X2V_ROUND_REF) {
+      const float mean = rbf(ss / 128.f);
+      rs = rbf(1.0f / sqrtf(rbf(mean + eps)));
+    } else {
+      rs = 1.0f / sqrtf(ss / 128.f + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (ROUND == X2V_ROUND_REF) ? rbf(rbf(v[j] * rs) * wv[j]) : rbf(v[j] * rs * wv[j]);
+  }
+  if (tok < l_rope) {
+    float c[8], sn[8];
+    unpack8(*reinterpret_cast<const uint4*>(cosb + tok * 128 + sub * 8), c);
+    unpack8(*reinterpret_cast<const uint4*>(sinb + tok * 128 + sub * 8), sn);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const float re = v[j], im = v[j + 1];
+      v[j] = rbf(re * c[j]) + rbf(-im * sn[j]);
+      v[j + 1] = rbf(im * c[j + 1]) + rbf(re * sn[j + 1]);
+    }
+  }
+  *reinterpret_cast<uint4*>(p) = pack8(v);
+}
+
 }  // namespace x2v
 
 using namespace x2v;
@@ -422,5 +480,27 @@ extern "C" __attribute__((visibility("default"))) int x2v_sinusoid_embed_bf16(co
   const int total = n * (dim / 2);
   hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, t, (unsigned short*)y, n, dim);
   X2V_LAUNCH_CHECK("sinusoid launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab,
+                                                                             const void* sin_tab, int64_t L, int H, int64_t l_rope, float eps, int round_mode,
+                                                                             void* stream) {
+  X2V_REQUIRE(q && k, X2V_E_ARG, "headnorm_rope: null pointer");
+  X2V_REQUIRE(L > 0 && H > 0 && l_rope >= 0 && l_rope <= L, X2V_E_SHAPE, "headnorm_rope: bad shape L=%lld H=%d l_rope=%lld", (long long)L, H, (long long)l_rope);
+  X2V_REQUIRE(l_rope == 0 || (cos_tab && sin_tab), X2V_E_ARG, "headnorm_rope: rope tables missing");
+  X2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldq >= (int64_t)H * 128 && ldk >= (int64_t)H * 128 && aligned16(q) && aligned16(k) && aligned16(wq) && aligned16(wk) &&
+                  aligned16(cos_tab) && aligned16(sin_tab),
+              X2V_E_ALIGN, "headnorm_rope: rows must be 16-byte aligned");
+  const int64_t rows = L * H;
+  X2V_REQUIRE((rows + 15) / 16 < (1ll << 31), X2V_E_SHAPE, "headnorm_rope: too many rows");
+  dim3 grid((unsigned)((rows + 15) / 16), 2);
+  if (round_mode == X2V_ROUND_REF)
+    hipLaunchKernelGGL((headnorm_rope_kernel<X2V_ROUND_REF>), grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)q, ldq, (unsigned short*)k, ldk,
+                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps);
+  else
+    hipLaunchKernelGGL((headnorm_rope_kernel<X2V_ROUND_FP32>), grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)q, ldq, (unsigned short*)k, ldk,
+                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps);
+  X2V_LAUNCH_CHECK("headnorm_rope launch");
   return X2V_OK;
 }

@@ -27,6 +27,7 @@ PROTOTYPES = {
     "x2v_rmsnorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
     "x2v_layernorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
     "x2v_rmsnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
+    "x2v_headnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _c_void_p],
     "x2v_gate_residual_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
@@ -303,3 +304,12 @@ def softmax_rows_(s, scale):
     init()
     _check(_lib.x2v_softmax_rows_f32(_p(s), s.stride(0), M, N, float(scale), _stream()), "softmax_rows")
     return s
+
+
+def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mode=ROUND_FP32):
+    """In place on q, k [L, H*128] views (unit inner stride, any token stride): per-head RMSNorm + real RoPE on the
+    first l_rope tokens (x2v_headnorm_rope_bf16)."""
+    L = q.shape[0]
+    init()
+    _check(_lib.x2v_headnorm_rope_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, _stream()),
+           "headnorm_rope")

@@ -159,3 +159,89 @@ def synth_wan_vae_weights(dim=96, z_dim=16, seed=0, device="cpu"):
     gamma("decoder.head.0.gamma", dims[-1], 1, 1, 1)
     conv("decoder.head.2", 3, dims[-1], 3, 3, 3, gain=0.5)
     return sd
+
+
+# HunyuanVideo DiT (reference: hunyuan/infer/transformer_infer.py:13-17 hard-codes the 13B numbers)
+HUNYUAN_DIMS = {
+    "hunyuan-13b": dict(hidden=3072, heads=24, mlp=12288, double_blocks=20, single_blocks=40, text_dim=4096, text_dim_2=768, text_len=256, refiner_mlp=12288),
+    "hunyuan-tiny": dict(hidden=256, heads=2, mlp=512, double_blocks=2, single_blocks=3, text_dim=64, text_dim_2=64, text_len=16, refiner_mlp=512),
+}
+HUNYUAN_WORKLOADS = {
+    # latent target_shape (1, 16, T, H, W): 720p x 129 frames (BASELINE config #5) and a plumbing size
+    "hunyuan13b_720px129f": dict(model="hunyuan-13b", target_shape=(1, 16, 33, 90, 160), frames=129),
+    "hunyuan-tiny": dict(model="hunyuan-tiny", target_shape=(1, 16, 3, 8, 12), frames=9),
+}
+
+
+def synth_hunyuan_weights(dims, seed=0, device="cpu", dtype=torch.bfloat16, gen_device="cpu"):
+    """{checkpoint tensor name: tensor} for the HunyuanVideo DiT under the reference's names
+    (hunyuan/weights/pre_weights.py:9-84, transformer_weights.py:18-71, post_weights.py:10-11)."""
+    h, mlp, hd = dims["hidden"], dims["mlp"], dims["hidden"] // dims["heads"]
+    gen = torch.Generator(device=gen_device)
+    gen.manual_seed(seed)
+    wd = {}
+
+    def lin(name, n, k, gain=1.0, bias_std=0.02):
+        wd[f"{name}.weight"] = _randn((n, k), gain / math.sqrt(k), gen, device, dtype)
+        wd[f"{name}.bias"] = _randn((n,), bias_std, gen, device, dtype)
+
+    def norm_w(name, n):
+        wd[name] = (1.0 + _randn((n,), 0.05, gen, device, torch.float32)).to(dtype)
+
+    wd["img_in.proj.weight"] = _randn((h, 16, 1, 2, 2), 0.1, gen, device, dtype)
+    wd["img_in.proj.bias"] = _randn((h,), 0.02, gen, device, dtype)
+    lin("txt_in.input_embedder", h, dims["text_dim"])
+    lin("txt_in.t_embedder.mlp.0", h, 256)
+    lin("txt_in.t_embedder.mlp.2", h, h)
+    lin("txt_in.c_embedder.linear_1", h, dims["text_dim"])
+    lin("txt_in.c_embedder.linear_2", h, h)
+    for j in range(2):
+        p = f"txt_in.individual_token_refiner.blocks.{j}"
+        norm_w(f"{p}.norm1.weight", h)
+        wd[f"{p}.norm1.bias"] = _randn((h,), 0.02, gen, device, dtype)
+        lin(f"{p}.self_attn_qkv", 3 * h, h)
+        lin(f"{p}.self_attn_proj", h, h)
+        norm_w(f"{p}.norm2.weight", h)
+        wd[f"{p}.norm2.bias"] = _randn((h,), 0.02, gen, device, dtype)
+        lin(f"{p}.mlp.fc1", dims["refiner_mlp"], h)
+        lin(f"{p}.mlp.fc2", h, dims["refiner_mlp"])
+        lin(f"{p}.adaLN_modulation.1", 2 * h, h, gain=0.5)
+    lin("time_in.mlp.0", h, 256)
+    lin("time_in.mlp.2", h, h)
+    lin("vector_in.in_layer", h, dims["text_dim_2"])
+    lin("vector_in.out_layer", h, h)
+    lin("guidance_in.mlp.0", h, 256)
+    lin("guidance_in.mlp.2", h, h)
+    for i in range(dims["double_blocks"]):
+        for s in ("img", "txt"):
+            p = f"double_blocks.{i}.{s}"
+            lin(f"{p}_mod.linear", 6 * h, h, gain=0.5)
+            lin(f"{p}_attn_qkv", 3 * h, h)
+            norm_w(f"{p}_attn_q_norm.weight", hd)
+            norm_w(f"{p}_attn_k_norm.weight", hd)
+            lin(f"{p}_attn_proj", h, h)
+            lin(f"{p}_mlp.fc1", mlp, h)
+            lin(f"{p}_mlp.fc2", h, mlp)
+    for i in range(dims["single_blocks"]):
+        p = f"single_blocks.{i}"
+        lin(f"{p}.linear1", 3 * h + mlp, h)
+        lin(f"{p}.linear2", h, h + mlp)
+        norm_w(f"{p}.q_norm.weight", hd)
+        norm_w(f"{p}.k_norm.weight", hd)
+        lin(f"{p}.modulation.linear", 3 * h, h, gain=0.5)
+    lin("final_layer.linear", 64, h)
+    lin("final_layer.adaLN_modulation.1", 2 * h, h, gain=0.5)
+    return wd
+
+
+def synth_hunyuan_inputs(dims, target_shape, seed=42, valid_text=None):
+    """latents fp32 [1,16,T,H,W] (cast by the caller), text_states [1,L,text_dim] bf16, text_mask [1,L] int64 (first
+    `valid_text` tokens valid; default all), text_states_2 [1,text_dim_2] bf16 (CLIP pooled stand-in)."""
+    g = torch.Generator().manual_seed(seed)
+    latents = torch.randn(*target_shape, generator=g, dtype=torch.float32)
+    L = dims["text_len"]
+    text_states = torch.randn(1, L, dims["text_dim"], generator=g).to(torch.bfloat16)
+    mask = torch.zeros(1, L, dtype=torch.int64)
+    mask[:, : (L if valid_text is None else valid_text)] = 1
+    text_states_2 = torch.randn(1, dims["text_dim_2"], generator=g).to(torch.bfloat16)
+    return latents, text_states, mask, text_states_2

@@ -225,10 +225,88 @@ def gen_vae(dim=32, seed=1):
     print("wan_vae_tiny.safetensors:", len(out), "tensors")
 
 
+def gen_hunyuan(name="hunyuan-tiny", seed=4):
+    """HunyuanVideo DiT fixtures from the reference's own infer objects at a reduced width (hidden 256, 2 heads of
+    128, 2 double + 3 single blocks): scheduler tables, pre-infer outputs, one double block, one single block, the
+    full forward.  Text mask all ones (then the `torch_sdpa` op's dense attention equals the flash varlen call)."""
+    ref_import.patch_and_import()
+    from easydict import EasyDict
+    from lightx2v.common.modules.weight_module import WeightModule, WeightModuleList
+    from lightx2v.models.networks.hunyuan.infer.post_infer import HunyuanPostInfer
+    from lightx2v.models.networks.hunyuan.infer.pre_infer import HunyuanPreInfer
+    from lightx2v.models.networks.hunyuan.infer.transformer_infer import HunyuanTransformerInfer
+    from lightx2v.models.networks.hunyuan.weights.post_weights import HunyuanPostWeights
+    from lightx2v.models.networks.hunyuan.weights.pre_weights import HunyuanPreWeights
+    from lightx2v.models.networks.hunyuan.weights.transformer_weights import HunyuanTransformerDoubleBlock, HunyuanTransformerSingleBlock, HunyuanTransformerWeights
+    from lightx2v.models.schedulers.hunyuan import scheduler as ref_sched
+
+    dims = synth.HUNYUAN_DIMS[name]
+    ts = synth.HUNYUAN_WORKLOADS[name]["target_shape"]
+    wd = synth.synth_hunyuan_weights(dims, seed=seed)
+    lat, text_states, text_mask, text_states_2 = synth.synth_hunyuan_inputs(dims, ts)
+    cfg = EasyDict(task="t2v", do_mm_calib=False, mm_config={}, attention_type="torch_sdpa", cpu_offload=False, feature_caching="NoCaching")
+    out = {}
+
+    # scheduler tables (pure functions of the reference module; diffusers stub only satisfies its import line)
+    timesteps, sigmas = ref_sched.set_timesteps_sigmas(4, 7.0, device=torch.device("cpu"))
+    rope_sizes = [ts[2], ts[3] // 2, ts[4] // 2]
+    fc, fs = ref_sched.get_nd_rotary_pos_embed([16, 56, 56], rope_sizes, theta=256, use_real=True, theta_rescale_factor=1)
+    fc, fs = fc.to(BF16), fs.to(BF16)
+    out.update(sched_timesteps=timesteps, sched_sigmas=sigmas, freqs_cos=fc, freqs_sin=fs)
+
+    class Sched:  # the attributes HunyuanPreInfer / HunyuanPostInfer read (pre_infer.py:15-19, post_infer.py:19)
+        pass
+
+    sch = Sched()
+    sch.latents, sch.timesteps, sch.step_index = lat.to(BF16), timesteps, 1
+    sch.freqs_cos, sch.freqs_sin = fc, fs
+    sch.guidance = torch.tensor([6.0], dtype=BF16) * 1000.0
+
+    pre_w, post_w = HunyuanPreWeights(cfg), HunyuanPostWeights(cfg)
+    tr_w = HunyuanTransformerWeights.__new__(HunyuanTransformerWeights)  # same classes, fewer blocks than the hard-coded 20 + 40
+    WeightModule.__init__(tr_w)
+    tr_w.config = cfg
+    tr_w.add_module("double_blocks", WeightModuleList([HunyuanTransformerDoubleBlock(i, cfg) for i in range(dims["double_blocks"])]))
+    tr_w.add_module("single_blocks", WeightModuleList([HunyuanTransformerSingleBlock(i, cfg) for i in range(dims["single_blocks"])]))
+    for w in (pre_w, post_w, tr_w):
+        w.load(wd)
+
+    class SDPA4D:  # 4-D form of TorchSDPAWeight.apply (attn_weight.py:229-239) for pre_infer.py:117-119,140 — see oracle header
+        def apply(self, q, k, v, attn_mask=None):
+            x = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=attn_mask)
+            x = x.transpose(1, 2)
+            return x.reshape(x.shape[0], x.shape[1], -1)
+
+    pre_w.txt_in_attn_1 = SDPA4D()
+    pre, tr, post = HunyuanPreInfer(cfg), HunyuanTransformerInfer(cfg), HunyuanPostInfer(cfg)
+    pre.heads_num = tr.heads_num = dims["heads"]
+    tr.hidden_size, tr.mlp_hidden_dim = dims["hidden"], dims["mlp"]
+    tr.double_blocks_num, tr.single_blocks_num = dims["double_blocks"], dims["single_blocks"]
+    pre.set_scheduler(sch)
+    post.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"text_encoder_1_text_states": text_states, "text_encoder_1_attention_mask": text_mask, "text_encoder_2_text_states": text_states_2}}
+    with torch.no_grad():
+        img, txt, vec, cu, max_len, freqs = pre.infer(pre_w, inputs)
+        out.update(latents=lat, text_states=text_states, text_mask=text_mask, text_states_2=text_states_2, t=timesteps[1].reshape(1).clone(), guidance=sch.guidance.clone(),
+                   pre_img=img.clone(), pre_txt=txt.clone(), pre_vec=vec.clone(), cu_seqlens=cu.clone(), max_seqlen=torch.tensor([max_len]))
+        i1, t1 = tr.infer_double_block(tr_w.double_blocks[0], img, txt, vec, cu, max_len, freqs, None, None)
+        out.update(d0_img=i1.clone(), d0_txt=t1.clone())
+        x = torch.cat((i1, t1), 0)
+        x1 = tr.infer_single_block(tr_w.single_blocks[0], x, vec, txt.shape[0], cu, max_len, freqs, None, None)
+        out.update(s0_in=x.clone(), s0_out=x1.clone())
+        img_o, vec_o = tr.infer(tr_w, img, txt, vec, cu, max_len, freqs)
+        out.update(tr_img=img_o.clone())
+        out.update(noise_pred=post.infer(post_w, img_o, vec_o).clone())
+    out["weights_checksum"] = weights_checksum(wd)
+    out["seed"] = torch.tensor([seed])
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "hunyuan_tiny.safetensors"))
+    print("hunyuan_tiny.safetensors:", len(out), "tensors; noise_pred", tuple(out["noise_pred"].shape), out["noise_pred"].dtype)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "model", "sched", "vae"]
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan"]
     if "ops" in which:
         gen_ops()
     if "model" in which:
@@ -237,3 +315,5 @@ if __name__ == "__main__":
         gen_scheduler_only()
     if "vae" in which:
         gen_vae()
+    if "hunyuan" in which:
+        gen_hunyuan()

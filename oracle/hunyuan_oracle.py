@@ -1,0 +1,220 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (never imported by the product path `lightx2v_amd/`).
+
+CPU restatement, in plain PyTorch, of the reference's HunyuanVideo DiT forward (DTYPE=BF16, t2v) — the algorithm
+`lightx2v_amd/hunyuan.py` must reproduce.  Paths below are relative to /root/reference/lightx2v/.
+
+  pre-infer     models/networks/hunyuan/infer/pre_infer.py:6-154
+  double block  models/networks/hunyuan/infer/transformer_infer.py:81-310
+  single block  models/networks/hunyuan/infer/transformer_infer.py:312-384
+  RoPE          models/networks/hunyuan/infer/utils_bf16.py:5-31 (real cos/sin form, bf16 arithmetic)
+  post-infer    models/networks/hunyuan/infer/post_infer.py:4-33
+  scheduler     models/schedulers/hunyuan/scheduler.py:18-63,66-108,111-172,175-179,237-260,278-319
+
+Pinning (tests/test_oracle_golden.py): `tests/golden/hunyuan_tiny.safetensors` is generated FROM THE REFERENCE's own
+HunyuanPreInfer / HunyuanTransformerInfer / HunyuanPostInfer objects (oracle/gen_golden.py::gen_hunyuan) at a reduced
+width; this file must reproduce it bit-exactly.  Two reference calls cannot be executed as shipped and are pinned
+through a documented substitute in the generator: (1) `txt_in_attn_1` (pre_infer.py:117-119,140) passes 4-D q/k/v to
+TorchSDPAWeight.apply, which only accepts 3-D at this snapshot (attn_weight.py:229-239) — the generator swaps in the
+4-D form of the same SDPA call; (2) the scheduler module imports `diffusers` (absent) for `randn_tensor` only — a stub
+provides that symbol, everything checked here (sigmas, timesteps, RoPE tables, Euler step) is the reference's code.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle.wan_oracle import layer_norm, mm, rms_norm
+
+BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------- scheduler pieces
+def set_timesteps_sigmas(num_inference_steps, shift, num_train_timesteps=1000):
+    """schedulers/hunyuan/scheduler.py:175-179."""
+    sigmas = torch.linspace(1, 0, num_inference_steps + 1)
+    sigmas = (shift * sigmas) / (1 + (shift - 1) * sigmas)
+    return (sigmas[:-1] * num_train_timesteps).to(torch.float32), sigmas
+
+
+def rope_tables(rope_sizes, rope_dim_list=(16, 56, 56), theta=256.0):
+    """get_nd_rotary_pos_embed(use_real=True) (scheduler.py:18-63,66-108,111-172) as called by
+    prepare_rotary_pos_embedding (:278-319): per axis a, freqs = 1/theta^(2j/d_a), cos/sin of pos*freqs with every value
+    repeated twice (interleaved pairs), axes concatenated → [T*H*W, 128] each, then rounded to bf16."""
+    axes = [torch.linspace(0, n, n + 1, dtype=torch.float32)[:n] for n in rope_sizes]
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=0)
+    cos, sin = [], []
+    for a, d in enumerate(rope_dim_list):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+        f = torch.outer(grid[a].reshape(-1), freqs)
+        cos.append(f.cos().repeat_interleave(2, dim=1))
+        sin.append(f.sin().repeat_interleave(2, dim=1))
+    return torch.cat(cos, dim=1).to(BF16), torch.cat(sin, dim=1).to(BF16)
+
+
+def euler_step(latents, noise_pred, sigmas, step_index):
+    """HunyuanScheduler.step_post, t2v (scheduler.py:256-260)."""
+    dt = sigmas[step_index + 1] - sigmas[step_index]
+    return latents.to(torch.float32) + noise_pred.to(torch.float32) * dt
+
+
+# ----------------------------------------------------------------------------- RoPE on q, k
+def apply_rotary_emb(xq, xk, cos, sin):
+    """utils_bf16.py:11-31: x*cos + rotate_half(x)*sin with rotate_half(x)[2i] = -x[2i+1], [2i+1] = x[2i]; bf16 tensors,
+    so the two products and the sum each round to bf16.  xq/xk [L, H, D]; cos/sin [L, D]."""
+    L, H, D = xq.shape
+    c, s = cos.view(L, 1, D), sin.view(L, 1, D)
+
+    def rot(x):
+        re, im = x.reshape(L, H, -1, 2).unbind(-1)
+        return torch.stack([-im, re], dim=-1).flatten(2)
+
+    return xq * c + rot(xq) * s, xk * c + rot(xk) * s
+
+
+def varlen_attention(q, k, v, cu_seqlens):
+    """What `flash_attn_varlen_func` computes for weights.double_attn / single_attn (attn_weight.py:76-126 with the
+    cu_seqlens built in pre_infer.py:50-56): dense non-causal attention inside each [cu[i], cu[i+1]) segment.
+    q, k, v [L, H, D] → [L, H*D].  With an all-ones text mask the second segment is empty and this equals the
+    `torch_sdpa` op's dense attention (the form the fixture was generated with)."""
+    out = torch.empty(q.shape[0], q.shape[1] * q.shape[2], dtype=q.dtype)
+    for a, b in zip(cu_seqlens[:-1].tolist(), cu_seqlens[1:].tolist()):
+        if b > a:
+            qs, ks, vs = (t[a:b].unsqueeze(0).transpose(1, 2) for t in (q, k, v))
+            o = F.scaled_dot_product_attention(qs, ks, vs).transpose(1, 2)
+            out[a:b] = o.reshape(b - a, -1)
+    return out
+
+
+def _split_heads(qkv, heads):
+    """rearrange(qkv, "L (K H D) -> K L H D", K=3, H=heads)."""
+    L = qkv.shape[0]
+    return qkv.view(L, 3, heads, -1).permute(1, 0, 2, 3)
+
+
+def _lin(wd, name, x):
+    return mm(x, wd[name + ".weight"], wd[name + ".bias"])
+
+
+# ----------------------------------------------------------------------------- blocks
+def double_block(wd, i, img, txt, vec, freqs, heads, cu_seqlens):
+    """transformer_infer.py:81-310 (t2v: token_replace_vec is None)."""
+    p = f"double_blocks.{i}."
+    vec_silu = F.silu(vec)
+    i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2 = _lin(wd, p + "img_mod.linear", vec_silu).chunk(6, dim=-1)
+    t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2 = _lin(wd, p + "txt_mod.linear", vec_silu).chunk(6, dim=-1)
+
+    x = layer_norm(img) * (1 + i_sc1) + i_sh1
+    iq, ik, iv = _split_heads(_lin(wd, p + "img_attn_qkv", x), heads)
+    iq, ik = rms_norm(iq, wd[p + "img_attn_q_norm.weight"]), rms_norm(ik, wd[p + "img_attn_k_norm.weight"])
+    iq, ik = apply_rotary_emb(iq, ik, *freqs)
+    y = layer_norm(txt) * (1 + t_sc1) + t_sh1
+    tq, tk, tv = _split_heads(_lin(wd, p + "txt_attn_qkv", y), heads)
+    tq, tk = rms_norm(tq, wd[p + "txt_attn_q_norm.weight"]), rms_norm(tk, wd[p + "txt_attn_k_norm.weight"])
+
+    attn = varlen_attention(torch.cat((iq, tq), 0), torch.cat((ik, tk), 0), torch.cat((iv, tv), 0), cu_seqlens)
+    n_img = img.shape[0]
+    img_out = _lin(wd, p + "img_attn_proj", attn[:n_img])
+    txt_out = _lin(wd, p + "txt_attn_proj", attn[n_img:])
+
+    img = img + img_out * i_g1
+    x = layer_norm(img) * (1 + i_sc2) + i_sh2
+    x = _lin(wd, p + "img_mlp.fc2", F.gelu(_lin(wd, p + "img_mlp.fc1", x), approximate="tanh"))
+    txt = txt + txt_out * t_g1
+    y = layer_norm(txt) * (1 + t_sc2) + t_sh2
+    y = _lin(wd, p + "txt_mlp.fc2", F.gelu(_lin(wd, p + "txt_mlp.fc1", y), approximate="tanh"))
+    return img + x * i_g2, txt + y * t_g2
+
+
+def single_block(wd, i, x, vec, txt_len, freqs, heads, hidden, cu_seqlens):
+    """transformer_infer.py:312-384."""
+    p = f"single_blocks.{i}."
+    shift, scale, gate = _lin(wd, p + "modulation.linear", F.silu(vec)).chunk(3, dim=-1)
+    xm = _lin(wd, p + "linear1", layer_norm(x) * (1 + scale) + shift)
+    qkv, mlp = xm[:, : 3 * hidden], xm[:, 3 * hidden :]
+    q, k, v = _split_heads(qkv, heads)
+    q, k = rms_norm(q, wd[p + "q_norm.weight"]), rms_norm(k, wd[p + "k_norm.weight"])
+    iq, ik = apply_rotary_emb(q[:-txt_len], k[:-txt_len], *freqs)
+    q, k = torch.cat((iq, q[-txt_len:]), 0), torch.cat((ik, k[-txt_len:]), 0)
+    attn = varlen_attention(q, k, v, cu_seqlens)
+    out = _lin(wd, p + "linear2", torch.cat((attn, F.gelu(mlp, approximate="tanh")), 1))
+    return x + out * gate
+
+
+def transformer_infer(wd, dims, img, txt, vec, cu_seqlens, freqs):
+    """transformer_infer.py:66-79 (_infer_without_offload)."""
+    for i in range(dims["double_blocks"]):
+        img, txt = double_block(wd, i, img, txt, vec, freqs, dims["heads"], cu_seqlens)
+    x = torch.cat((img, txt), 0)
+    for i in range(dims["single_blocks"]):
+        x = single_block(wd, i, x, vec, txt.shape[0], freqs, dims["heads"], dims["hidden"], cu_seqlens)
+    return x[: img.shape[0]], vec
+
+
+# ----------------------------------------------------------------------------- pre / post
+def _t_embed(t):
+    """pre_infer.py:62-64,73-75,147-149: cos|sin of t * exp(-ln(1e4) j / 128) in fp32, rounded to bf16; [1, 256]."""
+    freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=128, dtype=torch.float32) / 128)
+    args = t.reshape(1, 1).float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(BF16)
+
+
+def _mlp_silu(wd, a, b, x):
+    return _lin(wd, b, F.silu(_lin(wd, a, x)))
+
+
+def token_refiner_block(wd, j, x, c, mask, heads):
+    """pre_infer.py:105-125 / 127-145: adaLN gates, LN(affine), masked self-attention over the text tokens, MLP(SiLU)."""
+    p = f"txt_in.individual_token_refiner.blocks.{j}."
+    g_msa, g_mlp = _lin(wd, p + "adaLN_modulation.1", F.silu(c)).chunk(2, dim=1)
+    n = layer_norm(x, wd[p + "norm1.weight"], wd[p + "norm1.bias"])
+    q, k, v = _split_heads(_lin(wd, p + "self_attn_qkv", n), heads)  # [L, H, D] each
+    qs, ks, vs = (t.unsqueeze(0).transpose(1, 2) for t in (q, k, v))
+    a = F.scaled_dot_product_attention(qs, ks, vs, attn_mask=mask).transpose(1, 2).reshape(x.shape[0], -1)
+    x1 = x + _lin(wd, p + "self_attn_proj", a) * g_msa
+    n2 = layer_norm(x1, wd[p + "norm2.weight"], wd[p + "norm2.bias"])
+    return x1 + _mlp_silu(wd, p + "mlp.fc1", p + "mlp.fc2", n2) * g_mlp
+
+
+def pre_infer(wd, dims, latents, t, guidance, text_states, text_mask, text_states_2):
+    """pre_infer.py:14-60 (t2v).  latents [1,16,T,H,W]; text_states [1,L,4096] bf16; text_mask [1,L] int; text_states_2
+    [1,768] bf16.  Returns img [S, hidden], txt [L, hidden], vec [1, hidden], cu_seqlens_qkv, max_seqlen_qkv."""
+    time_out = _mlp_silu(wd, "time_in.mlp.0", "time_in.mlp.2", _t_embed(t))
+    img = F.conv3d(latents, wd["img_in.proj.weight"], wd["img_in.proj.bias"], stride=(1, 2, 2)).flatten(2).transpose(1, 2)[0]
+    # text: timestep- and context-aware conditioning vector, input embedding, two refiner blocks
+    t_aware = _mlp_silu(wd, "txt_in.t_embedder.mlp.0", "txt_in.t_embedder.mlp.2", _t_embed(t))
+    mask_float = text_mask.float().unsqueeze(-1).to(BF16)
+    ctx = (text_states * mask_float).sum(dim=1) / mask_float.sum(dim=1)
+    c = t_aware + _mlp_silu(wd, "txt_in.c_embedder.linear_1", "txt_in.c_embedder.linear_2", ctx)
+    x = _lin(wd, "txt_in.input_embedder", text_states[0])
+    L = text_mask.shape[1]
+    m1 = text_mask.view(1, 1, 1, L).repeat(1, 1, L, 1)
+    mask = (m1 & m1.transpose(2, 3)).bool()
+    mask[:, :, :, 0] = True
+    for j in range(2):
+        x = token_refiner_block(wd, j, x, c, mask, dims["heads"])
+    vec = time_out + _mlp_silu(wd, "vector_in.in_layer", "vector_in.out_layer", text_states_2)
+    g_embed = _t_embed(guidance)
+    vec = vec + _mlp_silu(wd, "guidance_in.mlp.0", "guidance_in.mlp.2", g_embed)
+    n_img = img.shape[0]
+    s1 = int(text_mask.sum()) + n_img
+    cu = torch.tensor([0, s1, L + n_img], dtype=torch.int32)
+    return img, x, vec, cu, n_img + L
+
+
+def post_infer(wd, img, vec, latent_shape):
+    """post_infer.py:11-33: adaLN (shift, scale) → LN → modulate → fp32 Linear (MM "Default-Force-FP32") → unpatchify."""
+    shift, scale = _lin(wd, "final_layer.adaLN_modulation.1", F.silu(vec)).chunk(2, dim=1)
+    out = layer_norm(img) * (1 + scale) + shift
+    out = mm(out.to(torch.float32), wd["final_layer.linear.weight"].float(), wd["final_layer.linear.bias"].float())
+    _, _, ot, oh, ow = latent_shape
+    tt, th, tw = ot, oh // 2, ow // 2
+    out = out.reshape(1, tt, th, tw, 16, 1, 2, 2)
+    out = torch.einsum("nthwcopq->nctohpwq", out)
+    return out.reshape(1, 16, tt, th * 2, tw * 2)
+
+
+def forward(wd, dims, latents, t, guidance, text_states, text_mask, text_states_2, freqs):
+    """HunyuanModel.infer (model.py:151-158): pre → blocks → post; returns noise_pred fp32 [1,16,T,H,W]."""
+    img, txt, vec, cu, _ = pre_infer(wd, dims, latents, t, guidance, text_states, text_mask, text_states_2)
+    img, vec = transformer_infer(wd, dims, img, txt, vec, cu, freqs)
+    return post_infer(wd, img, vec, latents.shape)

@@ -12,6 +12,9 @@ Shims applied (SURVEY.md §8c recipe):
   * `torch.empty(..., pin_memory=True)` → unpinned (mm_weight.py:77, rms_norm_weight.py:23, ... allocate
     pinned mirrors at load; no GPU here);
   * `Tensor.cuda()` → identity (pre_infer.py:20,60 call `.cuda()` unconditionally);
+  * `torch.zeros(..., device="cuda")` → CPU (hunyuan/infer/pre_infer.py:50);
+  * a `diffusers` stub package (oracle/ref_shims/diffusers) providing `randn_tensor`, the only symbol the Hunyuan
+    scheduler module needs from it at import time (schedulers/hunyuan/scheduler.py:3);
   * `DTYPE=BF16` (every shipped script exports it).
 """
 import os
@@ -48,6 +51,14 @@ def patch_and_import():
                 return _orig_empty(*a, **k)
 
             torch.empty = _empty
+            _orig_zeros = torch.zeros
+
+            def _zeros(*a, **k):  # hunyuan/infer/pre_infer.py:50 allocates cu_seqlens with device="cuda"
+                if str(k.get("device", "")).startswith("cuda"):
+                    k.pop("device")
+                return _orig_zeros(*a, **k)
+
+            torch.zeros = _zeros
             torch.Tensor.cuda = lambda self, *a, **k: self
             torch.Tensor.pin_memory = lambda self, *a, **k: self
             torch.cuda.synchronize = lambda *a, **k: None

@@ -112,3 +112,38 @@ def test_vae_decode_oracle_bit_exact():
         out = V.wan_vae_decode(sd, gld["z"], gld["mean"], gld["inv_std"], dim=int(gld["dim"]))
     assert torch.equal(raw, gld["decoded_raw"])
     assert torch.equal(out, gld["decoded"])
+
+
+def test_hunyuan_oracle_bit_exact():
+    """oracle/hunyuan_oracle.py reproduces the fixture generated from the reference's Hunyuan pre/transformer/post infer
+    objects and scheduler functions (tests/golden/hunyuan_tiny.safetensors)."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import synth
+    from oracle import hunyuan_oracle as H
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hunyuan_tiny.safetensors"))
+    dims = synth.HUNYUAN_DIMS["hunyuan-tiny"]
+    wd = synth.synth_hunyuan_weights(dims, seed=int(g["seed"]))
+    ts = synth.HUNYUAN_WORKLOADS["hunyuan-tiny"]["target_shape"]
+    tt, ss = H.set_timesteps_sigmas(4, 7.0)
+    assert torch.equal(tt, g["sched_timesteps"]) and torch.equal(ss, g["sched_sigmas"])
+    fc, fs = H.rope_tables([ts[2], ts[3] // 2, ts[4] // 2])
+    assert torch.equal(fc, g["freqs_cos"]) and torch.equal(fs, g["freqs_sin"])
+    with torch.no_grad():
+        img, txt, vec, cu, ml = H.pre_infer(wd, dims, g["latents"].to(torch.bfloat16), g["t"][0], g["guidance"], g["text_states"], g["text_mask"], g["text_states_2"])
+        assert torch.equal(img, g["pre_img"]) and torch.equal(txt, g["pre_txt"]) and torch.equal(vec, g["pre_vec"])
+        assert cu.tolist() == g["cu_seqlens"].tolist() and ml == int(g["max_seqlen"])
+        i1, t1 = H.double_block(wd, 0, img, txt, vec, (fc, fs), dims["heads"], cu)
+        assert torch.equal(i1, g["d0_img"]) and torch.equal(t1, g["d0_txt"])
+        x1 = H.single_block(wd, 0, g["s0_in"], vec, txt.shape[0], (fc, fs), dims["heads"], dims["hidden"], cu)
+        assert torch.equal(x1, g["s0_out"])
+        noise = H.forward(wd, dims, g["latents"].to(torch.bfloat16), g["t"][0], g["guidance"], g["text_states"], g["text_mask"], g["text_states_2"], (fc, fs))
+        assert torch.equal(noise, g["noise_pred"])
+    # the product-side table builder (lightx2v_amd.hunyuan.rope_tables) is the same function of the grid
+    from lightx2v_amd import hunyuan as hy
+
+    c2, s2 = hy.rope_tables([ts[2], ts[3] // 2, ts[4] // 2])
+    assert torch.equal(c2, fc) and torch.equal(s2, fs)
