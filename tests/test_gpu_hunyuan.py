@@ -55,9 +55,10 @@ def test_headnorm_rope_matches_reference_chain():
         diff = (got.float().cpu() - ref.reshape(L, D).float()).abs()
         # bit-exact except rows whose rstd lands on the other side of a bf16 rounding boundary: torch's CPU bf16 rsqrt is
         # not the correctly rounded 1/sqrt (0.03 % - 4 % of inputs differ by one bf16 ulp depending on its code path), so
-        # a few whole (token, head) rows may sit one ulp away; nothing may be further than one ulp
+        # a few whole (token, head) rows may start the rotary step one ulp away (its sum of two rounded products then
+        # moves by at most two); nothing may be further than that
         ulp = ref.reshape(L, D).float().abs() * 2.0 ** -7 + 1e-30
-        assert (diff > 0).float().mean() < 5e-2 and bool((diff <= ulp).all()), (nm, diff.max(), (diff > 0).float().mean())
+        assert (diff > 0).float().mean() < 5e-2 and bool((diff <= 2 * ulp).all()), (nm, diff.max(), (diff > 0).float().mean())
     assert torch.equal(d[:, 2 * D :].cpu(), qkv[:, 2 * D :])  # v untouched
 
 

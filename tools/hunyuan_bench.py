@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Times one HunyuanVideo-13B denoise step (HIP path) on a synthetic 720p x 129-frame latent (BASELINE config #5 on
+one GPU: 118 800 image + 256 text tokens, 20 double + 40 single blocks) with seeded random weights.
+    python tools/hunyuan_bench.py [--workload hunyuan13b_720px129f] [--steps 1] [--warmup 1]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lightx2v_amd import hunyuan as hy, lib, synth  # noqa: E402
+
+
+def step_flops(d, n_img, n_txt):
+    L, D, F = n_img + n_txt, d["hidden"], d["mlp"]
+    dbl = 2 * L * D * (3 * D + D + 2 * F) + 4 * L * L * D       # qkv, proj, fc1, fc2 (+ joint attention)
+    sgl = 2 * L * D * (3 * D + F) + 2 * L * (D + F) * D + 4 * L * L * D
+    return d["double_blocks"] * dbl + d["single_blocks"] * sgl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="hunyuan13b_720px129f")
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    lib.init(0)
+    wl = synth.HUNYUAN_WORKLOADS[a.workload]
+    dims = synth.HUNYUAN_DIMS[wl["model"]]
+    cfg = hy.default_config(dims, infer_steps=50)
+    wd = synth.synth_hunyuan_weights(dims, seed=0, device="cuda", gen_device="cuda")
+    model = hy.HunyuanModel(cfg, wd)
+    del wd
+    lat, text_states, mask, ts2 = synth.synth_hunyuan_inputs(dims, wl["target_shape"], valid_text=(dims["text_len"] * 3) // 4)
+    sch = hy.HunyuanScheduler(cfg)
+    sch.prepare(lat)
+    model.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"text_encoder_1_text_states": text_states.cuda(), "text_encoder_1_attention_mask": mask.cuda(), "text_encoder_2_text_states": ts2.cuda()}}
+
+    def one(i):
+        sch.step_pre(i)
+        model.infer(inputs)
+        sch.step_post()
+
+    for i in range(a.warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one(a.warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    assert torch.isfinite(sch.latents).all()
+    _, _, t, h, w = wl["target_shape"]
+    n_img = t * (h // 2) * (w // 2)
+    fl = step_flops(dims, n_img, dims["text_len"])
+    print(json.dumps({"workload": a.workload, "tokens": n_img + dims["text_len"], "ms_per_step": dt * 1e3, "step_tflop": fl / 1e12, "tflops_per_s": fl / dt / 1e12,
+                      "frac_of_bf16_peak": fl / dt / 1e12 / 2500.0, "frames_per_s_50_steps": wl["frames"] / (50 * dt), "hbm_gb": torch.cuda.max_memory_allocated() / 1e9}))
+
+
+if __name__ == "__main__":
+    main()
