@@ -72,13 +72,20 @@ int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b,
 int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S, int H,
                           int64_t s0, int gf, int gh, int gw, float eps, int round_mode, void* stream);
 
+/* Same, with q additionally multiplied by q_out_scale inside its single final rounding (k untouched).  Used by the fused
+ * block driver to hand the attention kernel a q that already carries softmax_scale * log2(e)
+ * (X2V_ATTN_Q_PRESCALED): numerically one rounding of the scaled value instead of one rounding of the unscaled one. */
+int x2v_rmsnorm_rope_scaled_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S, int H,
+                                 int64_t s0, int gf, int gh, int gw, float eps, int round_mode, float q_out_scale, void* stream);
+
 /* In-place per-head RMSNorm (d = 128) of q and k [L, H*128] (token strides ldq/ldk, e.g. the column blocks of a fused
  * QKV GEMM output), followed for tokens < l_rope by the real-valued RoPE x*cos + rotate_half(x)*sin with bf16 tables
  * cos/sin [l_rope, 128] — replaces RMSWeightSgl.apply on [L,H,128] (rms_norm_weight.py:102-113; hunyuan
  * transformer_infer.py:271-272,289-290,338-339) + hunyuan/infer/utils_bf16.apply_rotary_emb (:5-31).
- * wq/wk [128] bf16 (NULL = no norm); tokens >= l_rope (the text tokens) are only normalised. */
+ * wq/wk [128] bf16 (NULL = no norm); tokens >= l_rope (the text tokens) are only normalised.  q_out_scale (1 = none;
+ * ignored with X2V_ROUND_REF) multiplies q inside its final rounding, see x2v_rmsnorm_rope_scaled_bf16. */
 int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab, const void* sin_tab, int64_t L,
-                           int H, int64_t l_rope, float eps, int round_mode, void* stream);
+                           int H, int64_t l_rope, float eps, int round_mode, float q_out_scale, void* stream);
 
 /* x[M,D] = bf16(x + bf16(y * gate)) (gate [D] bf16, NULL = plain add) — replaces `x.add_(y * gate)`
  * (transformer_infer.py:402,468,503) for callers that do not fuse it into the GEMM epilogue. */
@@ -112,7 +119,12 @@ int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, co
  * v1: 1 = 4 waves x 32 queries, 2 = 8 waves x 32 queries, 3 = 4 waves with scalar LDS reads of V instead of the
  * hardware transpose read (cross-checks ds_read_b64_tr_b16 addressing);
  * v2 (software-pipelined, LDS-DMA K, buffer loads): 4 = eager rescale, 5/6 = lazy rescale (threshold 4 / 8 in
- * base-2 units), 7 = 4-wave workgroups. */
+ * base-2 units), 7 = 4-wave workgroups;
+ * v3 (softmax scale folded into Q, running max as the MFMA C operand): 8 = single tile body, 9 = x2-unrolled loop;
+ * v4: 10 (v3 numerics, copy-free single body).  OR-ing X2V_ATTN_Q_PRESCALED into a v3/v4 variant says q already carries
+ * scale * log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16), so the kernel skips its own bf16 prescale. */
+#define X2V_ATTN_Q_PRESCALED 0x100
+#define X2V_ATTN_LOG2E_SCALE(head_dim_rsqrt) ((head_dim_rsqrt) * 1.4426950408889634f)
 int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                               int64_t Sk, int H, int head_dim, float scale, int variant, void* stream);
 

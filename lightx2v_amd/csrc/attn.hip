@@ -487,6 +487,534 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
   }
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// v3 = v2 with (1) the softmax scale folded into Q and the running max entering each score chain as the MFMA's C
+// operand, so P = exp2(S') with no per-score FMA; (2) the tile loop unrolled x2 with the two score buffers swapping
+// roles, so there is no score copy and every LDS address is base + immediate.  Per score the VALU work drops from
+// {max, fma, exp2, add, 1/2 cvt, 1/2 mov} to {max, exp2, add, 1/2 cvt}.
+template <int NW, int RESCALE_THR, bool UNROLL2, bool PRESCALED>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v3_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
+                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                                   const unsigned short* __restrict__ Vp, int64_t ldv, unsigned short* __restrict__ O,
+                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
+                                                                   unsigned v_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CPT = (AT_KV * 16) / NT;   // V chunks per thread per tile
+  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
+  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
+  const unsigned short* Vh = Vp + (int64_t)head * AT_D;
+
+  bf16x8_t qf[8];
+  {
+    int64_t qr = q0 + fl;
+    qr = qr < Sq ? qr : Sq - 1;
+    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // fold softmax scale * log2(e) into Q (one extra bf16 rounding of Q, relative 2^-9): the scores leave the MFMA in
+    // the exp2 domain, and with the running max entering as the accumulator's initial value the per-score FMA is gone
+    // (PRESCALED: the producer kernel already did this inside q's own rounding)
+    if constexpr (!PRESCALED) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t v = qf[ks];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
+        qf[ks] = v;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // K by LDS-DMA, V to registers, both through raw buffer loads: per-lane byte offsets are loop-invariant, the
+  // tile offset travels in an SGPR (soffset), and rows past Sk read as zero (hardware bounds check) — no
+  // per-tile 64-bit address VALU, no clamping.  Descriptors are wave-uniform (kernel arguments + blockIdx).
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), v_tile_bytes = (unsigned)(AT_KV * ldv * 2);
+  unsigned k_voff[KDMA];
+#pragma unroll
+  for (int j = 0; j < KDMA; ++j) {
+    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
+    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
+  }
+#define AT_DMA_K(T_, BUF_)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
+  i32x4_t vst[CPT];
+  int v_wr[CPT];
+  unsigned v_voff[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int id = i * NT + tid;
+    const int key = id >> 4, c = id & 15;
+    v_wr[i] = V_OFF + (c >> 1) * AT_VSUB + key * 32 + (c & 1) * 16;
+    v_voff[i] = (unsigned)(key * ldv * 2) + (unsigned)(c << 4);
+  }
+#define AT_LOAD_V(T_) \
+  _Pragma("unroll") for (int i = 0; i < CPT; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[i], (unsigned)(T_) * v_tile_bytes, 0);
+#define AT_WRITE_V(BUF_)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < CPT; ++i) *reinterpret_cast<i32x4_t*>(smem + (BUF_) * AT_V_BYTES + v_wr[i]) = vst[i];
+
+  // K fragment offsets: row (u*32+fl)*256 + ((ks*2+hi) ^ (fl&15))*16 = kaddr[ks] + u*8192 (+ buffer offset, immediate)
+  int kaddr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = fl * 256 + (((hi ^ (fl & 15)) << 4) ^ (ks << 5));
+  const int L = lane & 15;
+  const int v_rd_base = ((fl >> 4) * 4) * AT_VSUB + (4 * hi + (L >> 2)) * 32 + (L & 3) * 8;
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int T = 0; T < 4; ++T)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
+  // m_run: running row max (exp2 domain), entered into every score chain as C = negm = -m_run.  A chain is started two
+  // decisions before its scores are exponentiated (software pipeline), so scores carry m_run(t-2); d_prev = the growth
+  // decided at tile t-1.  Growth is rare (lazy rescale), so the fix-up  S' -= d_prev + d_cur  lives in a cold branch.
+  float m_run = 0.f, l_run = 0.f, d_prev = 0.f;
+  bool force = true;  // first tile: adopt its row max in either direction (no underflow for very negative rows)
+  f32x16_t negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+
+#define AT_QK(DST_, BUF_)                                                                                     \
+  {                                                                                                            \
+    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
+      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
+    }                                                                                                          \
+  }
+
+  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
+  AT_DMA_K(0, 0)
+  if (nt > 1) {
+    AT_DMA_K(1, 1)
+  }
+  AT_LOAD_V(0)
+  AT_WRITE_V(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t sc[2];
+  AT_QK(sc, 0)
+  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
+  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
+  __syncthreads();
+
+  // One tile, written as an explicit 32-slot software pipeline (the compiler's own interleave of two
+  // independent streams proved unreliable): every slot = {fragment read for the NEXT slot, one MFMA, a fixed
+  // chunk of VALU work}, pinned by sched_barrier(0).
+  //   slots  0..15 (phase 1): MFMA = S(t+1) += K(t+1) Q^T;  VALU = softmax of S(t): 4 slots of row-max, 1 slot of
+  //                           max exchange + the lazy-rescale decision, 11 slots of exp2 + bf16 pack
+  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T;     VALU = row-sum adds
+  // SC_/SN_ are the two score buffers (they ping-pong: the loop is unrolled x2, nothing is copied), KN_/VB_ the
+  // compile-time LDS buffer indices of K(t+1) / V(t) (every LDS address = loop-invariant VGPR + immediate).
+  // LAST_ = true (peeled final tile): key masking, no next-tile MFMAs, no prefetch.
+#define AT_SB() __builtin_amdgcn_sched_barrier(0)
+#define AT_TILE(LAST_, SC_, SN_, KN_, VB_)                                                                     \
+  {                                                                                                            \
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  \
+    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
+      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
+        if (u * 32 + acc_row(r, hi) >= left) SC_[u][r] = -1e30f;                                               \
+    }                                                                                                          \
+    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
+    bf16x8_t kf_n = *reinterpret_cast<const bf16x8_t*>(kb_ + kaddr[0]);                                        \
+    float pm[4];                                                                                               \
+    unsigned pw[16];                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
+      const int ks = i >> 1, u = i & 1;                                                                        \
+      if (!(LAST_)) {                                                                                          \
+        const bf16x8_t kf_c = kf_n;                                                                            \
+        if (i < 15) kf_n = *reinterpret_cast<const bf16x8_t*>(kb_ + ((i + 1) & 1) * 8192 + kaddr[(i + 1) >> 1]); \
+        SN_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_c, qf[ks], ks == 0 ? negm : SN_[u], 0, 0, 0);    \
+      }                                                                                                        \
+      if (i < 4) { /* row max of 8 scores: 3 v_max3 + 1 v_max */                                               \
+        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
+        float m_ = vmax3(SC_[uu][r0], SC_[uu][r0 + 1], SC_[uu][r0 + 2]);                                       \
+        m_ = vmax3(m_, SC_[uu][r0 + 3], SC_[uu][r0 + 4]);                                                      \
+        m_ = vmax3(m_, SC_[uu][r0 + 5], SC_[uu][r0 + 6]);                                                      \
+        pm[i] = vmax2(m_, SC_[uu][r0 + 7]);                                                                    \
+      } else if (i == 4) {                                                                                     \
+        float mx = vmax2(vmax3(pm[0], pm[1], pm[2]), pm[3]);                                                   \
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
+        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
+        const float ex = mx - d_prev; /* this tile's row max relative to m_run(t-1) */                             \
+        if (force || __any(ex > (float)RESCALE_THR || d_prev != 0.f)) {                                        \
+          /* cold path: some row's max grew by more than THR (or did so one tile ago, or first tile) */        \
+          const bool grow = force || __any(ex > (float)RESCALE_THR);                                           \
+          const float d_cur = grow ? (force ? ex : fmaxf(ex, 0.f)) : 0.f;                                      \
+          if (grow) {                                                                                          \
+            m_run += d_cur;                                                                                    \
+            if (!force) {                                                                                      \
+              const float al = __builtin_amdgcn_exp2f(-d_cur);                                                 \
+              l_run *= al;                                                                                     \
+              _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
+            }                                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                   \
+          }                                                                                                    \
+          const float corr = d_prev + d_cur;                                                                   \
+          _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) SC_[u][e] -= corr; \
+          d_prev = d_cur;                                                                                      \
+          force = false;                                                                                       \
+        }                                                                                                      \
+      } else { /* slots 5..15: 3 (last: 2) elements of exp2, packed to bf16 pairs as they complete */          \
+        const int e0 = (i - 5) * 3, e1 = (e0 + 3 < 32) ? e0 + 3 : 32;                                          \
+        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
+          SC_[e >> 4][e & 15] = __builtin_amdgcn_exp2f(SC_[e >> 4][e & 15]);             \
+          if (e & 1) pw[e >> 1] = pack_bf2(SC_[e >> 4][(e & 15) - 1], SC_[e >> 4][e & 15]);                    \
+        }                                                                                                      \
+      }                                                                                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+    const char* vb = smem + V_OFF + (VB_) * AT_V_BYTES + v_rd_base;                                            \
+    bf16x8_t vf_n = tr_frag(vb, vb + 8 * 32);                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
+      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
+      const bf16x8_t vf_c = vf_n;                                                                              \
+      if (j < 15) {                                                                                            \
+        const char* p0 = vb + ((j + 1) >> 2) * AT_VSUB + (((j + 1) & 3) * 16) * 32;                            \
+        vf_n = tr_frag(p0, p0 + 8 * 32);                                                                       \
+      }                                                                                                        \
+      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
+      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_c, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      l_run += SC_[j >> 3][(j & 7) * 2] + SC_[j >> 3][(j & 7) * 2 + 1];                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+  }
+  // Two tiles per iteration with the score buffers swapping roles (compile-time names and LDS buffer indices): no
+  // score copy, no per-tile LDS address arithmetic.
+#define AT_ITER(T_, SC_, SN_, KN_, VB_)                                                                         \
+  {                                                                                                            \
+    if ((T_) + 2 < nt) {                                                                                       \
+      AT_DMA_K((T_) + 2, VB_)                                                                                  \
+    }                                                                                                          \
+    AT_LOAD_V((T_) + 1)                                                                                        \
+    AT_SB();                                                                                                   \
+    AT_TILE(false, SC_, SN_, KN_, VB_)                                                                         \
+    AT_WRITE_V(KN_)                                                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+    __syncthreads();                                                                                           \
+  }
+  f32x16_t sd[2];
+  int t = 0;
+  if constexpr (UNROLL2) {
+    for (; t + 2 < nt; t += 2) {
+      AT_ITER(t, sc, sd, 1, 0)
+      ++t;
+      AT_ITER(t, sd, sc, 0, 1)
+      --t;
+    }
+    if (t + 1 < nt) {
+      AT_ITER(t, sc, sd, 1, 0)
+      ++t;
+      AT_TILE(true, sd, sc, 0, 1)
+    } else {
+      AT_TILE(true, sc, sd, 1, 0)
+    }
+  } else {
+    for (; t < nt - 1; ++t) {
+      AT_ITER(t, sc, sd, (t + 1) & 1, t & 1)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) sc[u] = sd[u];
+    }
+    AT_TILE(true, sc, sd, (t + 1) & 1, t & 1)
+  }
+#undef AT_ITER
+#undef AT_TILE
+#undef AT_SB
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + fl;
+  if (qrow < Sq) {
+    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 8 * g + 4 * hi;
+        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
+        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dv) = pk;
+      }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// v4 = v3's numerics (scale folded into Q, running max as the chain's C operand) with a tile body in which the last
+// link of each S(t+1) chain writes into the buffer S(t) has just vacated (no score copy, no unroll), all softmax VALU
+// in phase 1 with row sums in four partial chains, tree-shaped row maxima, and fragment reads two slots ahead.
+template <int NW, int RESCALE_THR, bool PRESCALED>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
+                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                                   const unsigned short* __restrict__ Vp, int64_t ldv, unsigned short* __restrict__ O,
+                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
+                                                                   unsigned v_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CPT = (AT_KV * 16) / NT;   // V chunks per thread per tile
+  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
+  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
+  const unsigned short* Vh = Vp + (int64_t)head * AT_D;
+
+  bf16x8_t qf[8];
+  {
+    int64_t qr = q0 + fl;
+    qr = qr < Sq ? qr : Sq - 1;
+    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // fold softmax scale * log2(e) into Q (one extra bf16 rounding of Q, relative 2^-9): the scores leave the MFMA in
+    // the exp2 domain, and with the running max entering as the accumulator's initial value the per-score FMA is gone
+    // (PRESCALED: the producer kernel already did this inside q's own rounding)
+    if constexpr (!PRESCALED) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t v = qf[ks];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
+        qf[ks] = v;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // K by LDS-DMA, V to registers, both through raw buffer loads: per-lane byte offsets are loop-invariant, the
+  // tile offset travels in an SGPR (soffset), and rows past Sk read as zero (hardware bounds check) — no
+  // per-tile 64-bit address VALU, no clamping.  Descriptors are wave-uniform (kernel arguments + blockIdx).
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), v_tile_bytes = (unsigned)(AT_KV * ldv * 2);
+  unsigned k_voff[KDMA];
+#pragma unroll
+  for (int j = 0; j < KDMA; ++j) {
+    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
+    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
+  }
+#define AT_DMA_K(T_, BUF_)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
+  i32x4_t vst[CPT];
+  int v_wr[CPT];
+  unsigned v_voff[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int id = i * NT + tid;
+    const int key = id >> 4, c = id & 15;
+    v_wr[i] = V_OFF + (c >> 1) * AT_VSUB + key * 32 + (c & 1) * 16;
+    v_voff[i] = (unsigned)(key * ldv * 2) + (unsigned)(c << 4);
+  }
+#define AT_LOAD_V(T_) \
+  _Pragma("unroll") for (int i = 0; i < CPT; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[i], (unsigned)(T_) * v_tile_bytes, 0);
+#define AT_WRITE_V(BUF_)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < CPT; ++i) *reinterpret_cast<i32x4_t*>(smem + (BUF_) * AT_V_BYTES + v_wr[i]) = vst[i];
+
+  // K fragment offsets: row (u*32+fl)*256 + ((ks*2+hi) ^ (fl&15))*16 = kaddr[ks] + u*8192 (+ buffer offset, immediate)
+  int kaddr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = fl * 256 + (((hi ^ (fl & 15)) << 4) ^ (ks << 5));
+  const int L = lane & 15;
+  const int v_rd_base = ((fl >> 4) * 4) * AT_VSUB + (4 * hi + (L >> 2)) * 32 + (L & 3) * 8;
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int T = 0; T < 4; ++T)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
+  // m_run: running row max (exp2 domain), entered into every score chain as C = negm = -m_run.  A chain is started two
+  // decisions before its scores are exponentiated (software pipeline), so scores carry m_run(t-2); d_prev = the growth
+  // decided at tile t-1.  Growth is rare (lazy rescale), so the fix-up  S' -= d_prev + d_cur  lives in a cold branch.
+  float m_run = 0.f, d_prev = 0.f;
+  float lsum[4] = {0.f, 0.f, 0.f, 0.f};  // row sum in four partial chains (a single accumulator would serialise 32 dependent adds)
+  bool force = true;  // first tile: adopt its row max in either direction (no underflow for very negative rows)
+  f32x16_t negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+
+#define AT_QK(DST_, BUF_)                                                                                     \
+  {                                                                                                            \
+    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
+      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
+    }                                                                                                          \
+  }
+
+  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
+  AT_DMA_K(0, 0)
+  if (nt > 1) {
+    AT_DMA_K(1, 1)
+  }
+  AT_LOAD_V(0)
+  AT_WRITE_V(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t sc[2];
+  AT_QK(sc, 0)
+  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
+  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
+  __syncthreads();
+
+  // One tile = 32 slots, each {fragment read two slots ahead, one MFMA, a fixed chunk of VALU work}, pinned by
+  // sched_barrier(0).
+  //   slots  0..15 (phase 1): MFMA = S(t+1) chain (K(t+1) Q'^T, C = negm at its head), accumulated in `sn`; the LAST link
+  //                           of each chain (slots 14, 15) writes its result into `sc`, which the VALU side has finished
+  //                           with by then — the score buffers swap roles without a copy and without unrolling.
+  //                           VALU = softmax of S(t) in sc: slots 0-3 row max (trees), slot 4 half-wave exchange + the
+  //                           lazy-rescale decision (cold branch), slots 5-9 exp2 / row-sum / bf16 pack of sc[0],
+  //                           slots 10-14 of sc[1].
+  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T from the packed P; no VALU (sn is dead: registers are free for
+  //                           the deeper fragment prefetch).
+#define AT_SB() __builtin_amdgcn_sched_barrier(0)
+#define A4_KFRAG(I_) (*reinterpret_cast<const bf16x8_t*>(kb_ + ((I_) & 1) * 8192 + kaddr[(I_) >> 1]))
+#define A4_VFRAG(J_) tr_frag(vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32, vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32 + 8 * 32)
+#define A4_TILE(LAST_, KN_, VB_)                                                                               \
+  {                                                                                                            \
+    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
+      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
+        if (u * 32 + acc_row(r, hi) >= left) sc[u][r] = -1e30f;                                                \
+    }                                                                                                          \
+    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
+    bf16x8_t kfa, kfb;                                                                                         \
+    if (!(LAST_)) {                                                                                            \
+      kfa = A4_KFRAG(0);                                                                                       \
+      kfb = A4_KFRAG(1);                                                                                       \
+    }                                                                                                          \
+    float pm[4];                                                                                               \
+    unsigned pw[16];                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
+      const int ks = i >> 1, u = i & 1;                                                                        \
+      if (!(LAST_)) {                                                                                          \
+        if (i < 14) sn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], ks == 0 ? negm : sn[u], 0, 0, 0); \
+        else sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], sn[u], 0, 0, 0);           \
+        if (i + 2 < 16) {                                                                                      \
+          if (u) kfb = A4_KFRAG(i + 2); else kfa = A4_KFRAG(i + 2);                                            \
+        }                                                                                                      \
+      }                                                                                                        \
+      if (i < 4) { /* row max of 8 scores as a depth-2 tree */                                                 \
+        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
+        const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                    \
+        const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                \
+        const float c_ = vmax2(sc[uu][r0 + 6], sc[uu][r0 + 7]);                                                \
+        pm[i] = vmax3(a_, b_, c_);                                                                             \
+      } else if (i == 4) {                                                                                     \
+        float mx = vmax2(vmax2(pm[0], pm[1]), vmax2(pm[2], pm[3]));                                            \
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
+        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
+        const float ex = mx - d_prev; /* this tile's row max relative to m_run(t-1) */                         \
+        if (force || __any(ex > (float)RESCALE_THR || d_prev != 0.f)) {                                        \
+          /* cold path: some row's max grew by more than THR (or did so one tile ago, or first tile) */        \
+          const bool grow = force || __any(ex > (float)RESCALE_THR);                                           \
+          const float d_cur = grow ? (force ? ex : fmaxf(ex, 0.f)) : 0.f;                                      \
+          if (grow) {                                                                                          \
+            m_run += d_cur;                                                                                    \
+            if (!force) {                                                                                      \
+              const float al = __builtin_amdgcn_exp2f(-d_cur);                                                 \
+              _Pragma("unroll") for (int e = 0; e < 4; ++e) lsum[e] *= al;                                     \
+              _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
+            }                                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                   \
+          }                                                                                                    \
+          const float corr = d_prev + d_cur;                                                                   \
+          _Pragma("unroll") for (int u2 = 0; u2 < 2; ++u2) _Pragma("unroll") for (int e = 0; e < 16; ++e) sc[u2][e] -= corr; \
+          d_prev = d_cur;                                                                                      \
+          force = false;                                                                                       \
+        }                                                                                                      \
+      } else if (i < 15) { /* slots 5..9: sc[0], slots 10..14: sc[1]; 4,3,3,3,3 elements */                    \
+        const int uu = (i - 5) / 5, q_ = (i - 5) % 5;                                                          \
+        const int e0 = q_ == 0 ? 0 : 1 + 3 * q_, e1 = 4 + 3 * q_;                                              \
+        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
+          const float p_ = __builtin_amdgcn_exp2f(sc[uu][e]);                                                  \
+          sc[uu][e] = p_;                                                                                      \
+          lsum[e & 3] += p_;                                                                                   \
+          if (e & 1) pw[uu * 8 + (e >> 1)] = pack_bf2(sc[uu][e - 1], p_);                                      \
+        }                                                                                                      \
+      }                                                                                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+    const char* vb = smem + V_OFF + (VB_) * AT_V_BYTES + v_rd_base;                                            \
+    bf16x8_t vfa = A4_VFRAG(0), vfb = A4_VFRAG(1);                                                             \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
+      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
+      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
+      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((j & 1) ? vfb : vfa, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      if (j + 2 < 16) {                                                                                        \
+        if (j & 1) vfb = A4_VFRAG(j + 2); else vfa = A4_VFRAG(j + 2);                                          \
+      }                                                                                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+  }
+  f32x16_t sn[2];
+  int t = 0;
+  for (; t < nt - 1; ++t) {
+    if (t + 2 < nt) {
+      AT_DMA_K(t + 2, t & 1)
+    }
+    AT_LOAD_V(t + 1)
+    AT_SB();
+    A4_TILE(false, (t + 1) & 1, t & 1)
+    AT_WRITE_V((t + 1) & 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  A4_TILE(true, (t + 1) & 1, t & 1)
+#undef A4_TILE
+#undef A4_VFRAG
+#undef A4_KFRAG
+#undef AT_SB
+
+  const float l_run = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + fl;
+  if (qrow < Sq) {
+    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 8 * g + 4 * hi;
+        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
+        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dv) = pk;
+      }
+  }
+#endif
+}
 #undef AT_DMA_K
 #undef AT_LOAD_V
 #undef AT_WRITE_V
@@ -535,8 +1063,51 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
   return X2V_OK;
 }
 
+template <int NW, int THR, bool UNROLL2, bool PRESCALED>
+static int launch_attn_v3(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
+                            int64_t Sk, int H, float scale, hipStream_t st) {
+  // buffer descriptors address 32 bits: the per-head K/V views must stay below 4 GiB
+  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (Sk - 1) * ldv * 2 + AT_D * 2;
+  X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32) - (int64_t)AT_KV * ldv * 2, X2V_E_SHAPE,
+              "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_v3_kernel<NW, THR, UNROLL2, PRESCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  const int QB = NW * 32;
+  dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
+  hipLaunchKernelGGL((attn_fwd_v3_kernel<NW, THR, UNROLL2, PRESCALED>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
+                     (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
+  X2V_LAUNCH_CHECK("attn launch");
+  return X2V_OK;
+}
+
+template <int NW, int THR, bool PRESCALED>
+static int launch_attn_v4(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
+                            int64_t Sk, int H, float scale, hipStream_t st) {
+  // buffer descriptors address 32 bits: the per-head K/V views must stay below 4 GiB
+  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (Sk - 1) * ldv * 2 + AT_D * 2;
+  X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32) - (int64_t)AT_KV * ldv * 2, X2V_E_SHAPE,
+              "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_v4_kernel<NW, THR, PRESCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  const int QB = NW * 32;
+  dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
+  hipLaunchKernelGGL((attn_fwd_v4_kernel<NW, THR, PRESCALED>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
+                     (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
+  X2V_LAUNCH_CHECK("attn launch");
+  return X2V_OK;
+}
+
 // variant: 0 = default (= 6); v1 kernels: 1 = 4 waves, 2 = 8 waves, 3 = 4 waves + scalar-V validation path for the transpose read;
-// v2 software-pipelined kernels: 4 = 8 waves eager rescale, 5 = lazy rescale THR 4, 6 = lazy THR 8, 7 = 4 waves lazy THR 4
+// v2 software-pipelined kernels: 4 = 8 waves eager rescale, 5 = lazy rescale THR 4, 6 = lazy THR 8, 7 = 4 waves lazy THR 4;
+// v3 (scale folded into Q, running max as the MFMA C operand, x2-unrolled tile loop): 8 = THR 8, 9 = THR 4
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                                          int64_t Sk, int H, int head_dim, float scale, int variant, void* stream) {
   X2V_REQUIRE(q && k && v && o, X2V_E_ARG, "attn: null pointer");
@@ -557,6 +1128,11 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(
     case 4: return launch_attn_pipe<8, -1>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 5: return launch_attn_pipe<8, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 7: return launch_attn_pipe<4, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 8: return launch_attn_v3<8, 8, false, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 9: return launch_attn_v3<8, 8, true, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 10: return launch_attn_v4<8, 8, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 9 | X2V_ATTN_Q_PRESCALED: return launch_attn_v3<8, 8, true, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 10 | X2V_ATTN_Q_PRESCALED: return launch_attn_v4<8, 8, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     default: set_error("attn: unknown variant %d", variant); return X2V_E_ARG;
   }
 }

@@ -156,10 +156,11 @@ template <int CH, int ROUND>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
                                                            const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
                                                            const float2* __restrict__ cs, int64_t S, int D, int64_t s0, int gf, int gh, int gw,
-                                                           float eps) {
+                                                           float eps, float q_out_scale) {
   __shared__ float red[4];
   const int t = threadIdx.x;
   const int64_t row = blockIdx.x;
+  const float oscale = blockIdx.y == 0 ? q_out_scale : 1.f;  // folded into q's single final rounding (attention prescale)
   unsigned short* base = (blockIdx.y == 0 ? q + row * ldq : k + row * ldk);
   const unsigned short* w = blockIdx.y == 0 ? wq : wk;
   RowRegs<CH, 4> r;
@@ -217,8 +218,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(unsigned short* __res
         si = f.y;
       }
       const float a = xn[2 * p], bb = xn[2 * p + 1];
-      o[2 * p] = a * co - bb * si;
-      o[2 * p + 1] = a * si + bb * co;
+      o[2 * p] = (a * co - bb * si) * oscale;
+      o[2 * p + 1] = (a * si + bb * co) * oscale;
     }
     *reinterpret_cast<uint4*>(base + e) = pack8(o);
   }
@@ -291,7 +292,7 @@ template <int ROUND>
 __global__ __launch_bounds__(256) void headnorm_rope_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
                                                             const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
                                                             const unsigned short* __restrict__ cosb, const unsigned short* __restrict__ sinb, int64_t L,
-                                                            int H, int64_t l_rope, float eps) {
+                                                            int H, int64_t l_rope, float eps, float q_out_scale) {
   const int sub = threadIdx.x & 15;
   const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= L * H) return;  // whole 16-lane groups leave together; the shuffles below stay inside a group
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(unsigned short* __re
   unsigned short* base = blockIdx.y == 0 ? q + tok * ldq : k + tok * ldk;
   const unsigned short* w = blockIdx.y == 0 ? wq : wk;
   unsigned short* p = base + head * 128 + sub * 8;
+  const float oscale = (blockIdx.y == 0 && ROUND != X2V_ROUND_REF) ? q_out_scale : 1.f;
   float v[8], wv[8];
   unpack8(*reinterpret_cast<const uint4*>(p), v);
   if (w != nullptr) {
@@ -319,8 +321,12 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(unsigned short* __re
     } else {
       rs = 1.0f / sqrtf(ss / 128.f + eps);
     }
+    // q_out_scale (attention prescale, FP32 mode only): folded into the value's last rounding — for un-rotated (text)
+    // rows that is the norm's rounding, for rotated rows the rotary sum's
+    const bool scale_here = ROUND != X2V_ROUND_REF && tok >= l_rope;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (ROUND == X2V_ROUND_REF) ? rbf(rbf(v[j] * rs) * wv[j]) : rbf(v[j] * rs * wv[j]);
+    for (int j = 0; j < 8; ++j)
+      v[j] = (ROUND == X2V_ROUND_REF) ? rbf(rbf(v[j] * rs) * wv[j]) : (scale_here ? v[j] * rs * wv[j] * oscale : rbf(v[j] * rs * wv[j]));
   }
   if (tok < l_rope) {
     float c[8], sn[8];
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(unsigned short* __re
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
       const float re = v[j], im = v[j + 1];
-      v[j] = rbf(re * c[j]) + rbf(-im * sn[j]);
-      v[j + 1] = rbf(im * c[j + 1]) + rbf(re * sn[j + 1]);
+      v[j] = (rbf(re * c[j]) + rbf(-im * sn[j])) * oscale;
+      v[j + 1] = (rbf(im * c[j + 1]) + rbf(re * sn[j + 1])) * oscale;
     }
   }
   *reinterpret_cast<uint4*>(p) = pack8(v);
@@ -419,7 +425,14 @@ extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16(const v
 
 extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S,
                                      int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode, void* stream) {
+  return x2v_rmsnorm_rope_scaled_bf16(q, ldq, k, ldk, wq, wk, rope_cs, S, H, s0, gf, gh, gw, eps, round_mode, 1.0f, stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs,
+                                                                                   int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode,
+                                                                                   float q_out_scale, void* stream) {
   X2V_REQUIRE(q && k && rope_cs, X2V_E_ARG, "rmsnorm_rope: null pointer");
+  X2V_REQUIRE(q_out_scale > 0.f, X2V_E_ARG, "rmsnorm_rope: q_out_scale must be positive");
   X2V_REQUIRE((wq == nullptr) == (wk == nullptr), X2V_E_ARG, "rmsnorm_rope: wq and wk must be given together");
   const int D = H * 128;
   X2V_REQUIRE(H > 0 && D <= 16384, X2V_E_SHAPE, "rmsnorm_rope: H=%d out of range", H);
@@ -437,9 +450,9 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_bf16(void
   int rc = dispatch_ch(ch, D, [&](auto chc) {
     constexpr int CH = decltype(chc)::value;
     if (round_mode == X2V_ROUND_REF)
-      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_REF>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps);
+      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_REF>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
     else
-      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_FP32>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps);
+      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_FP32>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
   });
   if (rc != X2V_OK) return rc;
   X2V_LAUNCH_CHECK("rmsnorm_rope launch");
@@ -485,7 +498,8 @@ extern "C" __attribute__((visibility("default"))) int x2v_sinusoid_embed_bf16(co
 
 extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab,
                                                                              const void* sin_tab, int64_t L, int H, int64_t l_rope, float eps, int round_mode,
-                                                                             void* stream) {
+                                                                             float q_out_scale, void* stream) {
+  X2V_REQUIRE(q_out_scale > 0.f, X2V_E_ARG, "headnorm_rope: q_out_scale must be positive");
   X2V_REQUIRE(q && k, X2V_E_ARG, "headnorm_rope: null pointer");
   X2V_REQUIRE(L > 0 && H > 0 && l_rope >= 0 && l_rope <= L, X2V_E_SHAPE, "headnorm_rope: bad shape L=%lld H=%d l_rope=%lld", (long long)L, H, (long long)l_rope);
   X2V_REQUIRE(l_rope == 0 || (cos_tab && sin_tab), X2V_E_ARG, "headnorm_rope: rope tables missing");
@@ -497,10 +511,10 @@ extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_bf16(voi
   dim3 grid((unsigned)((rows + 15) / 16), 2);
   if (round_mode == X2V_ROUND_REF)
     hipLaunchKernelGGL((headnorm_rope_kernel<X2V_ROUND_REF>), grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)q, ldq, (unsigned short*)k, ldk,
-                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps);
+                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps, q_out_scale);
   else
     hipLaunchKernelGGL((headnorm_rope_kernel<X2V_ROUND_FP32>), grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)q, ldq, (unsigned short*)k, ldk,
-                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps);
+                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps, q_out_scale);
   X2V_LAUNCH_CHECK("headnorm_rope launch");
   return X2V_OK;
 }

@@ -171,6 +171,8 @@ class HunyuanTransformerInfer:
         self.round_mode = lib.ROUND_REF if config.get("hip_ref_rounding", False) else lib.ROUND_FP32
         self.parallel_attention = None
         self._segs = None
+        # fp32-statistics mode: q leaves the norm+RoPE kernel carrying softmax_scale*log2(e) (one rounding), see x2v.h
+        self._qs = lib.ATTN_PRESCALE if self.round_mode == lib.ROUND_FP32 else 1.0
 
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler
@@ -199,8 +201,9 @@ class HunyuanTransformerInfer:
         return dict(mod=e(L, D), qkv=e(L, 3 * D), cat=e(L, D + F), hid=e(L, F))
 
     def _attention(self, q, k, v, out):
+        variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if self._qs != 1.0 else 0
         for a, b in self._segs:
-            lib.attention(q[a:b], k[a:b], v[a:b], self.heads_num, 128, out=out[a:b])
+            lib.attention(q[a:b], k[a:b], v[a:b], self.heads_num, 128, out=out[a:b], variant=variant)
 
     def infer_double_block(self, weights, x, n_img, vec_silu, freqs_cis, ws):
         """transformer_infer.py:81-310 on the joint buffer x = [img ; txt]."""
@@ -216,8 +219,8 @@ class HunyuanTransformerInfer:
         weights.txt_attn_qkv.apply(mod[n_img:], out=qkv[n_img:])
         q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
         cos, sin = freqs_cis
-        lib.headnorm_rope_(q[:n_img], k[:n_img], weights.img_attn_q_norm.weight, weights.img_attn_k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode)
-        lib.headnorm_rope_(q[n_img:], k[n_img:], weights.txt_attn_q_norm.weight, weights.txt_attn_k_norm.weight, None, None, H, 0, 1e-6, self.round_mode)
+        lib.headnorm_rope_(q[:n_img], k[:n_img], weights.img_attn_q_norm.weight, weights.img_attn_k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
+        lib.headnorm_rope_(q[n_img:], k[n_img:], weights.txt_attn_q_norm.weight, weights.txt_attn_k_norm.weight, None, None, H, 0, 1e-6, self.round_mode, self._qs)
         attn = ws["cat"][:, :D]
         self._attention(q, k, v, attn)
         # x += proj(attn) * gate1 ; x += fc2(gelu(fc1(LN(x)*(1+scale2)+shift2))) * gate2   — per stream
@@ -244,7 +247,7 @@ class HunyuanTransformerInfer:
         lib.gemm(mod, w1[3 * D :], b1[3 * D :], epilogue=lib.EPI_GELU_TANH, out=cat[:, D:])      # mlp rows, GELU, into linear2's input
         q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
         cos, sin = freqs_cis
-        lib.headnorm_rope_(q, k, weights.q_norm.weight, weights.k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode)
+        lib.headnorm_rope_(q, k, weights.q_norm.weight, weights.k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
         self._attention(q, k, v, cat[:, :D])
         weights.linear2.apply(cat, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate)
         return x

@@ -8,6 +8,8 @@ device, raises — there is no eager/PyTorch fallback on the product path.
 import ctypes
 import os
 
+import math
+
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,7 +29,8 @@ PROTOTYPES = {
     "x2v_rmsnorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
     "x2v_layernorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
     "x2v_rmsnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
-    "x2v_headnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _c_void_p],
+    "x2v_rmsnorm_rope_scaled_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _c_void_p],
+    "x2v_headnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _f32, _c_void_p],
     "x2v_gate_residual_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
@@ -133,15 +136,21 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
     return out2
 
 
-def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_mode=ROUND_FP32):
-    """In place: q,k [S, H*128] ← RoPE3D(RMSNorm(q|k))."""
+ATTN_Q_PRESCALED = 0x100
+ATTN_FAST = 9  # v3 kernel, x2-unrolled (include/x2v.h); used with ATTN_Q_PRESCALED by the fused block drivers
+ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
+
+
+def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0):
+    """In place: q,k [S, H*128] ← RoPE3D(RMSNorm(q|k)); q additionally * q_out_scale inside its final rounding."""
     q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
     if rope_cs.dtype != torch.float32 or tuple(rope_cs.shape) != (1024, 64, 2) or not rope_cs.is_contiguous():
         raise X2VError("rope_cs must be a contiguous float32 [1024,64,2] (cos,sin) table")
     gf, gh, gw = grid
     init()
     _check(
-        _lib.x2v_rmsnorm_rope_bf16(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(wq), _p(wk), _p(rope_cs), q2.shape[0], num_heads, s0, gf, gh, gw, eps, round_mode, _stream()),
+        _lib.x2v_rmsnorm_rope_scaled_bf16(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(wq), _p(wk), _p(rope_cs), q2.shape[0], num_heads, s0, gf, gh, gw, eps, round_mode,
+                                          q_out_scale, _stream()),
         "rmsnorm_rope",
     )
     return q, k
@@ -306,10 +315,10 @@ def softmax_rows_(s, scale):
     return s
 
 
-def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mode=ROUND_FP32):
+def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0):
     """In place on q, k [L, H*128] views (unit inner stride, any token stride): per-head RMSNorm + real RoPE on the
     first l_rope tokens (x2v_headnorm_rope_bf16)."""
     L = q.shape[0]
     init()
-    _check(_lib.x2v_headnorm_rope_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, _stream()),
+    _check(_lib.x2v_headnorm_rope_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, q_out_scale, _stream()),
            "headnorm_rope")

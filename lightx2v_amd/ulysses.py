@@ -50,11 +50,11 @@ class UlyssesAttention:
 
     def __init__(self, group=None, attn_fn=None, overlap=True):
         self.group = group
-        self.attn_fn = attn_fn or (lambda q, k, v, h, d: lib.attention(q, k, v, h, d))
+        self.attn_fn = attn_fn or (lambda q, k, v, h, d, variant=0: lib.attention(q, k, v, h, d, variant=variant))
         self.overlap = overlap and torch.cuda.is_available()
         self.comm_stream = None
 
-    def __call__(self, q, k, v, num_heads, head_dim=128, timer=None):
+    def __call__(self, q, k, v, num_heads, head_dim=128, timer=None, variant=0):
         n, _ = _world(self.group)
         if num_heads % n != 0:
             raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
@@ -70,7 +70,7 @@ class UlyssesAttention:
             cur.wait_stream(self.comm_stream)
         else:
             qh, kh, vh = seq2head(q, self.group), seq2head(k, self.group), seq2head(v, self.group)
-        fn = lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim)
+        fn = (lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim, variant=variant)) if variant else (lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim))
         o = timer("self", fn) if timer is not None else fn()
         return head2seq(o, self.group)
 

@@ -246,12 +246,17 @@ class WanTransformerInfer:
             if self._rope_cs is None or self._rope_cs.device != x.device:
                 self._rope_cs = torch.stack([freqs.real, freqs.imag], dim=-1).to(torch.float32).contiguous().to(x.device)
             freqs = self._rope_cs
+        # default (fp32-statistics) mode: q leaves the norm+RoPE kernel already multiplied by softmax_scale*log2(e) inside
+        # its one rounding, and the attention kernel variant that expects that skips the per-score FMA (x2v.h)
+        fast = self.round_mode == lib.ROUND_FP32
         lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads,
-                          s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode)
+                          s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode,
+                          q_out_scale=lib.ATTN_PRESCALE if fast else 1.0)
+        variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if fast else 0
         if self.parallel_attention is None:
-            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim))
+            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant))
         else:
-            attn = self.parallel_attention(q=q, k=k, v=v, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed)
+            attn = self.parallel_attention(q=q, k=k, v=v, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)
         return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
 
     def infer_cross_attn(self, weights, x, context):

@@ -123,3 +123,18 @@ def test_padded_text_two_segments_vs_oracle(setup):
     with torch.no_grad():
         ref = H.forward(wd, dims, lat.to(torch.bfloat16), sch.timesteps[2].cpu(), sch.guidance.cpu(), text_states, mask, ts2, (sch.freqs_cos.cpu(), sch.freqs_sin.cpu()))
     assert_rel(sch.noise_pred, ref, 2e-2, "forward with padded text")
+
+
+def test_forward_default_rounding_fast_attention(setup):
+    """Default mode: fp32 norm statistics, q pre-scaled by the norm+RoPE kernel, v3 attention kernel (x2v.h variants)."""
+    from lightx2v_amd import hunyuan as hy
+
+    _, _, g, wd, dims = setup
+    cfg = hy.default_config(dims, infer_steps=4)
+    model = hy.HunyuanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+    sch = hy.HunyuanScheduler(cfg)
+    sch.prepare(g["latents"])
+    model.set_scheduler(sch)
+    sch.step_pre(1)
+    model.infer(_inputs(g))
+    assert_rel(sch.noise_pred, g["noise_pred"], 2e-2, "HunyuanModel.infer (default rounding)")

@@ -645,7 +645,7 @@ static void run_attn() {
     DevBuf<uint16_t> dq(q), dk(k), dv(v), dout((size_t)sh.Sq * sh.H * 128);
     std::vector<float> ref;
     ref_attn(q, k, v, sh.Sq, sh.Sk, sh.H, ref);
-    for (int variant = 0; variant <= 7; ++variant) {
+    for (int variant = 0; variant <= 10; ++variant) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       X2V_OKAY(x2v_attn_fwd_bf16_variant(dq.p, sh.H * 128, dk.p, sh.H * 128, dv.p, sh.H * 128, dout.p, sh.H * 128, sh.Sq, sh.Sk, sh.H, 128, 0.f, variant,
                                          nullptr));
@@ -653,6 +653,33 @@ static void run_attn() {
       char name[160];
       snprintf(name, sizeof name, "attn Sq=%lld Sk=%lld H=%d variant=%d", (long long)sh.Sq, (long long)sh.Sk, sh.H, variant);
       report(name, compare(to_f(dout.host()), ref, 6e-3, 0.016), 0.0);  // bf16 P + bf16 output
+    }
+  }
+  // every score strongly negative (keys anti-aligned with the queries): the running max must be adopted downwards on
+  // the first tile or exp2 underflows and l = 0; plus a late positive spike far above everything before it
+  {
+    const int64_t S = 300;
+    const int H = 2;
+    auto q = rand_bf((size_t)S * H * 128, rng, 1.0f), v = rand_bf((size_t)S * H * 128, rng, 1.0f);
+    std::vector<uint16_t> k(q.size());
+    for (int64_t s = 0; s < S; ++s)
+      for (int h = 0; h < H; ++h)
+        for (int e = 0; e < 128; ++e) {
+          const float base = bf2f(q[(size_t)(7 * H + h) * 128 + e]);
+          k[(size_t)(s * H + h) * 128 + e] = f2bf((s == 250 ? 6.0f : -12.0f) * base + 0.05f * rng.normal());
+        }
+    DevBuf<uint16_t> dq(q), dk(k), dv(v), dout((size_t)S * H * 128);
+    std::vector<float> ref;
+    ref_attn(q, k, v, S, S, H, ref);
+    for (int variant : {6, 8, 9, 10}) {
+      HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
+      X2V_OKAY(x2v_attn_fwd_bf16_variant(dq.p, H * 128, dk.p, H * 128, dv.p, H * 128, dout.p, H * 128, S, S, H, 128, 0.f, variant, nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      char name[160];
+      snprintf(name, sizeof name, "attn anti-aligned keys + late spike variant=%d", variant);
+      // v3/v4 round Q * scale * log2(e) to bf16 once more (relative 2^-9); keys 12x larger than any real (normalised) key
+      // amplify that to ~0.03 in the exponent where the spike and the 299 other keys carry comparable weight
+      report(name, compare(to_f(dout.host()), ref, variant >= 8 ? 6e-2 : 6e-3, 0.016), 0.0);
     }
   }
   // strided (fused-QKV style) views: ld = 3*H*128
@@ -878,7 +905,7 @@ static void run_bench(bool big) {
     fill_random(q, rng, 1.f);
     fill_random(k, rng, 1.f);
     fill_random(v, rng, 1.f);
-    for (int variant : {2, 4, 6}) {
+    for (int variant : {6, 9, 10}) {
       const double flop = 4.0 * a.Sq * a.Sk * a.H * 128;
       const int iters = flop > 2e13 ? 1 : 5;
       double ms = time_ms(iters, [&] {
