@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
+    ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
+    ap.add_argument("--distill", action="store_true", help="4-step distilled schedule of config #4 (no CFG, denoising_step_list 1000/750/500/250, shift 5)")
     return ap.parse_args()
 
 
@@ -148,10 +150,17 @@ def main():
     dims = synth.WAN_DIMS[wl["model"]]
     ts = wl["target_shape"]
     S = synth.seq_len_of(ts)
-    enable_cfg = not args.no_cfg
+    enable_cfg = not (args.no_cfg or args.distill)
+    if args.distill:
+        args.infer_steps = 4
+    extra = {}
+    if args.fp8:
+        extra["mm_config"] = {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}
+    if args.distill:
+        extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
     cfg = wan.default_config(
         dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
-        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding,
+        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, **extra,
     )
     if world > 1 and dims["num_heads"] % world != 0:
         raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
@@ -161,7 +170,7 @@ def main():
     model = wan.WanModel(cfg, wd)
     del wd
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
-    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch = (scheduler.WanStepDistillScheduler if args.distill else scheduler.WanScheduler)(cfg, device="cuda")
     sch.prepare(latents=lat)
     model.set_scheduler(sch)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
@@ -231,7 +240,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": "fp8-e4m3 w8a8 GEMMs, bf16 attention" if args.fp8 else "bf16",
         "data": "synthetic",
         "config": {
             "workload": args.workload,
@@ -242,6 +251,7 @@ def main():
             "infer_steps": args.infer_steps,
             "cfg_forwards_per_step": fwd,
             "parallelism": f"ulysses-sp{world}" if world > 1 else "single",
+            "schedule": "step-distill 4 steps (no CFG)" if args.distill else "UniPC",
             "fps_definition": "frames / (infer_steps * ms_per_step), denoise loop only (no text encoder / VAE)",
             "step_tflop": flop_step / 1e12,
             "step_tflops_per_s_per_gpu": flop_step / (ms_per_step * 1e-3) / 1e12 / world,

@@ -889,6 +889,30 @@ static void run_bench(bool big) {
       printf("BENCH gemm_bf16 v=%d gm=%d sched=%d %-42s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)\n", variant & 255, (variant >> 8) & 255, variant >> 16, g.name, ms, tf, tf / 25.0);
     }
   }
+  if (big) {  // fp8 w8a8 GEMMs (config #4) on the 14B shapes
+    struct F { const char* name; int64_t M; int N, K; } fs[] = {{"14B qkv/o   S=75600 D=5120", 75600, 5120, 5120}, {"14B ffn0    5120->13824", 75600, 13824, 5120},
+                                                              {"14B ffn2    13824->5120", 75600, 5120, 13824}};
+    for (auto f : fs) {
+      DevBuf<uint8_t> xq((size_t)f.M * f.K), wq((size_t)f.N * f.K);
+      DevBuf<float> sx(f.M), sw(f.N);
+      DevBuf<uint16_t> b(f.N), y((size_t)f.M * f.N);
+      {
+        std::vector<uint8_t> h(1 << 22);
+        for (auto& v : h) { v = (uint8_t)(rng.next() & 0xff); if ((v & 0x7f) >= 0x78) v &= 0xbf; }
+        for (size_t off = 0; off < xq.n; off += h.size()) HIP_OK(hipMemcpy(xq.p + off, h.data(), std::min(h.size(), xq.n - off), hipMemcpyHostToDevice));
+        for (size_t off = 0; off < wq.n; off += h.size()) HIP_OK(hipMemcpy(wq.p + off, h.data(), std::min(h.size(), wq.n - off), hipMemcpyHostToDevice));
+        std::vector<float> s1(f.M, 0.01f), s2(f.N, 0.001f);
+        HIP_OK(hipMemcpy(sx.p, s1.data(), s1.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(sw.p, s2.data(), s2.size() * 4, hipMemcpyHostToDevice));
+      }
+      fill_random(b, rng, 0.02f);
+      for (int variant : {1, 2}) {
+        double ms = time_ms(3, [&] { X2V_OKAY(x2v_gemm_fp8_variant(xq.p, f.K, sx.p, wq.p, f.K, sw.p, b.p, y.p, f.N, f.M, f.N, f.K, X2V_EPI_NONE, nullptr, 0, nullptr, variant, nullptr)); });
+        const double tf = 2.0 * f.M * f.N * f.K / (ms * 1e-3) / 1e12;
+        printf("BENCH gemm_fp8 v=%d %-42s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 5000)\n", variant, f.name, ms, tf, tf / 50.0);
+      }
+    }
+  }
   struct A {
     const char* name;
     int64_t Sq, Sk;
