@@ -42,6 +42,9 @@ class WanScheduler(BaseScheduler):
         self.num_train_timesteps = 1000
         self.solver_order = 2
         self.disable_corrector = []
+        # per-step calc/skip records of the feature-caching infer classes (wan/scheduler.py:22, feature_caching/scheduler.py)
+        self.caching_records = [True] * config["infer_steps"]
+        self.caching_records_2 = [True] * config["infer_steps"]
 
     # ---- setup -----------------------------------------------------------------------------------
     def prepare(self, image_encoder_output=None, latents=None):

@@ -283,6 +283,69 @@ class WanTransformerInfer:
             return fn()
 
 
+
+class WanTransformerInferTeaCaching(WanTransformerInfer):
+    """reference: wan/infer/feature_caching/transformer_infer.py:9-171 — TeaCache around the fused block stack.
+    Per CFG branch the polynomial-rescaled relative L1 change of the modulation input (embed0 with `use_ret_steps`,
+    else embed; a [6, D] / [1, D] tensor — the comparison is host-side control flow exactly as in the reference,
+    one .item() per forward) is accumulated; below `teacache_thresh` the block stack is skipped and the previous
+    residual x_out - x_in of that branch is re-applied.  The two [S, D] elementwise passes (residual capture, re-apply)
+    run on the gate-residual kernel (gate = -1 / none)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.cnt = 0
+        self.teacache_thresh = config["teacache_thresh"]
+        self.use_ret_steps = config["use_ret_steps"]
+        self.coefficients = config["coefficients"][0 if self.use_ret_steps else 1]
+        self.ret_steps = 5 * 2 if self.use_ret_steps else 1 * 2
+        self.cutoff_steps = config["infer_steps"] * 2 if self.use_ret_steps else config["infer_steps"] * 2 - 2
+        self.accumulated_rel_l1_distance_even = self.accumulated_rel_l1_distance_odd = 0
+        self.previous_e0_even = self.previous_e0_odd = None
+        self.previous_residual_even = self.previous_residual_odd = None
+        self._minus_one = None
+
+    def calculate_should_calc(self, embed, embed0):
+        import numpy as np
+
+        inp = embed0 if self.use_ret_steps else embed
+        tag = "even" if self.infer_conditional else "odd"
+        if self.cnt < self.ret_steps or self.cnt >= self.cutoff_steps:
+            should_calc = True
+            setattr(self, f"accumulated_rel_l1_distance_{tag}", 0)
+        else:
+            prev = getattr(self, f"previous_e0_{tag}")
+            acc = getattr(self, f"accumulated_rel_l1_distance_{tag}") + np.poly1d(self.coefficients)(((inp - prev).abs().mean() / prev.abs().mean()).cpu().item())
+            should_calc = not (acc < self.teacache_thresh)
+            setattr(self, f"accumulated_rel_l1_distance_{tag}", 0 if should_calc else acc)
+        setattr(self, f"previous_e0_{tag}", inp.clone())
+        return should_calc
+
+    def infer(self, weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context, audio_dit_blocks=None):
+        index = self.scheduler.step_index
+        records = self.scheduler.caching_records if self.infer_conditional else self.scheduler.caching_records_2
+        if index <= self.scheduler.infer_steps - 1:
+            records[index] = self.calculate_should_calc(embed, embed0)
+        tag = "even" if self.infer_conditional else "odd"
+        if records[index]:
+            ori_x = x.clone()
+            x = super().infer(weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context)
+            if self._minus_one is None or self._minus_one.device != x.device:
+                self._minus_one = torch.full((x.shape[1],), -1.0, dtype=x.dtype, device=x.device)
+            res = x.clone()
+            lib.gate_residual_(res, ori_x, self._minus_one)  # res = x_out - x_in (bf16, as the reference's tensor subtraction)
+            setattr(self, f"previous_residual_{tag}", res)
+        else:
+            lib.gate_residual_(x, getattr(self, f"previous_residual_{tag}"))  # x.add_(previous_residual)
+        if _cfg(self.config, "enable_cfg", True):
+            self.switch_status()
+        self.cnt += 1
+        return x
+
+    def clear(self):
+        self.previous_residual_even = self.previous_residual_odd = None
+        self.previous_e0_even = self.previous_e0_odd = None
+
 class WanPostInfer:
     """reference: wan/infer/post_infer.py:6-50."""
 
@@ -333,9 +396,14 @@ class WanModel:
             ulysses.parallelize_wan(self)
 
     def _init_infer_class(self):
-        if _cfg(self.config, "feature_caching", "NoCaching") != "NoCaching":
-            raise NotImplementedError("feature caching is out of scope of the hot path (SURVEY.md §2.1 #20)")
-        self.pre_infer_class, self.post_infer_class, self.transformer_infer_class = WanPreInfer, WanPostInfer, WanTransformerInfer
+        fc = _cfg(self.config, "feature_caching", "NoCaching")  # reference: wan/model.py:61-75
+        if fc == "NoCaching":
+            tr_cls = WanTransformerInfer
+        elif fc == "Tea":
+            tr_cls = WanTransformerInferTeaCaching
+        else:
+            raise NotImplementedError(f"feature_caching={fc}: only 'NoCaching' and 'Tea' are built")
+        self.pre_infer_class, self.post_infer_class, self.transformer_infer_class = WanPreInfer, WanPostInfer, tr_cls
 
     def _init_weights(self, weight_dict):
         self.original_weight_dict = weight_dict

@@ -203,6 +203,54 @@ def gen_scheduler_only():
     print("scheduler.safetensors:", len(out), "tensors")
 
 
+TEA_COEFFS = [[-5.21862437e04, 9.23041404e03, -5.28275948e02, 1.36987616e01, -4.99875664e-02],
+              [2.39676752e03, -1.31110545e03, 2.01331979e02, -8.29855975e00, 1.37887774e-01]]  # configs/caching/teacache/wan_t2v_1_3b_tea_480p.json
+
+
+TEA_TEST_COEFFS = [[0, 0, 0, 1.0, 0], [0, 0, 0.5, 1.0, 0]]  # with random weights the released polynomials saturate (all-skip / all-calc);
+# these make the rescaled distance O(1) so that threshold 2.5 yields a mixed calc/skip pattern on the tiny model
+
+
+def gen_teacache(name="wan-tiny", workload="wan-tiny", steps=16, thresh=2.5):
+    """TeaCache fixture: the reference's WanTransformerInferTeaCaching (wan/infer/feature_caching/transformer_infer.py:9-171)
+    driving the 16-step CFG loop of the tiny model; records the per-step calc/skip decisions of both branches and the
+    latents after every step."""
+    ref_import.patch_and_import()
+    from lightx2v.models.networks.wan.infer.feature_caching.transformer_infer import WanTransformerInferTeaCaching
+    from lightx2v.models.schedulers.wan.scheduler import WanScheduler
+
+    dims = synth.WAN_DIMS[name]
+    wl = synth.WORKLOADS[workload]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    latents, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    for use_ret in (True, False):
+        cfg = ref_import.make_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=steps, feature_caching="Tea",
+                                     coefficients=TEA_TEST_COEFFS, use_ret_steps=use_ret, teacache_thresh=thresh)
+        R = ref_import.build_reference_wan(cfg, wd)
+        R["tr"] = WanTransformerInferTeaCaching(cfg)
+        sch = WanScheduler(cfg)
+        sch.device = torch.device("cpu")
+        sch.prepare()
+        sch.latents = latents.clone()
+        sch.caching_records = [True] * steps
+        for m in ("pre", "post", "tr"):
+            R[m].set_scheduler(sch)
+        inputs = {"text_encoder_output": {"context": ctx, "context_null": ctx_null}}
+        tag = "ret" if use_ret else "noret"
+        out = {} if use_ret else out  # noqa: F821
+        for i in range(steps):
+            sch.step_pre(i)
+            _ref_model_infer(R, sch, cfg, inputs)
+            sch.step_post()
+            out[f"{tag}_latents_after_step{i}"] = sch.latents.clone()
+        out[f"{tag}_records_cond"] = torch.tensor(sch.caching_records, dtype=torch.int32)
+        out[f"{tag}_records_uncond"] = torch.tensor(sch.caching_records_2, dtype=torch.int32)
+        print(tag, "cond", "".join("C" if c else "." for c in sch.caching_records), "uncond", "".join("C" if c else "." for c in sch.caching_records_2))
+    out.update(latents0=latents, thresh=torch.tensor([thresh]), steps=torch.tensor([steps]))
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "wan-tiny_teacache.safetensors"))
+    print("wan-tiny_teacache.safetensors:", len(out), "tensors")
+
+
 def gen_vae(dim=32, seed=1):
     """Wan VAE decode fixture: the reference's WanVAE_ (vae.py:640-738) at a reduced channel width (dim 32 →
     128/128/128/64/32 channels; same depth, same cache logic) decoding z [16,3,8,8] → [3,9,64,64] one latent frame
@@ -306,7 +354,7 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan"]
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache"]
     if "ops" in which:
         gen_ops()
     if "model" in which:
@@ -317,3 +365,5 @@ if __name__ == "__main__":
         gen_vae()
     if "hunyuan" in which:
         gen_hunyuan()
+    if "teacache" in which:
+        gen_teacache()

@@ -129,3 +129,36 @@ def test_operator_api_drop_in():
     assert mm.weight.device.type == "cpu"
     mm.to_cuda()
     assert mm.weight.is_cuda
+
+
+def test_teacache_matches_reference_decisions_and_latents():
+    """feature_caching="Tea" on the HIP path vs the fixture generated from the reference's TeaCache class: identical
+    calc/skip pattern in both CFG branches (the decision input is the tiny time-embedding tensor) and latents within
+    the denoise-loop tolerance after all 16 steps."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import scheduler, synth, wan
+    from lightx2v_amd.scheduler import run_denoise_loop
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wan-tiny_teacache.safetensors"))
+    coeffs = [[0, 0, 0, 1.0, 0], [0, 0, 0.5, 1.0, 0]]  # oracle/gen_golden.py::TEA_TEST_COEFFS
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wl = synth.WORKLOADS["wan-tiny"]
+    wd = _to_dev(synth.synth_wan_weights(dims, seed=0))
+    _, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    steps = int(g["steps"])
+    for tag, use_ret in (("ret", True), ("noret", False)):
+        cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=steps, hip_ref_rounding=True,
+                                 feature_caching="Tea", coefficients=coeffs, use_ret_steps=use_ret, teacache_thresh=float(g["thresh"]))
+        model = wan.WanModel(cfg, wd)
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=g["latents0"])
+        model.set_scheduler(sch)
+        errs = []
+        run_denoise_loop(model, sch, inputs, step_callback=lambda i: errs.append(rel_l2(sch.latents, g[f"{tag}_latents_after_step{i}"])))
+        assert [int(c) for c in sch.caching_records] == g[f"{tag}_records_cond"].tolist(), tag
+        assert [int(c) for c in sch.caching_records_2] == g[f"{tag}_records_uncond"].tolist(), tag
+        assert max(errs) <= 5e-2, (tag, errs)

@@ -147,3 +147,30 @@ def test_hunyuan_oracle_bit_exact():
 
     c2, s2 = hy.rope_tables([ts[2], ts[3] // 2, ts[4] // 2])
     assert torch.equal(c2, fc) and torch.equal(s2, fs)
+
+
+def test_teacache_oracle_bit_exact():
+    """TeaCacheOracle + the oracle denoise loop reproduce the reference's WanTransformerInferTeaCaching run: same
+    calc/skip decisions in both CFG branches and bit-identical latents after every step, both `use_ret_steps` modes."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import synth
+    from oracle import wan_oracle as O
+    from oracle.gen_golden import TEA_TEST_COEFFS
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wan-tiny_teacache.safetensors"))
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    _, ctx, ctx_null = synth.synth_inputs(dims, synth.WORKLOADS["wan-tiny"]["target_shape"])
+    steps, thresh = int(g["steps"]), float(g["thresh"])
+    for tag, use_ret in (("ret", True), ("noret", False)):
+        tea = O.TeaCacheOracle(steps, thresh, TEA_TEST_COEFFS, use_ret)
+        bad = []
+        O.denoise_loop(wd, dims, g["latents0"], ctx, ctx_null, steps, 8.0, 6.0, True, tea,
+                       step_callback=lambda i, lat: bad.append(i) if not torch.equal(lat, g[f"{tag}_latents_after_step{i}"]) else None)
+        assert [int(c) for c in tea.records[True]] == g[f"{tag}_records_cond"].tolist()
+        assert [int(c) for c in tea.records[False]] == g[f"{tag}_records_uncond"].tolist()
+        assert not bad, (tag, bad)
+        assert 0 < sum(tea.records[True]) < steps  # the fixture exercises both paths
