@@ -183,6 +183,8 @@ class HunyuanTransformerInfer:
             raise NotImplementedError("i2v token-replace modulation (transformer_infer.py:95-100) is not built")
         n_img, n_txt = img.shape[0], txt.shape[0]
         self._segs = _segments(cu_seqlens_qkv)  # one host read per forward (the reference's flash call reads them per block)
+        cu = cu_seqlens_qkv.tolist() if torch.is_tensor(cu_seqlens_qkv) else list(cu_seqlens_qkv)
+        self._sp_lens = (n_img, cu[1] - n_img, n_txt)  # image tokens on this rank, valid text tokens, text tokens
         x = torch.empty((n_img + n_txt, self.hidden_size), dtype=BF16, device=img.device)
         x[:n_img].copy_(img)
         x[n_img:].copy_(txt)
@@ -202,6 +204,9 @@ class HunyuanTransformerInfer:
 
     def _attention(self, q, k, v, out):
         variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if self._qs != 1.0 else 0
+        if self.parallel_attention is not None:  # Ulysses (reference hook: transformer_infer.py:130-144,358-369)
+            n_img, n_valid, n_txt = self._sp_lens
+            return self.parallel_attention(q, k, v, n_img, (n_valid, n_txt), self.heads_num, out, variant=variant)
         for a, b in self._segs:
             lib.attention(q[a:b], k[a:b], v[a:b], self.heads_num, 128, out=out[a:b], variant=variant)
 

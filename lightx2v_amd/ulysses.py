@@ -107,3 +107,89 @@ def parallelize_wan(wan_model, group=None, attn_fn=None):
 
     tr.infer = new_infer
     return wan_model
+
+
+# ------------------------------------------------------------------------------------------------ HunyuanVideo
+def hunyuan_pre_process(latents, freqs_cos, freqs_sin, group=None):
+    """reference: attentions/distributed/utils/hunyuan/processor.py:5-50 — split the latent grid along H (or W) and the
+    RoPE tables the same way; text stays replicated.  Returns (latents, cos, sin, split_dim)."""
+    n, r = _world(group)
+    t, h, w = latents.shape[2], latents.shape[3] // 2, latents.shape[4] // 2
+    if h % n == 0:
+        split_dim = -2
+    elif w % n == 0:
+        split_dim = -1
+    else:
+        raise ValueError(f"Cannot split video sequence into world size ({n}) parts evenly")
+    lat = torch.chunk(latents, n, dim=split_dim)[r].contiguous()
+    d = freqs_cos.shape[-1]
+    cos = torch.chunk(freqs_cos.reshape(t, h, w, d), n, dim=split_dim - 1)[r].reshape(-1, d).contiguous()
+    sin = torch.chunk(freqs_sin.reshape(t, h, w, d), n, dim=split_dim - 1)[r].reshape(-1, d).contiguous()
+    return lat, cos, sin, split_dim
+
+
+def hunyuan_post_process(output, split_dim, group=None):
+    """reference: processor.py:53-77 — all_gather the per-rank noise predictions and concatenate along the split axis."""
+    n, _ = _world(group)
+    out = torch.empty((n * output.shape[0], *output.shape[1:]), dtype=output.dtype, device=output.device)  # dim-0 concatenation
+    dist.all_gather_into_tensor(out, output.contiguous(), group=group)
+    return torch.cat(list(out.chunk(n, dim=0)), dim=split_dim)
+
+
+class UlyssesHunyuanAttention:
+    """reference: attentions/distributed/ulysses/attn.py:7-91 for the joint img+txt attention: image q/k/v go seq→head by
+    all-to-all, the (replicated) text q/k/v contribute this rank's heads, one attention over [all image tokens ; text]
+    with H/N heads, image output head→seq by all-to-all, text output all-gathered over heads.  No host synchronisation
+    (the reference calls torch.cuda.synchronize() twice per attention, attn.py:48,85); receive buffers are row ranges of
+    the joint attention operands, so there is no torch.cat."""
+
+    def __init__(self, group=None, attn_fn=None):
+        self.group = group
+        self.attn_fn = attn_fn
+
+    def __call__(self, q, k, v, n_img, segs_txt, num_heads, out, variant=0):
+        """q, k, v: [n_img_local + n_txt, H*128] views; out: same rows, H*128 columns.  segs_txt = (n_valid_txt, n_txt)."""
+        n, r = _world(self.group)
+        if num_heads % n != 0:
+            raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
+        hd = q.shape[1]
+        hdn = hd // n
+        n_txt = q.shape[0] - n_img
+        tot = n * n_img
+        joint = [torch.empty((tot + n_txt, hdn), dtype=q.dtype, device=q.device) for _ in range(3)]
+        for src, dst in zip((q, k, v), joint):
+            send = src[:n_img].reshape(n_img, n, hdn).transpose(0, 1).contiguous()  # [N, n_img, hd/N]
+            dist.all_to_all_single(dst[:tot].view(n, n_img, hdn), send, group=self.group)
+            dst[tot:].copy_(src[n_img:, r * hdn : (r + 1) * hdn])
+        o = torch.empty((tot + n_txt, hdn), dtype=q.dtype, device=q.device)
+        n_valid = segs_txt[0]
+        fn = self.attn_fn or (lambda a, b, c, h, oo: lib.attention(a, b, c, h, 128, out=oo, variant=variant))
+        fn(joint[0][: tot + n_valid], joint[1][: tot + n_valid], joint[2][: tot + n_valid], num_heads // n, o[: tot + n_valid])
+        if n_valid < n_txt:
+            fn(joint[0][tot + n_valid :], joint[1][tot + n_valid :], joint[2][tot + n_valid :], num_heads // n, o[tot + n_valid :])
+        # image rows: head→seq; the send buffer [N, n_img, hd/N] is o's image part as it is
+        recv = torch.empty((n, n_img, hdn), dtype=q.dtype, device=q.device)
+        dist.all_to_all_single(recv, o[:tot].view(n, n_img, hdn), group=self.group)
+        out[:n_img].view(n_img, n, hdn).copy_(recv.transpose(0, 1))
+        # text rows: every rank holds all text tokens for its heads → gather the head blocks
+        gathered = torch.empty((n * n_txt, hdn), dtype=q.dtype, device=q.device)
+        dist.all_gather_into_tensor(gathered, o[tot:].contiguous(), group=self.group)
+        out[n_img:].view(n_txt, n, hdn).copy_(gathered.view(n, n_txt, hdn).transpose(0, 1))
+        return out
+
+
+def parallelize_hunyuan(hunyuan_model, group=None, attn_fn=None):
+    """reference: ulysses/wrap.py:5-50 — shard latents + RoPE tables around HunyuanModel.infer, swap the attention."""
+    hunyuan_model.transformer_infer.parallel_attention = UlyssesHunyuanAttention(group, attn_fn)
+    original_infer = hunyuan_model.infer
+
+    def new_infer(inputs):
+        sch = hunyuan_model.scheduler
+        keep = (sch.latents, sch.freqs_cos, sch.freqs_sin)
+        sch.latents, sch.freqs_cos, sch.freqs_sin, split_dim = hunyuan_pre_process(*keep, group=group)
+        original_infer(inputs)
+        sch.noise_pred = hunyuan_post_process(sch.noise_pred, split_dim, group)
+        sch.latents, sch.freqs_cos, sch.freqs_sin = keep
+
+    hunyuan_model.infer = new_infer
+    return hunyuan_model
