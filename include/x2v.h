@@ -185,6 +185,38 @@ int x2v_vae_prep_f32(const float* x, float* y, int T, int Hh, int Ww, int C, con
  * AttentionBlock (vae.py:249-253).  N % 4 == 0. */
 int x2v_softmax_rows_f32(float* s, int64_t ld, int64_t M, int N, float scale, void* stream);
 
+/* ---- HunyuanVideo VAE decode (video_encoders/hf/autoencoder_kl_causal_3d/), fp32, channels-last ------------------- */
+
+/* Pixel-wise producer: v = x*mul[c] + add[c] (mul/add optional; GroupNorm applied as a per-channel affine), optional SiLU
+ * and clamp to [0,1]; nearest x2 upsampling in H,W (up_hw) and/or in T where frame 0 is not duplicated (up_t) — replaces
+ * GroupNorm+SiLU in ResnetBlockCausal3D (unet_causal_3d_blocks.py:377-410), UpsampleCausal3D.forward (:168-187) and the
+ * final (x/2+0.5).clamp(0,1) of VideoEncoderKLCausal3DModel.decode (model.py:41).  Output addressing as x2v_vae_prep_f32. */
+int x2v_vae_prep_ex_f32(const float* x, float* y, int T, int Hh, int Ww, int C, const float* mul, const float* add, int silu, int clamp01, int up_hw, int up_t,
+                        int64_t y_frame_stride, int64_t y_row_stride, void* stream);
+
+/* Fill the borders of a conv input buffer [frames][Hp][Wp][C] by replication: spatial borders (width `pad`) from the
+ * nearest interior pixel, the `lead` leading frames from frame `lead` — F.pad(mode="replicate") of CausalConv3d
+ * (unet_causal_3d_blocks.py:84-91). */
+int x2v_vae_replicate_border_f32(float* buf, int frames, int lead, int Hp, int Wp, int C, int pad, void* stream);
+
+/* GroupNorm over x [npix, C] (G groups of consecutive channels, statistics over all pixels) reduced to a per-channel
+ * affine: mul[c] = rstd_g*gamma[c], add[c] = beta[c] - mean_g*mul[c] (apply with x2v_vae_prep_ex_f32) — replaces
+ * torch.nn.GroupNorm (unet_causal_3d_blocks.py:318,341; vae.py conv_norm_out; the attention block's group_norm).
+ * workspace: 2*G doubles (device).  fp64 accumulation. */
+int x2v_groupnorm_affine_f32(const float* x, int64_t npix, int C, int G, const float* gamma, const float* beta, float eps, double* workspace, float* mul,
+                             float* add, void* stream);
+
+/* In-place s[M,N] = softmax(scale*s) over the frame-causal prefix: row i sees keys j < min(n_keys, (i/hw + 1)*hw), the
+ * rest (incl. padding columns n_keys..N) becomes 0 (prepare_causal_attention_mask, unet_causal_3d_blocks.py:48-63, in
+ * UNetMidBlockCausal3D.forward :629-634). */
+int x2v_softmax_rows_causal_f32(float* s, int64_t ld, int64_t M, int N, float scale, int hw, int n_keys, void* stream);
+
+/* Linear cross-fade of overlapping tiles along one axis, tensors viewed as [outer][axis][inner]:
+ * b[idx] = a[na-extent+idx]*(1-idx/extent) + b[idx]*(idx/extent), idx < extent — blend_v / blend_h / blend_t
+ * (autoencoder_kl_causal_3d.py:347-364). */
+int x2v_blend_axis_f32(const float* a, float* b, int64_t outer, int na, int nb, int64_t inner, int64_t a_outer_stride, int64_t b_outer_stride, int extent,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -763,7 +763,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v3_kernel(const unsigned 
 // v4 = v3's numerics (scale folded into Q, running max as the chain's C operand) with a tile body in which the last
 // link of each S(t+1) chain writes into the buffer S(t) has just vacated (no score copy, no unroll), all softmax VALU
 // in phase 1 with row sums in four partial chains, tree-shaped row maxima, and fragment reads two slots ahead.
-template <int NW, int RESCALE_THR, bool PRESCALED>
+template <int NW, int RESCALE_THR, bool PRESCALED, int EXPERIMENT = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
                                                                    const unsigned short* __restrict__ Vp, int64_t ldv, unsigned short* __restrict__ O,
@@ -897,8 +897,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned 
   //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T from the packed P; no VALU (sn is dead: registers are free for
   //                           the deeper fragment prefetch).
 #define AT_SB() __builtin_amdgcn_sched_barrier(0)
-#define A4_KFRAG(I_) (*reinterpret_cast<const bf16x8_t*>(kb_ + ((I_) & 1) * 8192 + kaddr[(I_) >> 1]))
-#define A4_VFRAG(J_) tr_frag(vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32, vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32 + 8 * 32)
+#define A4_KFRAG(I_) (EXPERIMENT == 6 ? qf[(I_) & 7] : *reinterpret_cast<const bf16x8_t*>(kb_ + ((I_) & 1) * 8192 + kaddr[(I_) >> 1]))
+#define A4_VFRAG(J_) (EXPERIMENT == 6) ? qf[(J_) & 7] : tr_frag(vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32, vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32 + 8 * 32)
 #define A4_TILE(LAST_, KN_, VB_)                                                                               \
   {                                                                                                            \
     if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
@@ -917,13 +917,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned 
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
       const int ks = i >> 1, u = i & 1;                                                                        \
       if (!(LAST_)) {                                                                                          \
-        if (i < 14) sn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], ks == 0 ? negm : sn[u], 0, 0, 0); \
+        if (EXPERIMENT == 4) { asm volatile("" :: "v"(kfa), "v"(kfb)); }                                       \
+        else if (i < 14) sn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], ks == 0 ? negm : sn[u], 0, 0, 0); \
         else sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], sn[u], 0, 0, 0);           \
         if (i + 2 < 16) {                                                                                      \
           if (u) kfb = A4_KFRAG(i + 2); else kfa = A4_KFRAG(i + 2);                                            \
         }                                                                                                      \
       }                                                                                                        \
-      if (i < 4) { /* row max of 8 scores as a depth-2 tree */                                                 \
+      if (EXPERIMENT == 5) { if (i == 5) { _Pragma("unroll") for (int e = 0; e < 16; ++e) pw[e] = __float_as_uint(sc[e >> 3][e & 7]); } } \
+      else if (i < 4) { /* row max of 8 scores as a depth-2 tree */                                            \
         const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
         const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                    \
         const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                \
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned 
         const int uu = (i - 5) / 5, q_ = (i - 5) % 5;                                                          \
         const int e0 = q_ == 0 ? 0 : 1 + 3 * q_, e1 = 4 + 3 * q_;                                              \
         _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
-          const float p_ = __builtin_amdgcn_exp2f(sc[uu][e]);                                                  \
+          const float p_ = EXPERIMENT == 2 ? sc[uu][e] : __builtin_amdgcn_exp2f(sc[uu][e]); /* 2: timing probe */  \
           sc[uu][e] = p_;                                                                                      \
           lsum[e & 3] += p_;                                                                                   \
           if (e & 1) pw[uu * 8 + (e >> 1)] = pack_bf2(sc[uu][e - 1], p_);                                      \
@@ -969,7 +971,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned 
     _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
       const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
       i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
-      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((j & 1) ? vfb : vfa, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      if (EXPERIMENT != 3) oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((j & 1) ? vfb : vfa, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      else { asm volatile("" :: "v"(vfa), "v"(vfb), "v"(pq)); }                                               \
       if (j + 2 < 16) {                                                                                        \
         if (j & 1) vfb = A4_VFRAG(j + 2); else vfa = A4_VFRAG(j + 2);                                          \
       }                                                                                                        \
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned 
     A4_TILE(false, (t + 1) & 1, t & 1)
     AT_WRITE_V((t + 1) & 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (EXPERIMENT != 1) __syncthreads();  // EXPERIMENT 1: timing-only probe of the barrier cost (results invalid)
   }
   A4_TILE(true, (t + 1) & 1, t & 1)
 #undef A4_TILE
@@ -1084,7 +1087,7 @@ static int launch_attn_v3(const void* q, int64_t ldq, const void* k, int64_t ldk
   return X2V_OK;
 }
 
-template <int NW, int THR, bool PRESCALED>
+template <int NW, int THR, bool PRESCALED, int EXPERIMENT = 0>
 static int launch_attn_v4(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                             int64_t Sk, int H, float scale, hipStream_t st) {
   // buffer descriptors address 32 bits: the per-head K/V views must stay below 4 GiB
@@ -1093,13 +1096,13 @@ static int launch_attn_v4(const void* q, int64_t ldq, const void* k, int64_t ldk
               "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
   static bool attr_set = false;
   if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_v4_kernel<NW, THR, PRESCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
+    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_v4_kernel<NW, THR, PRESCALED, EXPERIMENT>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
     if (rc != X2V_OK) return rc;
     attr_set = true;
   }
   const int QB = NW * 32;
   dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
-  hipLaunchKernelGGL((attn_fwd_v4_kernel<NW, THR, PRESCALED>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
+  hipLaunchKernelGGL((attn_fwd_v4_kernel<NW, THR, PRESCALED, EXPERIMENT>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
                      (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
   X2V_LAUNCH_CHECK("attn launch");
   return X2V_OK;
@@ -1133,6 +1136,12 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(
     case 10: return launch_attn_v4<8, 8, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 9 | X2V_ATTN_Q_PRESCALED: return launch_attn_v3<8, 8, true, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 10 | X2V_ATTN_Q_PRESCALED: return launch_attn_v4<8, 8, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 101: return launch_attn_v4<8, 8, false, 1>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);  // timing probes, results invalid
+    case 102: return launch_attn_v4<8, 8, false, 2>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 104: return launch_attn_v4<8, 8, false, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 105: return launch_attn_v4<8, 8, false, 5>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 106: return launch_attn_v4<8, 8, false, 6>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
+    case 103: return launch_attn_v4<8, 8, false, 3>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     default: set_error("attn: unknown variant %d", variant); return X2V_E_ARG;
   }
 }

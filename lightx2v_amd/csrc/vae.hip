@@ -294,6 +294,161 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// HunyuanVideo VAE (AutoencoderKLCausal3D) helpers — reference: video_encoders/hf/autoencoder_kl_causal_3d/
+// unet_causal_3d_blocks.py (CausalConv3d replicate padding :65-91, UpsampleCausal3D :94-197, ResnetBlockCausal3D
+// :261-420, UNetMidBlockCausal3D :526-640) and autoencoder_kl_causal_3d.py (tiled decode + blends :347-518).
+
+// General pixel-wise producer (superset of vae_prep_kernel's affine path): v = x*mul[c] + add[c] (GroupNorm applied as a
+// per-channel affine), optional SiLU, optional clamp to [0,1], nearest upsampling x2 in H,W and/or in T where the FIRST
+// frame is not duplicated (UpsampleCausal3D.forward :168-187: frame 0 -> 0, frame t>=1 -> 2t-1 and 2t).
+template <int LPP>
+__global__ __launch_bounds__(256) void vae_prep_ex_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
+                                                          const float* __restrict__ mul, const float* __restrict__ add, int silu, int clamp01, int up_hw,
+                                                          int up_t, int64_t y_frame_stride, int64_t y_row_stride) {
+  constexpr int GPB = 256 / LPP;
+  const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+  const int nch = C / 4;
+  for (int64_t pix = (int64_t)blockIdx.x * GPB + g; pix < npix; pix += (int64_t)gridDim.x * GPB) {
+    const int64_t t = pix / ((int64_t)Hh * Ww);
+    const int rem = (int)(pix - t * (int64_t)Hh * Ww);
+    const int h = rem / Ww, wq = rem - h * Ww;
+    const int64_t t0 = up_t ? (t == 0 ? 0 : 2 * t - 1) : t;
+    const int nt = (up_t && t > 0) ? 2 : 1;
+    for (int c4 = l; c4 < nch; c4 += LPP) {
+      const float4 v = *reinterpret_cast<const float4*>(x + pix * C + c4 * 4);
+      float o[4] = {v.x, v.y, v.z, v.w};
+      if (mul != nullptr) {
+        const float4 m = *reinterpret_cast<const float4*>(mul + c4 * 4);
+        o[0] *= m.x; o[1] *= m.y; o[2] *= m.z; o[3] *= m.w;
+      }
+      if (add != nullptr) {
+        const float4 a = *reinterpret_cast<const float4*>(add + c4 * 4);
+        o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (silu) o[e] = o[e] / (1.f + __expf(-o[e]));
+        if (clamp01) o[e] = fminf(fmaxf(o[e], 0.f), 1.f);
+      }
+      const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+      for (int dt = 0; dt < nt; ++dt) {
+        float* yb = y + (t0 + dt) * y_frame_stride + (int64_t)(up_hw ? 2 * h : h) * y_row_stride + (int64_t)(up_hw ? 2 * wq : wq) * C + c4 * 4;
+        *reinterpret_cast<float4*>(yb) = ov;
+        if (up_hw) {
+          *reinterpret_cast<float4*>(yb + C) = ov;
+          *reinterpret_cast<float4*>(yb + y_row_stride) = ov;
+          *reinterpret_cast<float4*>(yb + y_row_stride + C) = ov;
+        }
+      }
+    }
+  }
+}
+
+// Replicate padding of a conv input buffer [lead + T][H + 2p][W + 2p][C]: spatial borders copy the nearest interior pixel,
+// the `lead` leading frames copy frame `lead` (F.pad(..., mode="replicate") with (p, p, p, p, kt-1, 0), :84-91).
+__global__ __launch_bounds__(256) void vae_replicate_border_kernel(float* __restrict__ buf, int frames, int lead, int Hp, int Wp, int C, int pad) {
+  const int nch = C / 4;
+  const int64_t total = (int64_t)frames * Hp * Wp * nch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % nch);
+    int64_t r = i / nch;
+    const int w = (int)(r % Wp);
+    r /= Wp;
+    const int h = (int)(r % Hp);
+    const int f = (int)(r / Hp);
+    const int hs = min(max(h, pad), Hp - 1 - pad), ws = min(max(w, pad), Wp - 1 - pad), fs = max(f, lead);
+    if (hs == h && ws == w && fs == f) continue;  // interior pixel of a real frame
+    const float4 v = *reinterpret_cast<const float4*>(buf + (((int64_t)fs * Hp + hs) * Wp + ws) * C + c4 * 4);
+    *reinterpret_cast<float4*>(buf + (((int64_t)f * Hp + h) * Wp + w) * C + c4 * 4) = v;
+  }
+}
+
+// GroupNorm statistics over a channels-last tensor [npix][C] with G groups of C/G consecutive channels: per-group
+// sum and sum of squares accumulated in fp64 (block partials in LDS, one fp64 atomicAdd pair per group per block).
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float* __restrict__ x, int64_t npix, int C, int G, double* __restrict__ acc) {
+  __shared__ double part[2 * 64];
+  if (threadIdx.x < 2 * G) part[threadIdx.x] = 0.0;
+  __syncthreads();
+  const int nch = C / 4, cpg = C / G;
+  const int64_t total = npix * nch;
+  // a thread keeps its channel chunk fixed across iterations when the stride is a multiple of nch; accumulate locally per visited group
+  double s = 0.0, q = 0.0;
+  int cur = -1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % nch);
+    const int grp = (c4 * 4) / cpg;
+    if (grp != cur) {
+      if (cur >= 0) {
+        atomicAdd(&part[2 * cur], s);
+        atomicAdd(&part[2 * cur + 1], q);
+      }
+      cur = grp;
+      s = q = 0.0;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (cur >= 0) {
+    atomicAdd(&part[2 * cur], s);
+    atomicAdd(&part[2 * cur + 1], q);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * G) atomicAdd(&acc[threadIdx.x], part[threadIdx.x]);
+}
+
+// per-channel affine of GroupNorm from the accumulated sums: mul[c] = rstd_g * gamma[c], add[c] = beta[c] - mean_g * mul[c]
+__global__ void groupnorm_finalize_kernel(const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mul,
+                                          float* __restrict__ add, int C, int G, double count, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int g = c / (C / G);
+  const double mean = acc[2 * g] / count;
+  const double var = fmax(acc[2 * g + 1] / count - mean * mean, 0.0);
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float m = rstd * gamma[c];
+  mul[c] = m;
+  add[c] = beta[c] - (float)mean * m;
+}
+
+// In-place row softmax with a frame-causal prefix mask (prepare_causal_attention_mask :48-63): row i (frame i / hw) sees keys
+// j < (i/hw + 1) * hw; masked entries become 0.
+__global__ __launch_bounds__(256) void softmax_rows_causal_kernel(float* __restrict__ s, int64_t lds_, int N, float scale, int hw, int n_keys) {
+  __shared__ float red[4];
+  float* row = s + (int64_t)blockIdx.x * lds_;
+  const int valid = min(n_keys, (int)((blockIdx.x / hw + 1) * hw));  // n_keys <= N: columns past it are padding
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x; i < valid; i += 256) mx = fmaxf(mx, row[i]);
+  mx = block_max<4>(mx, red) * scale;
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < valid; i += 256) {
+    const float e = __expf(row[i] * scale - mx);
+    row[i] = e;
+    sum += e;
+  }
+  sum = block_sum<4>(sum, red);
+  const float inv = 1.f / sum;
+  for (int i = threadIdx.x; i < N; i += 256) row[i] = i < valid ? row[i] * inv : 0.f;
+}
+
+// Linear cross-fade of two overlapping tiles along one axis (blend_v / blend_h / blend_t :347-364):
+// b[idx] = a[na - extent + idx] * (1 - idx/extent) + b[idx] * (idx/extent) for idx < extent along the axis.
+// Both tensors are addressed as [outer][axis][inner] with their own axis lengths; outer/inner extents are common.
+__global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict__ a, float* __restrict__ b, int64_t outer, int na, int nb, int64_t inner,
+                                                         int64_t a_outer_stride, int64_t b_outer_stride, int extent) {
+  const int64_t total = outer * extent * inner;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t in = i % inner;
+    const int idx = (int)((i / inner) % extent);
+    const int64_t o = i / (inner * extent);
+    const float wb = (float)idx / (float)extent;
+    const float av = a[o * a_outer_stride + (int64_t)(na - extent + idx) * inner + in];
+    float* bp = b + o * b_outer_stride + (int64_t)idx * inner + in;
+    *bp = av * (1.f - wb) + *bp * wb;
+  }
+}
+
 }  // namespace x2v
 
 using namespace x2v;
@@ -373,5 +528,72 @@ extern "C" __attribute__((visibility("default"))) int x2v_softmax_rows_f32(float
   X2V_REQUIRE(aligned16(s), X2V_E_ALIGN, "softmax_rows: 16-byte alignment");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, s, ld, M, N, scale);
   X2V_LAUNCH_CHECK("softmax_rows launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_ex_f32(const float* x, float* y, int T, int Hh, int Ww, int C, const float* mul, const float* add, int silu,
+                                                                          int clamp01, int up_hw, int up_t, int64_t y_frame_stride, int64_t y_row_stride,
+                                                                          void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "vae_prep_ex: null pointer");
+  X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 4 == 0, X2V_E_SHAPE, "vae_prep_ex: bad shape (C %% 4 == 0)");
+  X2V_REQUIRE(y_frame_stride % 4 == 0 && y_row_stride % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(mul) && aligned16(add), X2V_E_ALIGN,
+              "vae_prep_ex: 16-byte alignment");
+  const int64_t npix = (int64_t)T * Hh * Ww;
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 128) {
+    const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_ex_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, mul, add, silu, clamp01, up_hw, up_t, y_frame_stride, y_row_stride);
+  } else {
+    const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_ex_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, mul, add, silu, clamp01, up_hw, up_t, y_frame_stride, y_row_stride);
+  }
+  X2V_LAUNCH_CHECK("vae_prep_ex launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_replicate_border_f32(float* buf, int frames, int lead, int Hp, int Wp, int C, int pad, void* stream) {
+  X2V_REQUIRE(buf, X2V_E_ARG, "vae_replicate_border: null pointer");
+  X2V_REQUIRE(frames > lead && lead >= 0 && pad >= 0 && Hp > 2 * pad && Wp > 2 * pad && C > 0 && C % 4 == 0, X2V_E_SHAPE, "vae_replicate_border: bad shape");
+  X2V_REQUIRE(aligned16(buf), X2V_E_ALIGN, "vae_replicate_border: 16-byte alignment");
+  const int64_t total = (int64_t)frames * Hp * Wp * (C / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536 * 4);
+  hipLaunchKernelGGL(vae_replicate_border_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, buf, frames, lead, Hp, Wp, C, pad);
+  X2V_LAUNCH_CHECK("vae_replicate_border launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_groupnorm_affine_f32(const float* x, int64_t npix, int C, int G, const float* gamma, const float* beta, float eps,
+                                                                               double* workspace, float* mul, float* add, void* stream) {
+  X2V_REQUIRE(x && gamma && beta && workspace && mul && add, X2V_E_ARG, "groupnorm_affine: null pointer");
+  X2V_REQUIRE(npix > 0 && C > 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0, X2V_E_SHAPE, "groupnorm_affine: C=%d G=%d (C/G %% 4 == 0, G <= 64)", C, G);
+  X2V_REQUIRE(aligned16(x), X2V_E_ALIGN, "groupnorm_affine: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = check_hip(hipMemsetAsync(workspace, 0, sizeof(double) * 2 * G, st), "groupnorm memset");
+  if (rc != X2V_OK) return rc;
+  const int64_t total = npix * (C / 4);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(grid), dim3(256), 0, st, x, npix, C, G, workspace);
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, gamma, beta, mul, add, C, G, (double)npix * (C / G), eps);
+  X2V_LAUNCH_CHECK("groupnorm_affine launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_softmax_rows_causal_f32(float* s, int64_t ld, int64_t M, int N, float scale, int hw, int n_keys, void* stream) {
+  X2V_REQUIRE(s, X2V_E_ARG, "softmax_rows_causal: null pointer");
+  X2V_REQUIRE(M > 0 && N > 0 && hw > 0 && ld >= N && n_keys > 0 && n_keys <= N && M < (1ll << 31), X2V_E_SHAPE, "softmax_rows_causal: bad shape");
+  hipLaunchKernelGGL(softmax_rows_causal_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, s, ld, N, scale, hw, n_keys);
+  X2V_LAUNCH_CHECK("softmax_rows_causal launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_blend_axis_f32(const float* a, float* b, int64_t outer, int na, int nb, int64_t inner, int64_t a_outer_stride,
+                                                                         int64_t b_outer_stride, int extent, void* stream) {
+  X2V_REQUIRE(a && b, X2V_E_ARG, "blend_axis: null pointer");
+  X2V_REQUIRE(outer > 0 && inner > 0 && extent >= 0 && extent <= na && extent <= nb, X2V_E_SHAPE, "blend_axis: bad shape");
+  if (extent == 0) return X2V_OK;
+  const int64_t total = outer * extent * inner;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536 * 4);
+  hipLaunchKernelGGL(blend_axis_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, outer, na, nb, inner, a_outer_stride, b_outer_stride, extent);
+  X2V_LAUNCH_CHECK("blend_axis launch");
   return X2V_OK;
 }

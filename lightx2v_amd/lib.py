@@ -45,6 +45,11 @@ PROTOTYPES = {
     "x2v_vae_conv_f32": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "x2v_vae_prep_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_softmax_rows_f32": [_c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
+    "x2v_vae_prep_ex_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i64, _i64, _c_void_p],
+    "x2v_vae_replicate_border_f32": [_c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+    "x2v_groupnorm_affine_f32": [_c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p, _f32, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "x2v_softmax_rows_causal_f32": [_c_void_p, _i64, _i64, _i32, _f32, _i32, _i32, _c_void_p],
+    "x2v_blend_axis_f32": [_c_void_p, _c_void_p, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _c_void_p],
 }
 _RESTYPES = {"x2v_last_error": ctypes.c_char_p, "x2v_version": ctypes.c_char_p}
 
@@ -322,3 +327,50 @@ def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mo
     init()
     _check(_lib.x2v_headnorm_rope_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, q_out_scale, _stream()),
            "headnorm_rope")
+
+
+def vae_prep_ex(x, y_view, y_strides, mul=None, add=None, silu=False, clamp01=False, up_hw=False, up_t=False):
+    T, H, W, C = x.shape
+    init()
+    _check(_lib.x2v_vae_prep_ex_f32(_p(x), _p(y_view), T, H, W, C, _p(mul), _p(add), int(silu), int(clamp01), int(up_hw), int(up_t), y_strides[0], y_strides[1], _stream()),
+           "vae_prep_ex")
+
+
+def vae_replicate_border_(buf, lead, pad):
+    frames, hp, wp, c = buf.shape
+    init()
+    _check(_lib.x2v_vae_replicate_border_f32(_p(buf), frames, lead, hp, wp, c, pad, _stream()), "vae_replicate_border")
+
+
+def groupnorm_affine(x, groups, gamma, beta, eps=1e-6):
+    """x [..., C] contiguous fp32 → (mul[C], add[C]) such that GroupNorm(x)[..., c] = x[..., c]*mul[c] + add[c]."""
+    c = x.shape[-1]
+    npix = x.numel() // c
+    ws = torch.empty(2 * groups, dtype=torch.float64, device=x.device)
+    mul, add = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+    init()
+    _check(_lib.x2v_groupnorm_affine_f32(_p(x), npix, c, groups, _p(gamma), _p(beta), eps, _p(ws), _p(mul), _p(add), _stream()), "groupnorm_affine")
+    return mul, add
+
+
+def softmax_rows_causal_(s, scale, hw, n_keys=None):
+    M, N = s.shape
+    init()
+    _check(_lib.x2v_softmax_rows_causal_f32(_p(s), s.stride(0), M, N, float(scale), hw, N if n_keys is None else n_keys, _stream()), "softmax_rows_causal")
+    return s
+
+
+def blend_axis_(a, b, axis, extent):
+    """b[.., idx, ..] = a[.., na-extent+idx, ..]*(1-idx/extent) + b*(idx/extent) along `axis` of two contiguous fp32 tensors
+    that agree in every other dimension."""
+    axis = axis % a.dim()
+    outer = 1
+    for d in a.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in a.shape[axis + 1 :]:
+        inner *= d
+    na, nb = a.shape[axis], b.shape[axis]
+    init()
+    _check(_lib.x2v_blend_axis_f32(_p(a), _p(b), outer, na, nb, inner, na * inner, nb * inner, min(extent, na, nb), _stream()), "blend_axis")
+    return b

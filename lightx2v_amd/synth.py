@@ -245,3 +245,66 @@ def synth_hunyuan_inputs(dims, target_shape, seed=42, valid_text=None):
     mask[:, : (L if valid_text is None else valid_text)] = 1
     text_states_2 = torch.randn(1, dims["text_dim_2"], generator=g).to(torch.bfloat16)
     return latents, text_states, mask, text_states_2
+
+
+# HunyuanVideo VAE (AutoencoderKLCausal3D; config of hunyuan-video-t2v-720p/vae)
+HUNYUAN_VAE_CFG = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=16, norm_num_groups=32, sample_size=256, sample_tsize=64,
+                       scaling_factor=0.476986, time_compression_ratio=4, spatial_compression_ratio=8, tile_overlap_factor=0.25)
+HUNYUAN_VAE_TINY_CFG = dict(block_out_channels=(32, 64, 128, 128), layers_per_block=2, latent_channels=16, norm_num_groups=8, sample_size=64, sample_tsize=16,
+                            scaling_factor=0.476986, time_compression_ratio=4, spatial_compression_ratio=8, tile_overlap_factor=0.25)
+
+
+def hunyuan_vae_up_plan(cfg):
+    """DecoderCausal3D.__init__ (autoencoder_kl_causal_3d/vae.py:176-211): per up block (in_ch, out_ch, time factor, hw factor, has_upsampler)."""
+    boc = list(reversed(cfg["block_out_channels"]))
+    n_sp, n_t = int(math.log2(cfg["spatial_compression_ratio"])), int(math.log2(cfg["time_compression_ratio"]))
+    plan, prev = [], boc[0]
+    for i, out in enumerate(boc):
+        final = i == len(boc) - 1
+        sp, tm = i < n_sp, (i >= len(boc) - 1 - n_t and not final)
+        plan.append((prev, out, 2 if tm else 1, 2 if sp else 1, sp or tm))
+        prev = out
+    return plan
+
+
+def synth_hunyuan_vae_weights(cfg, seed=0, device="cpu"):
+    """Seeded fp32 decoder weights of AutoencoderKLCausal3D under diffusers' state-dict names (`decoder.*`, `post_quant_conv.*`)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k, gain=1.0):
+        sd[f"{name}.weight"] = (torch.randn((cout, cin, k, k, k), generator=gen) * (gain / math.sqrt(cin * k**3))).to(device)
+        sd[f"{name}.bias"] = (torch.randn((cout,), generator=gen) * 0.05).to(device)
+
+    def lin(name, cout, cin):
+        sd[f"{name}.weight"] = (torch.randn((cout, cin), generator=gen) / math.sqrt(cin)).to(device)
+        sd[f"{name}.bias"] = (torch.randn((cout,), generator=gen) * 0.05).to(device)
+
+    def norm(name, c):
+        sd[f"{name}.weight"] = (1.0 + 0.1 * torch.randn((c,), generator=gen)).to(device)
+        sd[f"{name}.bias"] = (0.05 * torch.randn((c,), generator=gen)).to(device)
+
+    def res(p, cin, cout):
+        norm(p + "norm1", cin)
+        conv(p + "conv1.conv", cout, cin, 3, gain=1.4)
+        norm(p + "norm2", cout)
+        conv(p + "conv2.conv", cout, cout, 3, gain=1.4)
+        if cin != cout:
+            conv(p + "conv_shortcut.conv", cout, cin, 1)
+
+    zc, top = cfg["latent_channels"], cfg["block_out_channels"][-1]
+    conv("post_quant_conv", zc, zc, 1)
+    conv("decoder.conv_in.conv", top, zc, 3)
+    res("decoder.mid_block.resnets.0.", top, top)
+    norm("decoder.mid_block.attentions.0.group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        lin(f"decoder.mid_block.attentions.0.{n}", top, top)
+    res("decoder.mid_block.resnets.1.", top, top)
+    for i, (cin, cout, _, _, has_up) in enumerate(hunyuan_vae_up_plan(cfg)):
+        for j in range(cfg["layers_per_block"] + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}.", cin if j == 0 else cout, cout)
+        if has_up:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv.conv", cout, cout, 3)
+    norm("decoder.conv_norm_out", cfg["block_out_channels"][0])
+    conv("decoder.conv_out.conv", 3, cfg["block_out_channels"][0], 3, gain=0.5)
+    return sd
