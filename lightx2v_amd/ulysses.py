@@ -54,6 +54,26 @@ class UlyssesAttention:
         self.overlap = overlap and torch.cuda.is_available()
         self.comm_stream = None
 
+    class _Pending:
+        """An exchange already issued on the communication stream (result valid once the compute stream has joined it)."""
+
+        def __init__(self, src, out):
+            self.src, self.out = src, out
+
+    def begin_exchange(self, x):
+        """Start seq→head of `x` on the communication stream now (stream-ordered after what has been enqueued on the
+        compute stream so far); the caller keeps enqueueing independent work and hands the result to __call__."""
+        if not (self.overlap and x.is_cuda):
+            return None
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream()
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            out = seq2head(x, self.group)
+        x.record_stream(self.comm_stream)
+        out.record_stream(self.comm_stream)
+        return self._Pending(x, out)
+
     def __call__(self, q, k, v, num_heads, head_dim=128, timer=None, variant=0):
         n, _ = _world(self.group)
         if num_heads % n != 0:
@@ -64,11 +84,14 @@ class UlyssesAttention:
             cur = torch.cuda.current_stream()
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
-                qh, kh, vh = seq2head(q, self.group), seq2head(k, self.group), seq2head(v, self.group)
-            for t in (q, k, v, qh, kh, vh):
+                qh, kh = seq2head(q, self.group), seq2head(k, self.group)
+                vh = v.out if isinstance(v, self._Pending) else seq2head(v, self.group)
+            for t in (q, k, qh, kh, vh) + (() if isinstance(v, self._Pending) else (v,)):
                 t.record_stream(self.comm_stream)
             cur.wait_stream(self.comm_stream)
         else:
+            if isinstance(v, self._Pending):
+                v = v.src
             qh, kh, vh = seq2head(q, self.group), seq2head(k, self.group), seq2head(v, self.group)
         fn = (lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim, variant=variant)) if variant else (lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim))
         o = timer("self", fn) if timer is not None else fn()

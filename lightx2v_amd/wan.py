@@ -237,9 +237,12 @@ class WanTransformerInfer:
     def infer_self_attn(self, weights, grid_sizes, x, seq_lens, freqs, shift_msa, scale_msa, gate_msa):
         """transformer_infer.py:321-396 + the `x.add_(y * gate_msa)` of :402 folded into the o-projection."""
         n1 = lib.layernorm(x, scale=scale_msa, shift=shift_msa, eps=weights.norm1.eps)  # norm1 has no affine (transformer_weights.py:127-129)
+        # Ulysses: v needs no norm/RoPE, so it is projected first and its seq→head exchange runs on the communication
+        # stream under the q and k projections and the norm+RoPE kernel
+        v = weights.self_attn_v.apply(n1)
+        v_pending = self.parallel_attention.begin_exchange(v) if hasattr(self.parallel_attention, "begin_exchange") else None
         q = weights.self_attn_q.apply(n1)
         k = weights.self_attn_k.apply(n1)
-        v = weights.self_attn_v.apply(n1)
         grid = tuple(int(g) for g in grid_sizes[0].tolist())
         s_local = x.shape[0]
         if freqs.is_complex():  # driven by the reference's WanPreInfer: complex128 [1024, 64] (pre_infer.py:12-19)
@@ -256,7 +259,8 @@ class WanTransformerInfer:
         if self.parallel_attention is None:
             attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant))
         else:
-            attn = self.parallel_attention(q=q, k=k, v=v, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)
+            attn = self.parallel_attention(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed,
+                                           variant=variant)
         return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
 
     def infer_cross_attn(self, weights, x, context):
