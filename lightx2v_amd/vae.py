@@ -124,23 +124,26 @@ class Decoder3d:
         """reference: AttentionBlock.forward (vae.py:226-262) — per frame, one head of dim C over h*w tokens."""
         t, h, w, c = x.shape
         n = h * w
-        if n % 16:
-            raise lib.X2VError(f"VAE attention: h*w = {n} must be a multiple of 16 (the PV GEMM reduces over tokens)")
+        npad = (n + 15) // 16 * 16  # the PV GEMM reduces over keys in 16-float slabs: zero-padded token rows beyond n
         xn = torch.empty_like(x)
         lib.vae_prep(x, xn, (n * c, w * c), gamma=self.w[p + "norm.gamma"])
         qkv = self._conv1x1(p + "to_qkv", xn)  # [t, h, w, 3C]
         out = torch.empty_like(x)
-        scores = torch.empty((n, n), dtype=torch.float32, device=x.device)
-        o = torch.empty((1, 1, n, c), dtype=torch.float32, device=x.device)
+        scores = torch.empty((npad, npad), dtype=torch.float32, device=x.device)
+        o = torch.empty((1, 1, npad, c), dtype=torch.float32, device=x.device)
+        qp = torch.zeros((npad, 3 * c), dtype=torch.float32, device=x.device) if npad > n else None
         for f in range(t):
             q = qkv[f].reshape(n, 3 * c)
+            if qp is not None:
+                qp[:n].copy_(q)
+                q = qp
             k = q[:, c : 2 * c]
-            vt = q[:, 2 * c :].t().contiguous()  # [C, n]: the PV GEMM wants the reduction index contiguous
+            vt = q[:, 2 * c :].t().contiguous()  # [C, npad]: the PV GEMM wants the reduction index contiguous
             # S = Q K^T: "pixels" = query tokens (stride 3C), "weights" = key rows (stride 3C)
-            lib.vae_conv(q, (n * 3 * c, n * 3 * c, 3 * c), k, scores, 1, 1, n, w_row_stride=3 * c, cin=c)
-            lib.softmax_rows_(scores, 1.0 / (c**0.5))
-            lib.vae_conv(scores, (n * n, n * n, n), vt, o, 1, 1, n)
-            lib.vae_conv(o, (n * c, w * c, c), self.w[p + "proj.weight"], out[f : f + 1], 1, h, w, bias=self.w[p + "proj.bias"], resid=x[f : f + 1])
+            lib.vae_conv(q, (npad * 3 * c, npad * 3 * c, 3 * c), k, scores, 1, 1, npad, w_row_stride=3 * c, cin=c)
+            lib.softmax_rows_causal_(scores, 1.0 / (c**0.5), npad, n_keys=n)  # hw = npad: no frame mask, only the padding columns are cut
+            lib.vae_conv(scores, (npad * npad, npad * npad, npad), vt, o, 1, 1, npad)
+            lib.vae_conv(o, (npad * c, w * c, c), self.w[p + "proj.weight"], out[f : f + 1], 1, h, w, bias=self.w[p + "proj.bias"], resid=x[f : f + 1])
         return out
 
     def resample(self, p, x, mode):
@@ -193,15 +196,52 @@ class WanVAE_:
 
 
 class WanVAE:
-    """reference: vae.py:789-957 (decode side; `parallel` / `use_tiling` variants are not built)."""
+    """reference: vae.py:789-957 (decode side; `use_tiling` is not built)."""
 
-    def __init__(self, sd, z_dim=16, dim=96, device="cuda"):
-        self.device = device
+    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False):
+        self.device, self.parallel = device, parallel
         self.mean = torch.tensor(synth.WAN_VAE_MEAN, dtype=torch.float32, device=device)
         self.inv_std = 1.0 / torch.tensor(synth.WAN_VAE_STD, dtype=torch.float32, device=device)
         self.scale = [self.mean, self.inv_std]
         self.model = WanVAE_(sd, dim=dim, z_dim=z_dim, device=device)
 
+    def decode_dist(self, zs, world_size, cur_rank, split_dim):
+        """reference: vae.py:883-929 — each rank decodes its slab of the latent (split along H = dim 2 or W = dim 3) plus a
+        one-latent-pixel halo on each side (two on the outer side for the edge ranks), crops the halo's 8 output pixels and
+        all-gathers the slabs."""
+        import torch.distributed as dist
+
+        total = zs.shape[split_dim]
+        chunk, pad = total // world_size, 1
+        if cur_rank == 0:
+            lo, hi = 0, chunk + 2 * pad
+        elif cur_rank == world_size - 1:
+            lo, hi = total - (chunk + 2 * pad), total
+        else:
+            lo, hi = cur_rank * chunk - pad, (cur_rank + 1) * chunk + pad
+        zs = zs.narrow(split_dim, lo, hi - lo).contiguous()
+        images = self.model.decode(zs.unsqueeze(0).to(self.device), self.scale)
+        px = split_dim + 1
+        if cur_rank == 0:
+            images = images.narrow(px, 0, chunk * 8)
+        elif cur_rank == world_size - 1:
+            images = images.narrow(px, images.shape[px] - chunk * 8, chunk * 8)
+        else:
+            images = images.narrow(px, 8 * pad, images.shape[px] - 16 * pad)
+        images = images.contiguous()
+        gathered = torch.empty((world_size * images.shape[0], *images.shape[1:]), dtype=images.dtype, device=images.device)
+        dist.all_gather_into_tensor(gathered, images)
+        return torch.cat(list(gathered.chunk(world_size, dim=0)), dim=px)
+
     def decode(self, zs, generator=None, config=None):
-        """zs [16, T, h, w] → images [1, 3, T_out, 8h, 8w] fp32 in [-1, 1] (vae.py:931-957, non-parallel branch)."""
+        """zs [16, T, h, w] → images [1, 3, T_out, 8h, 8w] fp32 in [-1, 1] (vae.py:931-957; `parallel` = the decode_dist
+        branch when H or W divides by the world size, else the plain decode like the reference's fallback)."""
+        if self.parallel:
+            import torch.distributed as dist
+
+            n, r = dist.get_world_size(), dist.get_rank()
+            if zs.shape[3] % n == 0:
+                return self.decode_dist(zs, n, r, 3)
+            if zs.shape[2] % n == 0:
+                return self.decode_dist(zs, n, r, 2)
         return self.model.decode(zs.unsqueeze(0).to(self.device), self.scale)

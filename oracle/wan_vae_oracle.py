@@ -142,3 +142,27 @@ def wan_vae_decode(sd, z, mean, inv_std, dim=96, clamp=True):
     outs = [decoder_chunk(sd, x[:, i : i + 1], cache, plan) for i in range(x.shape[1])]
     out = torch.cat(outs, dim=1)
     return out.float().clamp_(-1, 1) if clamp else out
+
+
+def wan_vae_decode_dist(sd, z, mean, inv_std, world_size, split_dim, dim=96):
+    """WanVAE.decode_dist (vae.py:883-929) evaluated for every rank in turn: slab + 1-latent-pixel halo (2 on the outer side of
+    the edge ranks), independent decode, crop 8 px per halo pixel, concatenate.  z [16, T, h, w]; split_dim 2 (H) or 3 (W)."""
+    total = z.shape[split_dim]
+    chunk, pad = total // world_size, 1
+    outs = []
+    for r in range(world_size):
+        if r == 0:
+            lo, hi = 0, chunk + 2 * pad
+        elif r == world_size - 1:
+            lo, hi = total - (chunk + 2 * pad), total
+        else:
+            lo, hi = r * chunk - pad, (r + 1) * chunk + pad
+        img = wan_vae_decode(sd, z.narrow(split_dim, lo, hi - lo).contiguous(), mean, inv_std, dim=dim)  # [3, T', H', W']
+        if r == 0:
+            img = img.narrow(split_dim, 0, chunk * 8)
+        elif r == world_size - 1:
+            img = img.narrow(split_dim, img.shape[split_dim] - chunk * 8, chunk * 8)
+        else:
+            img = img.narrow(split_dim, 8 * pad, img.shape[split_dim] - 16 * pad)
+        outs.append(img)
+    return torch.cat(outs, dim=split_dim)
