@@ -128,6 +128,16 @@ int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                               int64_t Sk, int H, int head_dim, float scale, int variant, void* stream);
 
+/* V [Sk, H*128] (token stride ldv) -> V^T [H][128][ldvt] with keys >= Sk zero-filled (ldvt % 64 == 0, ldvt >= Sk): the
+ * operand layout of x2v_attn_fwd_bf16_vt. */
+int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt, int64_t Sk, int H, void* stream);
+
+/* x2v_attn_fwd_bf16 on a pre-transposed V (x2v_transpose_heads_bf16): V^T is staged by LDS-DMA and read as plain
+ * 16-byte fragments (no transpose reads, a third fewer LDS instructions per MFMA).  v3/v4 numerics (scale folded into q;
+ * q_prescaled != 0: q already carries scale*log2(e), see X2V_ATTN_Q_PRESCALED). */
+int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
+                         int H, int head_dim, float scale, int q_prescaled, void* stream);
+
 /* Per-token dynamic fp8 quantisation: s[m] = amax(|x[m,:]|)/448, xq = e4m3fn(x / s) — replaces
  * vllm ops.scaled_fp8_quant(use_per_token_if_dynamic=True) / sgl_kernel.sgl_per_token_quant_fp8
  * (mm_weight.py:236-245).  xq [M,K] bytes (ld = ldq), scale fp32 [M]. */

@@ -1018,12 +1018,550 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned 
   }
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// v6 = v4's pipeline on a pre-transposed V: V^T [H][128][Sk padded] (x2v_transpose_heads_bf16) is staged by LDS-DMA like K
+// and read with ds_read_b128; K rows are permuted in the fragment read so that P's register order matches 8 consecutive
+// keys.  Per tile and wave: 32 LDS fragment reads instead of 48, no ds_read_tr, no V register staging / ds_write.
+template <int NW, int RESCALE_THR, bool PRESCALED>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v6_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
+                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                                   const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
+                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
+                                                                   unsigned v_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
+  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
+  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;  // this head's V^T block: [128 dv rows][ldvt keys]
+
+  bf16x8_t qf[8];
+  {
+    int64_t qr = q0 + fl;
+    qr = qr < Sq ? qr : Sq - 1;
+    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    // fold softmax scale * log2(e) into Q (one extra bf16 rounding of Q, relative 2^-9): the scores leave the MFMA in
+    // the exp2 domain, and with the running max entering as the accumulator's initial value the per-score FMA is gone
+    // (PRESCALED: the producer kernel already did this inside q's own rounding)
+    if constexpr (!PRESCALED) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t v = qf[ks];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
+        qf[ks] = v;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // K and V^T both by LDS-DMA through raw buffer loads: per-lane byte offsets are loop-invariant, the tile offset travels
+  // in an SGPR (soffset); K rows past Sk read as zero (hardware bounds check), V^T is zero-padded to a tile multiple by the
+  // transpose kernel.  V^T [128 dv][ldvt keys] makes the PV A-operand a plain ds_read_b128 of 8 consecutive keys — no
+  // transpose reads, no register staging, the same [rows][128 B] swizzled image as the GEMM tiles.
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2);
+  unsigned k_voff[KDMA], v_voff[KDMA];
+#pragma unroll
+  for (int j = 0; j < KDMA; ++j) {
+    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
+    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
+    const int vrow = (wid * KDMA + j) * 8 + (lane >> 3);  // dv row of the [128][128 B] tile; 8 rows per 1 KiB piece
+    v_voff[j] = (unsigned)(vrow * ldvt * 2) + (unsigned)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
+  }
+#define AT_DMA_K(T_, BUF_)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
+#define AT_DMA_V(T_, BUF_)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, v_voff[j], (unsigned)(T_) * (AT_KV * 2), 0, 0);
+
+  // K fragment offsets.  MFMA row i = fl reads key row perm(fl) = fl with bits 2 and 3 swapped, so that a half-wave's
+  // accumulator registers hold 8 CONSECUTIVE keys per 16-key group (keys 16g + 8*hi + 0..7) — the k-order of a plain
+  // 16-byte V^T fragment.  (Any key permutation is legal for QK^T; it only has to agree with the PV operands.)
+  int kaddr[8];
+  const int krow_rd = (fl & 0x13) | ((fl & 4) << 1) | ((fl & 8) >> 1);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = krow_rd * 256 + (((hi ^ (krow_rd & 15)) << 4) ^ (ks << 5));
+  // V^T fragment offsets: dv row (T*32 + fl), 16-byte chunk (g*2 + hi) of 16-key group g, GEMM-style swizzle
+  int vaddr[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) vaddr[g] = fl * 128 + ((((g << 1) | hi) ^ ((fl >> 1) & 7)) << 4);
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int T = 0; T < 4; ++T)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
+  // m_run: running row max (exp2 domain), entered into every score chain as C = negm = -m_run.  A chain is started two
+  // decisions before its scores are exponentiated (software pipeline), so scores carry m_run(t-2); d_prev = the growth
+  // decided at tile t-1.  Growth is rare (lazy rescale), so the fix-up  S' -= d_prev + d_cur  lives in a cold branch.
+  float m_run = 0.f, d_prev = 0.f;
+  float lsum[4] = {0.f, 0.f, 0.f, 0.f};  // row sum in four partial chains (a single accumulator would serialise 32 dependent adds)
+  bool force = true;  // first tile: adopt its row max in either direction (no underflow for very negative rows)
+  f32x16_t negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+
+#define AT_QK(DST_, BUF_)                                                                                     \
+  {                                                                                                            \
+    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
+      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
+    }                                                                                                          \
+  }
+
+  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
+  AT_DMA_K(0, 0)
+  if (nt > 1) {
+    AT_DMA_K(1, 1)
+  }
+  AT_DMA_V(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16_t sc[2];
+  AT_QK(sc, 0)
+  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
+  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
+  __syncthreads();
+
+  // One tile = 32 slots, each {fragment read two slots ahead, one MFMA, a fixed chunk of VALU work}, pinned by
+  // sched_barrier(0).
+  //   slots  0..15 (phase 1): MFMA = S(t+1) chain (K(t+1) Q'^T, C = negm at its head), accumulated in `sn`; the LAST link
+  //                           of each chain (slots 14, 15) writes its result into `sc`, which the VALU side has finished
+  //                           with by then — the score buffers swap roles without a copy and without unrolling.
+  //                           VALU = softmax of S(t) in sc: slots 0-3 row max (trees), slot 4 half-wave exchange + the
+  //                           lazy-rescale decision (cold branch), slots 5-9 exp2 / row-sum / bf16 pack of sc[0],
+  //                           slots 10-14 of sc[1].
+  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T from the packed P; no VALU (sn is dead: registers are free for
+  //                           the deeper fragment prefetch).
+#define AT_SB() __builtin_amdgcn_sched_barrier(0)
+#define A4_KFRAG(I_) (*reinterpret_cast<const bf16x8_t*>(kb_ + ((I_) & 1) * 8192 + kaddr[(I_) >> 1]))
+#define A4_VFRAG(J_) (*reinterpret_cast<const bf16x8_t*>(vb + ((J_) >> 2) * 4096 + vaddr[(J_) & 3]))
+#define A4_TILE(LAST_, KN_, VB_)                                                                               \
+  {                                                                                                            \
+    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
+      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
+        if (u * 32 + (r & 7) + 8 * hi + 16 * (r >> 3) >= left) sc[u][r] = -1e30f;                              \
+    }                                                                                                          \
+    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
+    bf16x8_t kfa, kfb;                                                                                         \
+    if (!(LAST_)) {                                                                                            \
+      kfa = A4_KFRAG(0);                                                                                       \
+      kfb = A4_KFRAG(1);                                                                                       \
+    }                                                                                                          \
+    float pm[4];                                                                                               \
+    unsigned pw[16];                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
+      const int ks = i >> 1, u = i & 1;                                                                        \
+      if (!(LAST_)) {                                                                                          \
+        if (i < 14) sn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], ks == 0 ? negm : sn[u], 0, 0, 0); \
+        else sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], sn[u], 0, 0, 0);           \
+        if (i + 2 < 16) {                                                                                      \
+          if (u) kfb = A4_KFRAG(i + 2); else kfa = A4_KFRAG(i + 2);                                            \
+        }                                                                                                      \
+      }                                                                                                        \
+      if (i < 4) { /* row max of 8 scores as a depth-2 tree */                                                 \
+        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
+        const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                    \
+        const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                \
+        const float c_ = vmax2(sc[uu][r0 + 6], sc[uu][r0 + 7]);                                                \
+        pm[i] = vmax3(a_, b_, c_);                                                                             \
+      } else if (i == 4) {                                                                                     \
+        float mx = vmax2(vmax2(pm[0], pm[1]), vmax2(pm[2], pm[3]));                                            \
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
+        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
+        const float ex = mx - d_prev; /* this tile's row max relative to m_run(t-1) */                         \
+        if (force || __any(ex > (float)RESCALE_THR || d_prev != 0.f)) {                                        \
+          /* cold path: some row's max grew by more than THR (or did so one tile ago, or first tile) */        \
+          const bool grow = force || __any(ex > (float)RESCALE_THR);                                           \
+          const float d_cur = grow ? (force ? ex : fmaxf(ex, 0.f)) : 0.f;                                      \
+          if (grow) {                                                                                          \
+            m_run += d_cur;                                                                                    \
+            if (!force) {                                                                                      \
+              const float al = __builtin_amdgcn_exp2f(-d_cur);                                                 \
+              _Pragma("unroll") for (int e = 0; e < 4; ++e) lsum[e] *= al;                                     \
+              _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
+            }                                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                   \
+          }                                                                                                    \
+          const float corr = d_prev + d_cur;                                                                   \
+          _Pragma("unroll") for (int u2 = 0; u2 < 2; ++u2) _Pragma("unroll") for (int e = 0; e < 16; ++e) sc[u2][e] -= corr; \
+          d_prev = d_cur;                                                                                      \
+          force = false;                                                                                       \
+        }                                                                                                      \
+      } else if (i < 15) { /* slots 5..9: sc[0], slots 10..14: sc[1]; 4,3,3,3,3 elements */                    \
+        const int uu = (i - 5) / 5, q_ = (i - 5) % 5;                                                          \
+        const int e0 = q_ == 0 ? 0 : 1 + 3 * q_, e1 = 4 + 3 * q_;                                              \
+        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
+          const float p_ = __builtin_amdgcn_exp2f(sc[uu][e]);                                                  \
+          sc[uu][e] = p_;                                                                                      \
+          lsum[e & 3] += p_;                                                                                   \
+          if (e & 1) pw[uu * 8 + (e >> 1)] = pack_bf2(sc[uu][e - 1], p_);                                      \
+        }                                                                                                      \
+      }                                                                                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                        \
+    bf16x8_t vfa = A4_VFRAG(0), vfb = A4_VFRAG(1);                                                             \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
+      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
+      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
+      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((j & 1) ? vfb : vfa, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      if (j + 2 < 16) {                                                                                        \
+        if (j & 1) vfb = A4_VFRAG(j + 2); else vfa = A4_VFRAG(j + 2);                                          \
+      }                                                                                                        \
+      AT_SB();                                                                                                 \
+    }                                                                                                          \
+  }
+  f32x16_t sn[2];
+  int t = 0;
+  for (; t < nt - 1; ++t) {
+    if (t + 2 < nt) {
+      AT_DMA_K(t + 2, t & 1)
+    }
+    AT_DMA_V(t + 1, (t + 1) & 1)
+    AT_SB();
+    A4_TILE(false, (t + 1) & 1, t & 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  A4_TILE(true, (t + 1) & 1, t & 1)
+#undef A4_TILE
+#undef A4_VFRAG
+#undef A4_KFRAG
+#undef AT_SB
+
+  const float l_run = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + fl;
+  if (qrow < Sq) {
+    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = 32 * T + 8 * g + 4 * hi;  // accumulator row of the 32x32 tile = dv row of the V^T fragment
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
+        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dv) = pk;
+      }
+  }
+#endif
+}
+#undef AT_DMA_V
+// ------------------------------------------------------------------------------------------------
+// v8 = "ping-pong" on the v6 operand layouts: every wave alternates a pure matrix half-step {PV(t-1) then QK^T(t): 32 MFMAs +
+// their LDS fragment reads} with a pure vector half-step {softmax(t): row max, exp2, row sum, bf16 pack}, and the two waves of
+// a SIMD (wid and wid + NW/2) run half a step apart — while one occupies the matrix pipe the other occupies the VALU port.
+// In phase (v2..v6) both waves want the VALU during the softmax (exp2 is quarter rate) and both want the matrix pipe during
+// PV; the measured decomposition of v4 showed the parts adding up rather than overlapping.
+//   * one barrier per half-step; data movement is by global half-step g, identical for all waves: even g = 2t issues
+//     K(t+1) and V^T(t) (both double buffered), the odd half-step that follows ends with s_waitcnt vmcnt(0);
+//   * scores leave the MFMA already relative to the running max (C = -m_run, known before QK^T(t) starts because softmax(t-1)
+//     is the same wave's previous half-step — no one-tile lag as in v3/v4), rescale stays lazy (cold branch);
+//   * no second score buffer: 32 accumulator registers fewer than v4/v6, nothing spills at 2 waves per SIMD.
+template <int NW, int RESCALE_THR, bool PRESCALED, int PRIO, int DEPTH, int PROBE, bool DMA_LATE>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
+                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                                   const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
+                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
+                                                                   unsigned v_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t q0 = (int64_t)blockIdx.x * (NW * 32) + wid * 32;
+  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
+  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;
+
+  bf16x8_t qf[8];
+  {
+    int64_t qr = q0 + fl;
+    qr = qr < Sq ? qr : Sq - 1;
+    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+    if constexpr (!PRESCALED) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        bf16x8_t v = qf[ks];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
+        qf[ks] = v;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // LDS-DMA of K [64 keys][256 B] and V^T [128 dv][128 B] tiles, 1 KiB pieces (4 K rows / 8 V^T rows).  A wave moves pieces
+  // wid + NW*j: the rows of its pieces differ by a multiple of 16, so the swizzled source chunk is the same and ONE per-lane
+  // offset register per operand serves all pieces (the piece stride travels in the scalar offset with the tile offset).
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
+  // DMA_LATE: only the upper half of the waves moves data (all 16 pieces per operand, during their vector half-step: an LDS-DMA
+  // issue costs ~60 cycles between bare MFMAs and about half of that in VALU-only gaps); their pieces are wl + (NW/2) j.
+  constexpr int NDW = DMA_LATE ? NW / 2 : NW;      // waves that issue
+  constexpr int NPC = 16 / NDW;                    // pieces per issuing wave and operand
+  const int wl = DMA_LATE ? (wid & (NW / 2 - 1)) : wid;
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_piece_bytes = (unsigned)(4 * NDW * ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * ldvt * 2);
+  const int krow_w = wl * 4 + (lane >> 4), vrow_w = wl * 8 + (lane >> 3);
+  const unsigned k_voff = (unsigned)(krow_w * ldk * 2) + (unsigned)(((lane & 15) ^ (krow_w & 15)) << 4);
+  const unsigned v_voff = (unsigned)(vrow_w * ldvt * 2) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
+#define A8_DMA_K(T_, BUF_)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, k_voff, (unsigned)(T_) * k_tile_bytes + j * k_piece_bytes, 0, 0);
+#define A8_DMA_V(T_, BUF_)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
+      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (unsigned)(T_) * (AT_KV * 2) + j * v_piece_bytes, 0, 0);
+
+  // fragment offsets (see v6): K rows read through the bit-2/bit-3 swap so a half-wave's P registers are 8 consecutive keys
+  int kaddr[8], vaddr[4];
+  const int krow_rd = (fl & 0x13) | ((fl & 4) << 1) | ((fl & 8) >> 1);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = krow_rd * 256 + (((hi ^ (krow_rd & 15)) << 4) ^ (ks << 5));
+#pragma unroll
+  for (int g = 0; g < 4; ++g) vaddr[g] = fl * 128 + ((((g << 1) | hi) ^ ((fl >> 1) & 7)) << 4);
+
+  f32x16_t oacc[4], sc[2], negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    negm[e] = 0.f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) oacc[T][e] = 0.f;
+  }
+  float m_run = 0.f;
+  float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+  bool force = true;  // first tile: adopt its row max in either direction
+  unsigned pw[16];
+  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+
+#define A8_SB() __builtin_amdgcn_sched_barrier(0)
+  // matrix half-step: unified stream of fragment slots n = 0..15 (K: key block n&1, head-dim step n>>1) and 16..31 (V^T: dv block
+  // n&3, key group (n-16)>>2), each fragment read DEPTH slots ahead of the MFMA that consumes it.  QK^T(t) goes first: its scores
+  // are what the next half-step needs, so they are long complete at the barrier, and PV(t-1)'s results are not read for a whole step.
+#define A8_FRAG(N_)                                                                                            \
+  ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + ((N_) & 1) * 8192 + kaddr[(N_) >> 1])                \
+             : *reinterpret_cast<const bf16x8_t*>(vb + ((N_) & 3) * 4096 + vaddr[((N_) - 16) >> 2]))
+#define A8_MATRIX(N0_, N1_, VB_, KB_)                                                                          \
+  if (PROBE != 2) {                                                                                            \
+    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                        \
+    const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                       \
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                              \
+    bf16x8_t fr[DEPTH];                                                                                        \
+    _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A8_FRAG((N0_) + d);                              \
+    _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                    \
+      const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                             \
+      if (n < 16) {                                                                                            \
+        const int ks = n >> 1, u = n & 1;                                                                      \
+        sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, qf[ks], ks == 0 ? negm : sc[u], 0, 0, 0);          \
+      } else {                                                                                                 \
+        const int T = n & 3, uh = (n - 16) >> 2;                                                               \
+        i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};     \
+        oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
+      }                                                                                                        \
+      if (n + DEPTH < (N1_)) fr[(n - (N0_)) % DEPTH] = A8_FRAG(n + DEPTH);                                     \
+      A8_SB();                                                                                                 \
+    }                                                                                                          \
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                              \
+  }
+  // vector half-step: softmax of the tile in sc -> packed bf16 P in pw
+#define A8_SOFTMAX(LAST_)                                                                                      \
+  if (PROBE == 1) {                                                                                            \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) pw[e] = __float_as_uint(sc[e >> 3][e & 7]) >> 8;            \
+  } else {                                                                                                     \
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                              \
+    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
+      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
+        if (u * 32 + (r & 7) + 8 * hi + 16 * (r >> 3) >= left) sc[u][r] = -1e30f;                              \
+    }                                                                                                          \
+    float pm[4];                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+      const int uu = i >> 1, r0 = (i & 1) * 8;                                                                 \
+      const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                      \
+      const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                  \
+      const float c_ = vmax2(sc[uu][r0 + 6], sc[uu][r0 + 7]);                                                  \
+      pm[i] = vmax3(a_, b_, c_);                                                                               \
+    }                                                                                                          \
+    float mx = vmax2(vmax2(pm[0], pm[1]), vmax2(pm[2], pm[3]));                                                \
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);        \
+    mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])); /* row max relative to m_run */                \
+    if (force || __any(mx > (float)RESCALE_THR)) { /* cold: some row's max grew by more than THR (or first tile) */ \
+      const float d = force ? mx : fmaxf(mx, 0.f);                                                             \
+      m_run += d;                                                                                              \
+      if (!force) {                                                                                            \
+        const float al = __builtin_amdgcn_exp2f(-d);                                                           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) lsum[e] *= al;                                           \
+        _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
+      }                                                                                                        \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                         \
+      _Pragma("unroll") for (int u2 = 0; u2 < 2; ++u2) _Pragma("unroll") for (int e = 0; e < 16; ++e) sc[u2][e] -= d; \
+      force = false;                                                                                           \
+    }                                                                                                          \
+    _Pragma("unroll") for (int uu = 0; uu < 2; ++uu) _Pragma("unroll") for (int e = 0; e < 16; e += 2) {       \
+      const float p0 = __builtin_amdgcn_exp2f(sc[uu][e]), p1 = __builtin_amdgcn_exp2f(sc[uu][e + 1]);         \
+      lsum[e & 3] += p0;                                                                                       \
+      lsum[(e + 1) & 3] += p1;                                                                                 \
+      pw[uu * 8 + (e >> 1)] = pack_bf2(p0, p1);                                                                \
+    }                                                                                                          \
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                              \
+  }
+
+  // ---- prologue: K(0)
+  if (!DMA_LATE || wid >= NW / 2) {
+    A8_DMA_K(0, 0)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- global half-steps g = 0 .. 2 nt + 1; a wave's own step is gl = g - late (late = the upper half of the waves):
+  //      gl = 2t   : matrix half-step  PV(t-1) [t > 0]  +  QK^T(t) [t < nt]
+  //      gl = 2t+1 : vector half-step  softmax(t)
+  // Written out per role (straight-line loops keep the accumulator tuples in place; a single loop with a phase switch made
+  // the register allocator copy and spill them).  Every wave passes 2 nt + 2 barriers.
+  int t = 0;
+#define A8_ISSUE(TG_) /* even half-step g = 2 TG_ */            \
+  if ((TG_) + 1 < nt) {                                        \
+    A8_DMA_K((TG_) + 1, ((TG_) + 1) & 1)                       \
+  }                                                            \
+  if ((TG_) < nt) {                                            \
+    A8_DMA_V((TG_), (TG_) & 1)                                 \
+  }                                                            \
+  A8_SB();
+  // the data issued in an even half-step is awaited at the end of the following odd one: two half-steps of flight
+#define A8_BAR_EVEN() __syncthreads();
+#define A8_BAR_ODD()                                   \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+  __syncthreads();
+  if (wid < NW / 2) {
+    if (!DMA_LATE) {
+      A8_ISSUE(0)
+    }
+    A8_MATRIX(0, 16, 0, 0)
+    A8_BAR_EVEN()
+    for (; t < nt - 1; ++t) {
+      A8_SOFTMAX(false)
+      A8_BAR_ODD()
+      if (!DMA_LATE) {
+        A8_ISSUE(t + 1)
+      }
+      A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
+      A8_BAR_EVEN()
+    }
+    A8_SOFTMAX(true)
+    A8_BAR_ODD()
+    A8_MATRIX(16, 32, t & 1, 0)
+    A8_BAR_EVEN()
+    A8_BAR_ODD()
+  } else {
+    A8_ISSUE(0)
+    A8_BAR_EVEN()
+    A8_MATRIX(0, 16, 0, 0)
+    A8_BAR_ODD()
+    for (; t < nt - 1; ++t) {
+      A8_ISSUE(t + 1)
+      A8_SOFTMAX(false)
+      A8_BAR_EVEN()
+      A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
+      A8_BAR_ODD()
+    }
+    A8_SOFTMAX(true)
+    A8_BAR_EVEN()
+    A8_MATRIX(16, 32, t & 1, 0)
+    A8_BAR_ODD()
+  }
+#undef A8_ISSUE
+#undef A8_BAR_EVEN
+#undef A8_BAR_ODD
+#undef A8_SOFTMAX
+#undef A8_MATRIX
+#undef A8_FRAG
+#undef A8_SB
+#undef A8_DMA_K
+#undef A8_DMA_V
+
+  const float l_run = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + fl;
+  if (qrow < Sq) {
+    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = 32 * T + 8 * g + 4 * hi;
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
+        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dv) = pk;
+      }
+  }
+#endif
+}
 #undef AT_DMA_K
 #undef AT_LOAD_V
 #undef AT_WRITE_V
 #undef AT_QK
 
 
+
+
+// V [Sk, H*128] (token stride ldv) -> V^T [H][128][ldvt] bf16 with keys >= Sk zero-filled up to ldvt (a multiple of 64).
+// 64 keys x 128 dv per block through LDS.
+__global__ __launch_bounds__(256) void transpose_heads_kernel(const unsigned short* __restrict__ V, int64_t ldv, unsigned short* __restrict__ VT, int64_t ldvt,
+                                                              int64_t Sk) {
+  __shared__ unsigned short tile[64][128 + 2];
+  const int head = blockIdx.y;
+  const int64_t k0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + threadIdx.x;
+    const int row = id >> 4, c = id & 15;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (k0 + row < Sk) v = *reinterpret_cast<const uint4*>(V + (k0 + row) * ldv + (int64_t)head * 128 + c * 8);
+    unsigned short* d = &tile[row][c * 8];
+    d[0] = (unsigned short)(v.x & 0xffff); d[1] = (unsigned short)(v.x >> 16);
+    d[2] = (unsigned short)(v.y & 0xffff); d[3] = (unsigned short)(v.y >> 16);
+    d[4] = (unsigned short)(v.z & 0xffff); d[5] = (unsigned short)(v.z >> 16);
+    d[6] = (unsigned short)(v.w & 0xffff); d[7] = (unsigned short)(v.w >> 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + threadIdx.x;
+    const int dv = id >> 3, kc = id & 7;
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (unsigned)tile[kc * 8 + 2 * e][dv] | ((unsigned)tile[kc * 8 + 2 * e + 1][dv] << 16);
+    *reinterpret_cast<uint4*>(VT + ((int64_t)head * 128 + dv) * ldvt + k0 + kc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
 
 }  // namespace x2v
 using namespace x2v;
@@ -1106,6 +1644,68 @@ static int launch_attn_v4(const void* q, int64_t ldq, const void* k, int64_t ldk
                      (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
   X2V_LAUNCH_CHECK("attn launch");
   return X2V_OK;
+}
+
+// KIND 0: v8 default; 1: v6 (in phase); 2..7: v8 variants for A/B measurements and timing probes (table in x2v_attn_fwd_bf16_vt)
+template <int KIND> struct V8Cfg { static constexpr int prio = 1, depth = 4, probe = 0; static constexpr bool late = true; };
+template <> struct V8Cfg<2> { static constexpr int prio = 1, depth = 4, probe = 0; static constexpr bool late = false; };
+template <> struct V8Cfg<3> { static constexpr int prio = 0, depth = 4, probe = 0; static constexpr bool late = true; };
+template <> struct V8Cfg<4> { static constexpr int prio = 1, depth = 2, probe = 0; static constexpr bool late = true; };
+template <> struct V8Cfg<6> { static constexpr int prio = 1, depth = 4, probe = 1; static constexpr bool late = true; };
+template <> struct V8Cfg<7> { static constexpr int prio = 1, depth = 4, probe = 2; static constexpr bool late = true; };
+template <int NW, int THR, bool PRESCALED, int KIND>
+static int launch_attn_v6(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
+                          int H, float scale, hipStream_t st) {
+  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (int64_t)AT_D * ldvt * 2;
+  X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
+  auto kern = KIND == 1 ? attn_fwd_v6_kernel<NW, THR, PRESCALED>
+                        : attn_fwd_v8_kernel<NW, THR, PRESCALED, V8Cfg<KIND>::prio, V8Cfg<KIND>::depth, V8Cfg<KIND>::probe, V8Cfg<KIND>::late>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AT_K_BYTES), "attn attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), 4 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
+                     (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
+  X2V_LAUNCH_CHECK("attn launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt, int64_t Sk, int H, void* stream) {
+  X2V_REQUIRE(v && vt, X2V_E_ARG, "transpose_heads: null pointer");
+  X2V_REQUIRE(Sk > 0 && H > 0 && H <= 65535 && ldvt % 64 == 0 && ldvt >= Sk && ldv >= (int64_t)H * AT_D && ldv % 8 == 0, X2V_E_SHAPE,
+              "transpose_heads: bad shape (ldvt must be a multiple of 64 and >= Sk)");
+  X2V_REQUIRE(aligned16(v) && aligned16(vt), X2V_E_ALIGN, "transpose_heads: 16-byte alignment");
+  hipLaunchKernelGGL(transpose_heads_kernel, dim3((unsigned)(ldvt / 64), (unsigned)H), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)v, ldv,
+                     (unsigned short*)vt, ldvt, Sk);
+  X2V_LAUNCH_CHECK("transpose_heads launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo,
+                                                                           int64_t Sq, int64_t Sk, int H, int head_dim, float scale, int q_prescaled, void* stream) {
+  X2V_REQUIRE(q && k && vt && o, X2V_E_ARG, "attn_vt: null pointer");
+  X2V_REQUIRE(head_dim == AT_D, X2V_E_SHAPE, "attn_vt: head_dim=%d (only 128 is built)", head_dim);
+  X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535, X2V_E_SHAPE, "attn_vt: bad shape Sq=%lld Sk=%lld H=%d", (long long)Sq, (long long)Sk, H);
+  X2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 64 == 0 && ldvt >= Sk && ldo % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(vt) && aligned16(o), X2V_E_ALIGN,
+              "attn_vt: rows must be 16-byte aligned, ldvt a multiple of 64");
+  X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D, X2V_E_SHAPE, "attn_vt: token stride smaller than H*128");
+  if (scale <= 0.f) scale = 0.08838834764831845f;
+  // bits 1-3 of the flag word pick a kernel for A/B measurements: 0 default (ping-pong, s_setprio in the matrix half-step, fragment
+  // prefetch depth 4, DMA issued by the vector-phase waves), 1 in-phase v6, 2 every wave issues DMA, 3 no s_setprio, 4 prefetch depth 2,
+  // 6/7 timing probes (no softmax / no matrix half-step: results invalid)
+  const int pre = q_prescaled & 1, kind = (q_prescaled >> 1) & 7;
+#define X2V_VT(K_)                                                                                                              \
+  case K_:                                                                                                                      \
+    return pre ? launch_attn_v6<8, 8, true, K_>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, (hipStream_t)stream)         \
+               : launch_attn_v6<8, 8, false, K_>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, (hipStream_t)stream);
+  switch (kind) {
+    X2V_VT(0) X2V_VT(1) X2V_VT(2) X2V_VT(3) X2V_VT(4) X2V_VT(6) X2V_VT(7)
+  }
+#undef X2V_VT
+  return X2V_E_ARG;
 }
 
 // variant: 0 = default (= 6); v1 kernels: 1 = 4 waves, 2 = 8 waves, 3 = 4 waves + scalar-V validation path for the transpose read;

@@ -36,6 +36,8 @@ PROTOTYPES = {
     "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
     "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
+    "x2v_transpose_heads_bf16": [_c_void_p, _i64, _c_void_p, _i64, _i64, _i32, _c_void_p],
+    "x2v_attn_fwd_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
@@ -142,7 +144,9 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
 
 
 ATTN_Q_PRESCALED = 0x100
-ATTN_FAST = 9  # v3 kernel, x2-unrolled (include/x2v.h); used with ATTN_Q_PRESCALED by the fused block drivers
+ATTN_V3 = 9  # v3 kernel, x2-unrolled (include/x2v.h)
+ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
+#                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
 
 
@@ -203,6 +207,18 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
     return out2
 
 
+def transpose_heads(v, num_heads):
+    """v [Sk, H*128] (any token stride) → V^T [H, 128, ceil64(Sk)] with the key padding zero-filled: the operand of the
+    pre-transposed-V attention kernel."""
+    v2 = _row2d(_bf16(v, "v"), "v")
+    Sk = v2.shape[0]
+    ldvt = (Sk + 63) // 64 * 64
+    vt = torch.empty((num_heads, 128, ldvt), dtype=torch.bfloat16, device=v.device)
+    init()
+    _check(_lib.x2v_transpose_heads_bf16(_p(v2), v2.stride(0), _p(vt), ldvt, Sk, num_heads, _stream()), "transpose_heads")
+    return vt
+
+
 def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0):
     """q [Sq, H*d] (or [Sq,H,d]), k/v [Sk, H*d]; any token stride (fused-QKV views are fine)."""
 
@@ -217,6 +233,14 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0):
     Sq, Sk = q2.shape[0], k2.shape[0]
     out2 = torch.empty((Sq, num_heads * head_dim), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(out, "out")
     init()
+    if (variant & 0xFF) == ATTN_FAST:
+        vt = transpose_heads(v2, num_heads)
+        _check(
+            _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[2], _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
+                                      1 if (variant & ATTN_Q_PRESCALED) else 0, _stream()),
+            "attn_fwd_vt",
+        )
+        return out2
     _check(
         _lib.x2v_attn_fwd_bf16_variant(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(v2), v2.stride(0), _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale, variant, _stream()),
         "attn_fwd",

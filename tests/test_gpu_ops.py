@@ -99,6 +99,29 @@ def test_attention_golden(lib, golden_ops):
         assert_bf16_close(o, g["xattn_o"], ulps=0.128, atol=4e-3, name=f"cross attention variant {variant}")
 
 
+def test_attention_fast_variants(lib, golden_ops):
+    """v3 / v4 / ping-pong kernels fold scale*log2(e) into q (one more bf16 rounding of q, relative 2^-9) — compared with the golden
+    outputs at twice the default tolerance; the ping-pong kernel runs on the pre-transposed V (transposition checked exactly)."""
+    g = golden_ops
+    for variant in (lib.ATTN_V3, 10, lib.ATTN_FAST):
+        o = lib.attention(dev(g["attn_q"]), dev(g["attn_k"]), dev(g["attn_v"]), 2, variant=variant)
+        assert_bf16_close(o, g["attn_o"], ulps=0.256, atol=8e-3, name=f"self attention variant {variant}")
+        o = lib.attention(dev(g["attn_q"]), dev(g["xattn_k"]), dev(g["xattn_v"]), 2, variant=variant)
+        assert_bf16_close(o, g["xattn_o"], ulps=0.256, atol=8e-3, name=f"cross attention variant {variant}")
+    # ragged sizes: Sq, Sk not multiples of the tiles; strided (fused-qkv) views; many tiles
+    gen = torch.Generator().manual_seed(77)
+    for Sq, Sk, H in ((1, 1, 1), (33, 65, 2), (300, 1000, 3), (257, 4100, 1)):
+        qkv = torch.randn(max(Sq, Sk), 3 * H * 128, generator=gen).to(torch.bfloat16).cuda()
+        q, k, v = qkv[:Sq, : H * 128], qkv[:Sk, H * 128 : 2 * H * 128], qkv[:Sk, 2 * H * 128 :]
+        ref = lib.attention(q, k, v, H)
+        got = lib.attention(q, k, v, H, variant=lib.ATTN_FAST)
+        assert_bf16_close(got, ref.cpu(), ulps=0.256, atol=8e-3, name=f"ping-pong vs default Sq={Sq} Sk={Sk} H={H}")
+        vt = lib.transpose_heads(v, H)
+        want = torch.zeros_like(vt)
+        want[:, :, :Sk] = v.reshape(Sk, H, 128).permute(1, 2, 0)
+        assert torch.equal(vt, want)
+
+
 # ---------------------------------------------------------------------------- oracle on seeded inputs
 @pytest.mark.parametrize("M,K,N", [(1280, 1536, 1536), (1280, 1536, 8960), (333, 8960, 1536), (1, 256, 1536), (512, 4096, 1536), (700, 1536, 64)])
 def test_gemm_vs_oracle(lib, M, K, N):

@@ -631,6 +631,27 @@ static void ref_attn(const std::vector<uint16_t>& q, const std::vector<uint16_t>
     }
 }
 
+// variant 11 = pre-transposed V path (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); everything else goes to the variant entry
+struct AttnVt {
+  DevBuf<uint16_t>* vt = nullptr;
+  int64_t ldvt = 0;
+  ~AttnVt() { delete vt; }
+  void prepare(const void* v, int64_t ldv, int64_t Sk, int H) {
+    ldvt = (Sk + 63) / 64 * 64;
+    delete vt;
+    vt = new DevBuf<uint16_t>((size_t)H * 128 * ldvt);
+    X2V_OKAY(x2v_transpose_heads_bf16(v, ldv, vt->p, ldvt, Sk, H, nullptr));
+  }
+};
+static void attn_any(int variant, AttnVt& t, const void* q, const void* k, const void* v, void* o, int64_t Sq, int64_t Sk, int H) {
+  if (variant >= 11 && variant <= 18) {  // 11: in-phase v6; 12: the _vt default (v8 ping-pong); 13..15: v8 A/B kinds 2..4; 17/18: timing probes
+    const int kind = variant == 11 ? 1 : variant == 12 ? 0 : variant - 11;
+    X2V_OKAY(x2v_attn_fwd_bf16_vt(q, H * 128, k, H * 128, t.vt->p, t.ldvt, o, H * 128, Sq, Sk, H, 128, 0.f, kind << 1, nullptr));
+  }
+  else
+    X2V_OKAY(x2v_attn_fwd_bf16_variant(q, H * 128, k, H * 128, v, H * 128, o, H * 128, Sq, Sk, H, 128, 0.f, variant, nullptr));
+}
+
 static void run_attn() {
   Rng rng(11);
   struct Shape {
@@ -645,10 +666,11 @@ static void run_attn() {
     DevBuf<uint16_t> dq(q), dk(k), dv(v), dout((size_t)sh.Sq * sh.H * 128);
     std::vector<float> ref;
     ref_attn(q, k, v, sh.Sq, sh.Sk, sh.H, ref);
-    for (int variant = 0; variant <= 10; ++variant) {
+    AttnVt vt;
+    vt.prepare(dv.p, sh.H * 128, sh.Sk, sh.H);
+    for (int variant = 0; variant <= 15; ++variant) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
-      X2V_OKAY(x2v_attn_fwd_bf16_variant(dq.p, sh.H * 128, dk.p, sh.H * 128, dv.p, sh.H * 128, dout.p, sh.H * 128, sh.Sq, sh.Sk, sh.H, 128, 0.f, variant,
-                                         nullptr));
+      attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, sh.Sq, sh.Sk, sh.H);
       HIP_OK(hipDeviceSynchronize());
       char name[160];
       snprintf(name, sizeof name, "attn Sq=%lld Sk=%lld H=%d variant=%d", (long long)sh.Sq, (long long)sh.Sk, sh.H, variant);
@@ -671,9 +693,11 @@ static void run_attn() {
     DevBuf<uint16_t> dq(q), dk(k), dv(v), dout((size_t)S * H * 128);
     std::vector<float> ref;
     ref_attn(q, k, v, S, S, H, ref);
-    for (int variant : {6, 8, 9, 10}) {
+    AttnVt vt;
+    vt.prepare(dv.p, H * 128, S, H);
+    for (int variant : {6, 8, 9, 10, 11, 12, 13, 14, 15}) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
-      X2V_OKAY(x2v_attn_fwd_bf16_variant(dq.p, H * 128, dk.p, H * 128, dv.p, H * 128, dout.p, H * 128, S, S, H, 128, 0.f, variant, nullptr));
+      attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, S, S, H);
       HIP_OK(hipDeviceSynchronize());
       char name[160];
       snprintf(name, sizeof name, "attn anti-aligned keys + late spike variant=%d", variant);
@@ -929,12 +953,16 @@ static void run_bench(bool big) {
     fill_random(q, rng, 1.f);
     fill_random(k, rng, 1.f);
     fill_random(v, rng, 1.f);
-    for (int variant : {6, 9, 10}) {
+    AttnVt vt;
+    vt.prepare(v.p, a.H * 128, a.Sk, a.H);
+    {
+      double ms = time_ms(5, [&] { X2V_OKAY(x2v_transpose_heads_bf16(v.p, a.H * 128, vt.vt->p, vt.ldvt, a.Sk, a.H, nullptr)); });
+      printf("BENCH transpose_heads %-40s %9.3f ms  %8.1f GB/s\n", a.name, ms, 4.0 * a.Sk * a.H * 128 / ms / 1e6);
+    }
+    for (int variant : {6, 9, 11, 12}) {
       const double flop = 4.0 * a.Sq * a.Sk * a.H * 128;
       const int iters = flop > 2e13 ? 1 : 5;
-      double ms = time_ms(iters, [&] {
-        X2V_OKAY(x2v_attn_fwd_bf16_variant(q.p, a.H * 128, k.p, a.H * 128, v.p, a.H * 128, o.p, a.H * 128, a.Sq, a.Sk, a.H, 128, 0.f, variant, nullptr));
-      });
+      double ms = time_ms(iters, [&] { attn_any(variant, vt, q.p, k.p, v.p, o.p, a.Sq, a.Sk, a.H); });
       const double tf = flop / (ms * 1e-3) / 1e12;
       printf("BENCH attn variant=%d %-40s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)\n", variant, a.name, ms, tf, tf / 25.0);
     }
@@ -973,7 +1001,9 @@ static void run_single(int argc, char** argv) {
     fill_random(q, rng, 1.f);
     fill_random(k, rng, 1.f);
     fill_random(v, rng, 1.f);
-    double ms = time_ms(iters, [&] { X2V_OKAY(x2v_attn_fwd_bf16_variant(q.p, H * 128, k.p, H * 128, v.p, H * 128, o.p, H * 128, S, S, H, 128, 0.f, variant, nullptr)); });
+    AttnVt vt;
+    vt.prepare(v.p, H * 128, S, H);
+    double ms = time_ms(iters, [&] { attn_any(variant, vt, q.p, k.p, v.p, o.p, S, S, H); });
     printf("pattn variant=%d S=%lld H=%d: %.3f ms %.1f TFLOP/s\n", variant, (long long)S, H, ms, 4.0 * S * S * H * 128 / ms / 1e9);
   } else {
     const int64_t M = atoll(argv[2]);
