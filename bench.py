@@ -217,7 +217,7 @@ def main():
     flop_cross = 4.0 * s_local * dims["text_len"] * dims["num_heads"] * 128
     n_self, n_cross = timer.count("self"), timer.count("cross")
     ms_self, ms_cross = timer.total_ms("self"), timer.total_ms("cross")
-    # roofline object = the self-attention launches of the dominant kernel (x2v::attn_fwd_v3_kernel: 99 % of the attention
+    # roofline object = the self-attention launches of the dominant kernel (x2v::attn_fwd_v8_kernel: 99 % of the attention
     # FLOPs, 72 % of the step's); cross-attention runs a different instantiation and is reported beside it
     attn_ms = ms_self / max(n_self, 1)
     flop_launch = flop_self
@@ -258,7 +258,7 @@ def main():
             "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
         },
         "roofline": {
-            "kernel": "x2v::attn_fwd_v3_kernel<8, 8, true, true> (self-attention launches)",
+            "kernel": "x2v::attn_fwd_v8_kernel<8, 8, true, 1, 4, 0, true> (self-attention launches)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": BF16_MFMA_PEAK_TFLOPS,

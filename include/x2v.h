@@ -128,8 +128,8 @@ int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                               int64_t Sk, int H, int head_dim, float scale, int variant, void* stream);
 
-/* V [Sk, H*128] (token stride ldv) -> V^T [H][128][ldvt] with keys >= Sk zero-filled (ldvt % 64 == 0, ldvt >= Sk): the
- * operand layout of x2v_attn_fwd_bf16_vt. */
+/* V [Sk, H*128] (token stride ldv) -> V^T [H][ldvt/64][128][64] (per head and 64-key tile a contiguous [dv][key] block) with
+ * keys >= Sk zero-filled (ldvt % 64 == 0, ldvt >= Sk): the operand layout of x2v_attn_fwd_bf16_vt. */
 int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt, int64_t Sk, int H, void* stream);
 
 /* x2v_attn_fwd_bf16 on a pre-transposed V (x2v_transpose_heads_bf16): V^T is staged by LDS-DMA and read as plain

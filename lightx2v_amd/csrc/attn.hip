@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v6_kernel(const unsigned 
   const int head = blockIdx.y;
   const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
   const unsigned short* Kh = Kp + (int64_t)head * AT_D;
-  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;  // this head's V^T block: [128 dv rows][ldvt keys]
+  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;  // this head's V^T block: [ldvt/64 tiles][128 dv rows][64 keys]
 
   bf16x8_t qf[8];
   {
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v6_kernel(const unsigned 
 
   // K and V^T both by LDS-DMA through raw buffer loads: per-lane byte offsets are loop-invariant, the tile offset travels
   // in an SGPR (soffset); K rows past Sk read as zero (hardware bounds check), V^T is zero-padded to a tile multiple by the
-  // transpose kernel.  V^T [128 dv][ldvt keys] makes the PV A-operand a plain ds_read_b128 of 8 consecutive keys — no
+  // transpose kernel.  V^T tiles [128 dv][64 keys] (16 KiB contiguous each) make the PV A-operand a plain ds_read_b128 of 8 consecutive keys — no
   // transpose reads, no register staging, the same [rows][128 B] swizzled image as the GEMM tiles.
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
@@ -1080,14 +1080,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v6_kernel(const unsigned 
     const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
     k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
     const int vrow = (wid * KDMA + j) * 8 + (lane >> 3);  // dv row of the [128][128 B] tile; 8 rows per 1 KiB piece
-    v_voff[j] = (unsigned)(vrow * ldvt * 2) + (unsigned)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
+    v_voff[j] = (unsigned)(vrow * 128) + (unsigned)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
   }
 #define AT_DMA_K(T_, BUF_)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
       rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
 #define AT_DMA_V(T_, BUF_)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, v_voff[j], (unsigned)(T_) * (AT_KV * 2), 0, 0);
+      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, v_voff[j], (unsigned)(T_) * AT_K_BYTES, 0, 0);
 
   // K fragment offsets.  MFMA row i = fl reads key row perm(fl) = fl with bits 2 and 3 swapped, so that a half-wave's
   // accumulator registers hold 8 CONSECUTIVE keys per 16-key group (keys 16g + 8*hi + 0..7) — the k-order of a plain
@@ -1328,16 +1328,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   constexpr int NDW = DMA_LATE ? NW / 2 : NW;      // waves that issue
   constexpr int NPC = 16 / NDW;                    // pieces per issuing wave and operand
   const int wl = DMA_LATE ? (wid & (NW / 2 - 1)) : wid;
-  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_piece_bytes = (unsigned)(4 * NDW * ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * ldvt * 2);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_piece_bytes = (unsigned)(4 * NDW * ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * 128);
   const int krow_w = wl * 4 + (lane >> 4), vrow_w = wl * 8 + (lane >> 3);
   const unsigned k_voff = (unsigned)(krow_w * ldk * 2) + (unsigned)(((lane & 15) ^ (krow_w & 15)) << 4);
-  const unsigned v_voff = (unsigned)(vrow_w * ldvt * 2) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
+  const unsigned v_voff = (unsigned)(vrow_w * 128) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
 #define A8_DMA_K(T_, BUF_)                                                                                   \
   _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
       rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, k_voff, (unsigned)(T_) * k_tile_bytes + j * k_piece_bytes, 0, 0);
 #define A8_DMA_V(T_, BUF_)                                                                                   \
   _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (unsigned)(T_) * (AT_KV * 2) + j * v_piece_bytes, 0, 0);
+      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (unsigned)(T_) * AT_K_BYTES + j * v_piece_bytes, 0, 0);
 
   // fragment offsets (see v6): K rows read through the bit-2/bit-3 swap so a half-wave's P registers are 8 consecutive keys
   int kaddr[8], vaddr[4];
@@ -1532,8 +1532,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
 
 
 
-// V [Sk, H*128] (token stride ldv) -> V^T [H][128][ldvt] bf16 with keys >= Sk zero-filled up to ldvt (a multiple of 64).
-// 64 keys x 128 dv per block through LDS.
+// V [Sk, H*128] (token stride ldv) -> V^T [H][ldvt/64][128][64] bf16 (per head and 64-key tile a contiguous 16 KiB [dv][key] block: one
+// attention tile = one linear stream, like K's) with keys >= Sk zero-filled up to ldvt (a multiple of 64).  One tile per block, through LDS.
 __global__ __launch_bounds__(256) void transpose_heads_kernel(const unsigned short* __restrict__ V, int64_t ldv, unsigned short* __restrict__ VT, int64_t ldvt,
                                                               int64_t Sk) {
   __shared__ unsigned short tile[64][128 + 2];
@@ -1559,7 +1559,7 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const unsigned sho
     unsigned w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = (unsigned)tile[kc * 8 + 2 * e][dv] | ((unsigned)tile[kc * 8 + 2 * e + 1][dv] << 16);
-    *reinterpret_cast<uint4*>(VT + ((int64_t)head * 128 + dv) * ldvt + k0 + kc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(VT + (((int64_t)head * (ldvt >> 6) + blockIdx.x) * 128 + dv) * 64 + kc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 

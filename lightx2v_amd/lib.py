@@ -208,19 +208,20 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
 
 
 def transpose_heads(v, num_heads):
-    """v [Sk, H*128] (any token stride) → V^T [H, 128, ceil64(Sk)] with the key padding zero-filled: the operand of the
-    pre-transposed-V attention kernel."""
+    """v [Sk, H*128] (any token stride) → V^T [H, ceil(Sk/64), 128, 64] (per head and 64-key tile a contiguous [dv][key] block)
+    with the key padding zero-filled: the operand of the pre-transposed-V attention kernel."""
     v2 = _row2d(_bf16(v, "v"), "v")
     Sk = v2.shape[0]
     ldvt = (Sk + 63) // 64 * 64
-    vt = torch.empty((num_heads, 128, ldvt), dtype=torch.bfloat16, device=v.device)
+    vt = torch.empty((num_heads, ldvt // 64, 128, 64), dtype=torch.bfloat16, device=v.device)
     init()
     _check(_lib.x2v_transpose_heads_bf16(_p(v2), v2.stride(0), _p(vt), ldvt, Sk, num_heads, _stream()), "transpose_heads")
     return vt
 
 
-def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0):
-    """q [Sq, H*d] (or [Sq,H,d]), k/v [Sk, H*d]; any token stride (fused-QKV views are fine)."""
+def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, vt=None):
+    """q [Sq, H*d] (or [Sq,H,d]), k/v [Sk, H*d]; any token stride (fused-QKV views are fine).
+    variant ATTN_FAST runs on V^T: pass `vt` (transpose_heads(v, H)) or let this call transpose v."""
 
     def as2d(t, name):
         if t.dim() == 3:
@@ -234,9 +235,12 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0):
     out2 = torch.empty((Sq, num_heads * head_dim), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(out, "out")
     init()
     if (variant & 0xFF) == ATTN_FAST:
-        vt = transpose_heads(v2, num_heads)
+        if vt is None:
+            vt = transpose_heads(v2, num_heads)
+        elif vt.dtype != torch.bfloat16 or not vt.is_cuda or not vt.is_contiguous() or tuple(vt.shape) != (num_heads, (Sk + 63) // 64, 128, 64):
+            raise X2VError(f"attention: vt must be the contiguous bf16 [H, ceil(Sk/64), 128, 64] tensor of transpose_heads, got {tuple(vt.shape)}")
         _check(
-            _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[2], _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
+            _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[1] * 64, _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
                                       1 if (variant & ATTN_Q_PRESCALED) else 0, _stream()),
             "attn_fwd_vt",
         )

