@@ -351,10 +351,56 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
     print("hunyuan_tiny.safetensors:", len(out), "tensors; noise_pred", tuple(out["noise_pred"].shape), out["noise_pred"].dtype)
 
 
+CONVERTER_DIMS = dict(dim=64, ffn_dim=128, num_heads=1, num_layers=2, text_len=8, text_dim=64)
+CONVERTER_CASES = {
+    "fp8_by_block": dict(linear_dtype="torch.float8_e4m3fn", save_by_block=True, chunk_size=100),
+    "int8_chunked": dict(linear_dtype="torch.int8", save_by_block=False, chunk_size=20),
+}
+
+
+def gen_converter():
+    """Checkpoint-format fixture: the reference's own converter (tools/convert/converter.py::convert_weights, driven through its
+    argparse namespace exactly as `main()` builds it, :668-707) quantising a small fp32 Wan checkpoint to e4m3 per-block files and to
+    int8 chunk files.  Every tensor of every output file is stored as `<case>/<file>/<key>`, the index json as metadata.
+    (qtorch is absent: oracle/ref_shims/qtorch restates float_quantize(4, 3, nearest), see there.)"""
+    import argparse
+    import importlib.util
+    import json
+    import tempfile
+
+    from safetensors import safe_open
+
+    ref_import.patch_and_import()
+    spec = importlib.util.spec_from_file_location("ref_converter", os.path.join(ref_import.REFERENCE_ROOT, "tools", "convert", "converter.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    src = synth.synth_wan_weights(CONVERTER_DIMS, seed=11, dtype=torch.float32)
+    out, meta = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "src"))
+        save_file({k: v.contiguous() for k, v in src.items()}, os.path.join(tmp, "src", "model.safetensors"))
+        for case, c in CONVERTER_CASES.items():
+            args = argparse.Namespace(
+                source=os.path.join(tmp, "src"), output=os.path.join(tmp, case), output_ext=".safetensors", output_name="converted", direction=None,
+                chunk_size=c["chunk_size"], model_type="wan_dit", save_by_block=c["save_by_block"], quantized=True, bits=8, device="cpu",
+                linear_dtype=eval(c["linear_dtype"]), non_linear_dtype=torch.float32, lora_path=None, lora_alpha=[1.0], copy_no_weight_files=False,
+                key_idx=2, target_keys=["self_attn", "cross_attn", "ffn"], ignore_key=None,
+            )
+            conv.convert_weights(args)
+            with open(os.path.join(args.output, "diffusion_pytorch_model.safetensors.index.json")) as fh:
+                meta[case] = json.dumps(json.load(fh), sort_keys=True)
+            for name in sorted(f for f in os.listdir(args.output) if f.endswith(".safetensors")):
+                with safe_open(os.path.join(args.output, name), framework="pt") as fh:
+                    for k in fh.keys():
+                        out[f"{case}/{name}/{k}"] = fh.get_tensor(k).clone()
+    save_file(out, os.path.join(GOLDEN, "converter_tiny.safetensors"), metadata=meta)
+    print("converter fixture:", len(out), "tensors")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache"]
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "converter"]
     if "ops" in which:
         gen_ops()
     if "model" in which:
@@ -367,3 +413,5 @@ if __name__ == "__main__":
         gen_hunyuan()
     if "teacache" in which:
         gen_teacache()
+    if "converter" in which:
+        gen_converter()

@@ -162,3 +162,46 @@ def test_teacache_matches_reference_decisions_and_latents():
         assert [int(c) for c in sch.caching_records] == g[f"{tag}_records_cond"].tolist(), tag
         assert [int(c) for c in sch.caching_records_2] == g[f"{tag}_records_uncond"].tolist(), tag
         assert max(errs) <= 5e-2, (tag, errs)
+
+
+def test_quantized_checkpoint_roundtrip_forward(tmp_path):
+    """a bf16 checkpoint directory converted to the reference's e4m3 per-block layout, read back through the
+    config-driven loader and run through the fp8 operator class gives (a) bit-identical results to the same quantised tensors handed
+    over in memory, (b) a forward within fp8 tolerance of the bf16 model's."""
+    from safetensors.torch import save_file
+
+    from lightx2v_amd import checkpoint as ck
+    from lightx2v_amd import scheduler, synth, wan
+
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wl = synth.WORKLOADS["wan-tiny"]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    src, out = tmp_path / "bf16", tmp_path / "bf16" / "fp8"
+    src.mkdir()
+    save_file({k: v.contiguous() for k, v in wd.items()}, str(src / "model.safetensors"))
+    ck.convert_checkpoint(str(src), str(out), model_type="wan_dit", quantized=True, linear_dtype=torch.float8_e4m3fn, non_linear_dtype=torch.bfloat16,
+                          save_by_block=True)
+    mm = {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip"}
+    cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=4, mm_config=mm)
+    loaded = ck.load_for_config(str(src), cfg, device="cuda")  # default dit_quantized_ckpt = <model_path>/fp8 (model.py:38-40)
+    assert loaded["blocks.0.ffn.0.weight"].dtype == torch.float8_e4m3fn and loaded["blocks.0.ffn.0.weight_scale"].shape == (dims["ffn_dim"], 1)
+    in_mem = ck.quantize_model({k: v.clone() for k, v in wd.items()}, **{k: ck.MODEL_TYPE_KEYS["wan_dit"][k] for k in ("target_keys", "key_idx", "ignore_key")},
+                               non_linear_dtype=torch.bfloat16)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+
+    def forward(cfg_, weights):
+        model = wan.WanModel(cfg_, weights)
+        sch = scheduler.WanScheduler(cfg_, device="cuda")
+        sch.prepare(latents=lat)
+        model.set_scheduler(sch)
+        sch.step_pre(0)
+        model.infer(inputs)
+        return sch.noise_pred.float().cpu()
+
+    a = forward(cfg, loaded)
+    b = forward(cfg, _to_dev(in_mem))
+    assert torch.equal(a, b), "checkpoint round trip changed the quantised tensors"
+    ref = forward(wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=4), _to_dev(wd))
+    assert_rel(a, ref, 6e-2, "fp8 checkpoint forward vs bf16 forward")
+    assert rel_l2(a, ref) > 1e-4  # it really is the quantised path
