@@ -157,16 +157,22 @@ int x2v_gemm_fp8_variant(const void* xq, int64_t ldx, const float* sx, const voi
 /* MXFP8 (OCP microscaling) activation / weight quantisation — replaces lightx2v_kernel.gemm.scaled_fp8_quant
  * (lightx2v_kernel/python/lightx2v_kernel/gemm.py:73-83, csrc/gemm/mxfp8_quant_kernels_sm120.cu:139-196): per 32 consecutive K
  * elements one e8m0 scale = the smallest power of two >= max|x|/448, elements = e4m3fn_rne(x / scale).
- * x bf16 [M,K]; q bytes [M,K] (ld = ldq); scales bytes [M, K/32] row-major (ld = lds) — the layout x2v_gemm_mxfp8 consumes (the
- * reference's 128x4 swizzle is the sm120 tensor-core operand format, not part of the numerical contract).  K % 32 == 0. */
-int x2v_quant_mxfp8_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int64_t M, int K, void* stream);
+ * x bf16 [M,K]; q bytes [M,K] (ld = ldq); scales: bytes [K/128][M][4] — K-tile major, row, the 4 k blocks of that K-tile: the
+ * layout x2v_gemm_mxfp8 consumes (as the reference's 128x4 swizzle is the sm120 tensor core's; logical element (m, kb) sits at
+ * ((kb/4)*M + m)*4 + kb%4).  K % 128 == 0. */
+int x2v_quant_mxfp8_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t M, int K, void* stream);
 
 /* y[M,N] = alpha * (deq(a)[M,K] . deq(b)[N,K]^T) + bias[n] → bf16, deq = e4m3 element * 2^(scale byte - 127) of its row and
  * 32-wide k block — replaces lightx2v_kernel.gemm.cutlass_scaled_mxfp8_mm (gemm.py:93-97,
- * csrc/gemm/mxfp8_scaled_mm_kernels_sm120.cu:60-66,150-160).  alpha: device pointer to one fp32 (NULL = 1), bias bf16 [N] or NULL.
+ * csrc/gemm/mxfp8_scaled_mm_kernels_sm120.cu:60-66,150-160).  sa [K/128][M][4], sb [K/128][N][4] as written by
+ * x2v_quant_mxfp8_bf16; alpha: device pointer to one fp32 (NULL = 1), bias bf16 [N] or NULL.
  * Runs on v_mfma_scale_f32_32x32x64_f8f6f4 with the block scales applied by the matrix instruction.  K % 128 == 0, N % 8 == 0. */
-int x2v_gemm_mxfp8(const void* a, int64_t lda, const void* sa, int64_t ldsa, const void* b, int64_t ldb, const void* sb, int64_t ldsb, const void* bias,
-                   const float* alpha, void* y, int64_t ldy, int64_t M, int N, int K, void* stream);
+int x2v_gemm_mxfp8(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
+                   int64_t ldy, int64_t M, int N, int K, void* stream);
+
+/* Same with a kernel selector: 0 = automatic (as x2v_gemm_mxfp8), 1 = 128x128-tile kernel, 2 = 256x256-tile ping-pong kernel. */
+int x2v_gemm_mxfp8_variant(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha,
+                           void* y, int64_t ldy, int64_t M, int N, int K, int variant, void* stream);
 
 /* Timestep sinusoid: y[n, dim] bf16 = [cos(t*f_j) | sin(t*f_j)], f_j = 10000^(-j/(dim/2)) computed in
  * float64 then rounded — replaces sinusoidal_embedding_1d (wan/infer/utils.py:161-172).  t: int64 [n]. */

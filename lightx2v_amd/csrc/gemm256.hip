@@ -39,14 +39,16 @@ constexpr int T_LDS_BYTES = 256 * T_EPI_LD; // 135168 >= 8 * T_HALF_BYTES
 
 typedef __attribute__((address_space(3))) void* t_lds_ptr_t;
 
-template <bool FP8, int EPI, int LEAD, int KW, int SCHED>
+template <bool FP8, int EPI, int LEAD, int KW, int SCHED, bool MX>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict__ A, int64_t lda_bytes, const char* __restrict__ W, int64_t ldw_bytes,
                                                          const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y, int64_t ldy, int64_t M,
                                                          int N, int nk, const unsigned short* __restrict__ resid, int64_t ldr,
                                                          const unsigned short* __restrict__ gate, const float* __restrict__ sx,
-                                                         const float* __restrict__ sw, int ntm, int ntn, int gm_tiles) {
+                                                         const float* __restrict__ sw, int ntm, int ntn, int gm_tiles,
+                                                         const unsigned* __restrict__ SA, const unsigned* __restrict__ SB) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(LEAD >= KW + 3 && LEAD <= 7, "see the hazard accounting in the header comment");
+  static_assert(!MX || (FP8 && EPI == X2V_EPI_NONE && SCHED == 0), "MX: block-scaled fp8, plain epilogue (alpha, bias)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,15 +95,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #define T_ISSUE(J_, SLOT_, KOFF_) { T_ISSUE1(J_, SLOT_, KOFF_, 0) T_ISSUE1(J_, SLOT_, KOFF_, 1) }
 
   // ---- fragment read addresses: row (32-row block base + fl), 16-byte chunk index kpart(ks) ^ lanepart
-  //      bf16: step ks (K=16) reads chunk ks*2+fh; fp8: MFMA s (K=64) reads chunks s*4+fh*2+{0,1} (ks = s*2+e).
-  //      A and B use the same (lane, element) -> k map, which is all an MFMA requires.
+  //      bf16: step ks (K=16) reads chunk ks*2+fh; fp8: MFMA s (K=64) reads chunks s*4+fh and s*4+2+fh (ks = s*2+e) — the
+  //      instruction's own k order (first 16 bytes of a lane = k fh*16.., last 16 = k 32+fh*16..), which matters once the
+  //      hardware applies block scales (MX); with unit scales any map shared by A and B would do.
   int rd_a[4], rd_b[4];
   {
     const int swz = (fl >> 1) & 7;
-    const int lp = (FP8 ? (fh << 1) : fh) ^ swz;
+    const int lp = fh ^ swz;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int kp = FP8 ? (((ks >> 1) << 2) | (ks & 1)) : (ks << 1);
+      const int kp = FP8 ? (((ks >> 1) << 2) | ((ks & 1) << 1)) : (ks << 1);
       const int o = fl * 128 + ((lp ^ kp) << 4);
       rd_a[ks] = o + wr * 4096;
       rd_b[ks] = o + wc * 4096;
@@ -116,6 +119,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   i32x4_t xa[2][4], wb0[4], wb1[4];
+
+  // ---- MX block scales: per operand row and K-tile one dword = the 4 e8m0 bytes of its 32-wide k blocks, tables [K/128][rows]
+  //      (mx.hip).  A lane needs the dwords of its 4 x rows (mi) and 2 W rows (nj) — 32 consecutive rows per load = one 128-byte
+  //      line; they are fetched one K-tile ahead by plain buffer loads issued in phase 0 BEFORE that phase's DMA pair, so the counted
+  //      vmcnt waits stay exact: phases 0..KW-1 allow NSC more loads in flight.  Lanes of the upper half (k block 2s+1) shift their
+  //      dword down one byte so that opsel = 2s selects the right byte in both halves.
+  constexpr int NSC = MX ? 6 : 0;
+  unsigned sx_cur[4] = {0, 0, 0, 0}, sw_cur[2] = {0, 0}, sx_nxt[4] = {0, 0, 0, 0}, sw_nxt[2] = {0, 0};
+  __amdgpu_buffer_rsrc_t rsa = ra, rsb = rw;
+  unsigned sa_voff = 0, sb_voff = 0;
+  if constexpr (MX) {
+    // whole tables behind the descriptors; rows of a partial last tile read a neighbour's scales (their outputs are never stored) or,
+    // past the end of the table, zero
+    rsa = __builtin_amdgcn_make_buffer_rsrc((void*)SA, 0, (unsigned)((int64_t)nk * M * 4), 0x00020000);
+    rsb = __builtin_amdgcn_make_buffer_rsrc((void*)SB, 0, (unsigned)((int64_t)nk * N * 4), 0x00020000);
+    sa_voff = (unsigned)((m0 + wr * 32 + fl) * 4);
+    sb_voff = (unsigned)((n0 + wc * 32 + fl) * 4);
+  }
+#define T_SC_LOAD(T_)                                                                                                          \
+  {                                                                                                                            \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_)                                                                        \
+      sx_nxt[mi_] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsa, sa_voff, (unsigned)((int64_t)(T_) * M * 4) + (unsigned)(mi_ * 256), 0); \
+    _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_)                                                                        \
+      sw_nxt[nj_] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsb, sb_voff, (unsigned)((int64_t)(T_) * N * 4) + (unsigned)(nj_ * 512), 0); \
+  }
+#define T_SC_ADOPT()                                                                                                           \
+  {                                                                                                                            \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < 4; ++mi_) sx_cur[mi_] = sx_nxt[mi_] >> (fh * 8);                                 \
+    _Pragma("unroll") for (int nj_ = 0; nj_ < 2; ++nj_) sw_cur[nj_] = sw_nxt[nj_] >> (fh * 8);                                 \
+  }
 
   const int total = nk * 4;  // half-tiles in this tile's K loop
 
@@ -140,9 +173,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     constexpr int kOne = 0x7f7f7f7f; /* e8m0 2^0 block scales */                                                               \
     _Pragma("unroll") for (int idx_ = 0; idx_ < 4; ++idx_) {                                                                   \
       const int s_ = idx_ >> 1, i_ = idx_ & 1;                                                                                 \
-      acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                                 \
-          __builtin_shufflevector(WB_[2 * s_], WB_[2 * s_ + 1], 0, 1, 2, 3, 4, 5, 6, 7),                                       \
-          __builtin_shufflevector(xa[i_][2 * s_], xa[i_][2 * s_ + 1], 0, 1, 2, 3, 4, 5, 6, 7), acc[(MI0_) + i_][NJ_], 0, 0, 0, kOne, 0, kOne); \
+      const i32x8_t wf_ = __builtin_shufflevector(WB_[2 * s_], WB_[2 * s_ + 1], 0, 1, 2, 3, 4, 5, 6, 7);                       \
+      const i32x8_t xf_ = __builtin_shufflevector(xa[i_][2 * s_], xa[i_][2 * s_ + 1], 0, 1, 2, 3, 4, 5, 6, 7);                 \
+      if constexpr (!MX)                                                                                                       \
+        acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf_, xf_, acc[(MI0_) + i_][NJ_], 0, 0, 0, kOne, 0, kOne); \
+      else if (s_ == 0)                                                                                                        \
+        acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf_, xf_, acc[(MI0_) + i_][NJ_], 0, 0, 0, (int)sw_cur[NJ_], 0, (int)sx_cur[(MI0_) + i_]); \
+      else                                                                                                                     \
+        acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf_, xf_, acc[(MI0_) + i_][NJ_], 0, 0, 2, (int)sw_cur[NJ_], 2, (int)sx_cur[(MI0_) + i_]); \
       if (SCHED == 1 && (idx_ == 0 || idx_ == 2)) {                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                     \
         if (DO_) { if (idx_ == 0) { T_ISSUE1(J_, SLOT_, KOFF_, 0) } else { T_ISSUE1(J_, SLOT_, KOFF_, 1) } }                   \
@@ -167,6 +205,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
       T_RD(wb0, ((TB_) ^ 1) * 4 + 0, rd_b, 0)                                                                                  \
     }                                                                                                                          \
     const bool live_ = (CHK_) ? (4 * t + (Q_) + LEAD < total) : true;                                                          \
+    if constexpr (MX && (Q_) == 0) {                                                                                           \
+      if ((CHK_) ? (t + 1 < nk) : true) T_SC_LOAD(t + 1)                                                                        \
+    }                                                                                                                          \
     if (SCHED == 0 && live_) T_ISSUE(((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, (t + ((Q_) + LEAD) / 4) * 128)          \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
     __builtin_amdgcn_s_barrier();                                                                                              \
@@ -183,8 +224,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     __builtin_amdgcn_s_setprio(0);                                                                                             \
     T_PIN(((Q_) >> 1) * 2, (Q_) == 1 || (Q_) == 3)                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
-    if (live_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KW) : "memory");                                                   \
+    /* steady state: the newest KW phases' loads may stay in flight = 2 DMA pieces each, plus the NSC scale loads of phase 0 */ \
+    if (live_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KW + ((CHK_) == 0 && (Q_) < KW ? NSC : 0)) : "memory");            \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
+    if constexpr (MX && (Q_) == 3) T_SC_ADOPT()                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
   }
@@ -193,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   {
     const int t = 0;
     (void)t;
+    if constexpr (MX) T_SC_LOAD(0)  // oldest loads in flight: complete after the prologue wait below
 #pragma unroll
     for (int g = 0; g < LEAD; ++g)
       if (g < total) T_ISSUE(g & 3, g & 7, (g >> 2) * 128)
@@ -200,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     // wr = 0 waves, which see no later wait of the wr = 1 waves) has landed too
     if (total >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MX) T_SC_ADOPT()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     T_RD(wb0, 0, rd_b, 0)
@@ -237,6 +282,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #undef T_RD
 #undef T_ISSUE
 #undef T_ISSUE1
+#undef T_SC_LOAD
+#undef T_SC_ADOPT
 
   // ---- epilogue phase 1: acc (+scales, bias, activation) -> bf16 -> LDS [256][T_EPI_LD]
   //      acc[mi][nj][r]: tile row mi*64 + wr*32 + fl, tile col nj*128 + wc*32 + (r&3) + 8*(r>>2) + 4*fh
@@ -252,9 +299,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
       gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
       bv[nj][g] = make_uint2(0u, 0u);
       if (bias != nullptr) bv[nj][g] = *reinterpret_cast<const uint2*>(bias + gn);
-      if constexpr (FP8) swv[nj][g] = *reinterpret_cast<const float4*>(sw + gn);
+      if constexpr (FP8 && !MX) swv[nj][g] = *reinterpret_cast<const float4*>(sw + gn);
     }
-  if constexpr (FP8) {
+  float mx_alpha = 1.0f;
+  if constexpr (MX) {
+    if (sx != nullptr) mx_alpha = *sx;  // MX: `sx` carries the device pointer to alpha (x2v_gemm_mxfp8)
+  } else if constexpr (FP8) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       int64_t gmr = m0 + mi * 64 + wr * 32 + fl;
@@ -273,7 +323,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
         float vv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) vv[e] = acc[mi][nj][4 * g + e];
-        if constexpr (FP8) {
+        if constexpr (MX) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] *= mx_alpha;
+        } else if constexpr (FP8) {
           vv[0] = vv[0] * sxv[mi] * swv[nj][g].x;
           vv[1] = vv[1] * sxv[mi] * swv[nj][g].y;
           vv[2] = vv[2] * sxv[mi] * swv[nj][g].z;
@@ -328,21 +381,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #endif
 }
 
-template <bool FP8, int EPI, int SCHED>
+template <bool FP8, int EPI, int SCHED, bool MX = false>
 static int launch_gemm256_s(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N,
-                          int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st) {
+                          int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st,
+                          const void* sa = nullptr, const void* sb = nullptr) {
   constexpr int LEAD = 6, KW = 3;
   const int ntm = (int)((M + T_M - 1) / T_M), ntn = (N + T_N - 1) / T_N;
   static bool attr_set = false;  // idempotent; racing threads set the same value
   if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)gemm256_kernel<FP8, EPI, LEAD, KW, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES),
+    int rc = check_hip(hipFuncSetAttribute((const void*)gemm256_kernel<FP8, EPI, LEAD, KW, SCHED, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES),
                        "gemm256 attr");
     if (rc != X2V_OK) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<FP8, EPI, LEAD, KW, SCHED>), dim3((unsigned)ntm * (unsigned)ntn), dim3(512), T_LDS_BYTES, st, (const char*)x, ldx_bytes,
+  hipLaunchKernelGGL((gemm256_kernel<FP8, EPI, LEAD, KW, SCHED, MX>), dim3((unsigned)ntm * (unsigned)ntn), dim3(512), T_LDS_BYTES, st, (const char*)x, ldx_bytes,
                      (const char*)w, ldw_bytes, (const unsigned short*)bias, (unsigned short*)y, ldy, M, N, nk, (const unsigned short*)resid, ldr,
-                     (const unsigned short*)gate, sx, sw, ntm, ntn, gm_tiles);
+                     (const unsigned short*)gate, sx, sw, ntm, ntn, gm_tiles, (const unsigned*)sa, (const unsigned*)sb);
   X2V_LAUNCH_CHECK("gemm256 launch");
   return X2V_OK;
 }
@@ -372,6 +426,12 @@ int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, i
     default: set_error("gemm: unknown epilogue %d", epilogue); return X2V_E_ARG;
   }
 }
+// MXFP8 (mx.hip): e4m3 operands with e8m0 block-scale tables [K/128][rows][4]; alpha = device pointer or null.  Arguments validated by the caller.
+int gemm256_mx_dispatch(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
+                        int64_t ldy, int64_t M, int N, int nk, hipStream_t st) {
+  return launch_gemm256_s<true, X2V_EPI_NONE, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+}
+
 template int gemm256_dispatch<false>(int, const void*, int64_t, const void*, int64_t, const void*, void*, int64_t, int64_t, int, int, const void*, int64_t,
                                      const void*, const float*, const float*, int, hipStream_t);
 template int gemm256_dispatch<true>(int, const void*, int64_t, const void*, int64_t, const void*, void*, int64_t, int64_t, int, int, const void*, int64_t,

@@ -3,9 +3,11 @@
 //   scaled_fp8_quant            lightx2v_kernel/python/lightx2v_kernel/gemm.py:73-83, csrc/gemm/mxfp8_quant_kernels_sm120.cu:139-196
 //   cutlass_scaled_mxfp8_mm     gemm.py:93-97, csrc/gemm/mxfp8_scaled_mm_kernels_sm120.cu:60-66,150-160  (D = alpha * A.B^T + bias[n], bf16)
 //
-// Scale layout: plain row-major bytes sc[row][K/32].  (The reference's [m/128][k/128][32][4][4] swizzle is the operand format of
-// the sm120 tensor core; v_mfma_scale_f32_32x32x64_f8f6f4 instead takes, per lane, the scale byte of that lane's operand row and
-// 32-wide k block from a VGPR — here one dword per row and 128-wide K-tile, i.e. 4 consecutive bytes of the row-major table.)
+// Scale layout: sc[K/128][rows][4] bytes — K-tile major, then operand row, then the 4 k blocks of that 128-wide K-tile.  Like the
+// reference's [m/128][k/128][32][4][4] swizzle (the operand format of the sm120 tensor core) it is the consumer's format:
+// v_mfma_scale_f32_32x32x64_f8f6f4 takes, per lane, the scale byte of that lane's operand row and 32-wide k block from a VGPR, so a
+// GEMM wave needs one dword per row and K-tile, and with this layout the 32 rows of a fragment are 128 contiguous bytes (one cache
+// line per load instead of 32 with a row-major [rows][K/32] table: 1.6-1.85 -> 2.4-2.7 PFLOP/s on the 14B shapes, profiles/r01_mxfp8_*).
 //
 // quant: HBM-bound — reads M*K bf16, writes M*K bytes + M*K/32 scale bytes (algorithmic bytes 3.03 per element).
 // GEMM:  MFMA-bound — 2*M*N*K FLOP per launch against the 5 PFLOP/s fp8 peak; the 128x128-tile / two-barrier structure of gemm.hip
@@ -29,11 +31,11 @@ __device__ __forceinline__ unsigned e8m0_ceil(float sf) {
 }
 
 __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const unsigned short* __restrict__ x, int64_t ldx, unsigned char* __restrict__ q, int64_t ldq,
-                                                          unsigned char* __restrict__ sc, int64_t lds, int64_t M, int K) {
+                                                          unsigned* __restrict__ sc, int64_t M, int K) {
   const int kc = K >> 3;  // 16-byte chunks per row
   const int64_t total = M * kc;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total + 3; id += (int64_t)gridDim.x * 256) {
-    // lanes of one scale block (4 consecutive ids) are always all in range or all out of range (kc % 4 == 0)
+    // the 16 lanes of one K-tile of one row (16 consecutive ids) are always all in range or all out of range (kc % 16 == 0)
     const bool ok = id < total;
     const int64_t row = ok ? id / kc : 0;
     const int c = ok ? (int)(id - row * kc) : 0;
@@ -56,7 +58,12 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const unsigned short* 
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
     *reinterpret_cast<uint2*>(q + row * ldq + c * 8) = make_uint2(lo, hi);
-    if ((c & 3) == 0) sc[row * lds + (c >> 2)] = (unsigned char)byte;
+    // the 4 scale bytes of a row's K-tile sit in lanes c, c+4, c+8, c+12 (16 lanes = 128 elements): gather them into one dword
+    unsigned dw = byte;
+    dw |= (unsigned)__shfl_down((int)byte, 4, 64) << 8;
+    dw |= (unsigned)__shfl_down((int)byte, 8, 64) << 16;
+    dw |= (unsigned)__shfl_down((int)byte, 12, 64) << 24;
+    if ((c & 15) == 0) sc[(int64_t)(c >> 4) * M + row] = dw;
   }
 }
 
@@ -72,8 +79,8 @@ typedef const __attribute__((address_space(1))) void* mx_gbl_ptr_t;
 __device__ __forceinline__ int mx_swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 // y[M,N] = alpha * (A[M,K] . B[N,K]^T) + bias[n], A/B e4m3 with per-(row, 32-k) e8m0 scales.  Same tile structure as gemm_kernel<true>.
-__global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const char* __restrict__ A, int64_t lda, const unsigned char* __restrict__ SA, int64_t ldsa,
-                                                            const char* __restrict__ B, int64_t ldb, const unsigned char* __restrict__ SB, int64_t ldsb,
+__global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const char* __restrict__ A, int64_t lda, const unsigned* __restrict__ SA,
+                                                            const char* __restrict__ B, int64_t ldb, const unsigned* __restrict__ SB,
                                                             const unsigned short* __restrict__ bias, const float* __restrict__ alpha_p,
                                                             unsigned short* __restrict__ Y, int64_t ldy, int64_t M, int N, int nk, int ntm, int ntn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,23 +139,23 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const char* __restri
     }
   // block scales: one dword per operand row and K-tile = the 4 scale bytes of its k blocks.  The instruction takes byte `opsel` of the
   // scale VGPR of every lane; lanes fh = 1 (k block s*2 + 1) shift their dword down by one byte so that opsel = 2 s serves both halves.
-  const unsigned char* sa_row[2];
-  const unsigned char* sb_row[2];
+  const unsigned* sa_row[2];
+  const unsigned* sb_row[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int64_t gm = m0 + wr * 64 + i * 32 + fl;
     gm = gm < M ? gm : M - 1;
     int gn = n0 + wc * 64 + i * 32 + fl;
     gn = gn < N ? gn : N - 1;
-    sa_row[i] = SA + gm * ldsa;
-    sb_row[i] = SB + (int64_t)gn * ldsb;
+    sa_row[i] = SA + gm;  // [K-tile][row] dwords
+    sb_row[i] = SB + gn;
   }
   const int sh = fh * 8;
   unsigned sa_cur[2], sb_cur[2], sa_nxt[2] = {0u, 0u}, sb_nxt[2] = {0u, 0u};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    sa_cur[i] = *reinterpret_cast<const unsigned*>(sa_row[i]) >> sh;
-    sb_cur[i] = *reinterpret_cast<const unsigned*>(sb_row[i]) >> sh;
+    sa_cur[i] = sa_row[i][0] >> sh;
+    sb_cur[i] = sb_row[i][0] >> sh;
   }
 
   f32x16_t acc[2][2];
@@ -168,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const char* __restri
       stage(cur ^ 1, kt + 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        sa_nxt[i] = *reinterpret_cast<const unsigned*>(sa_row[i] + (kt + 1) * 4);
-        sb_nxt[i] = *reinterpret_cast<const unsigned*>(sb_row[i] + (kt + 1) * 4);
+        sa_nxt[i] = sa_row[i][(int64_t)(kt + 1) * M];
+        sb_nxt[i] = sb_row[i][(int64_t)(kt + 1) * N];
       }
     }
     const char* base = smem + cur * MX_STAGE_BYTES;
@@ -236,33 +243,41 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const char* __restri
   }
 }
 
+// gemm256.hip: the 256x256-tile ping-pong kernel with hardware block scales (large shapes)
+int gemm256_mx_dispatch(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
+                        int64_t ldy, int64_t M, int N, int nk, hipStream_t st);
+
 }  // namespace x2v
 
 using namespace x2v;
 
-extern "C" __attribute__((visibility("default"))) int x2v_quant_mxfp8_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int64_t M,
-                                                                          int K, void* stream) {
+extern "C" __attribute__((visibility("default"))) int x2v_quant_mxfp8_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t M, int K,
+                                                                          void* stream) {
   X2V_REQUIRE(x && q && scales, X2V_E_ARG, "quant_mxfp8: null pointer");
-  X2V_REQUIRE(K > 0 && K % 32 == 0, X2V_E_SHAPE, "quant_mxfp8: K=%d must be a multiple of the 32-element scale block", K);
-  X2V_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K && lds >= K / 32 && aligned16(x) && ((uintptr_t)q % 8) == 0, X2V_E_ALIGN,
-              "quant_mxfp8: rows must be 16-byte (input) / 8-byte (output) aligned");
+  X2V_REQUIRE(K > 0 && K % 128 == 0, X2V_E_SHAPE, "quant_mxfp8: K=%d must be a multiple of 128 (4 scale blocks = one K-tile of the GEMM)", K);
+  X2V_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K && aligned16(x) && ((uintptr_t)q % 8) == 0 && ((uintptr_t)scales % 4) == 0, X2V_E_ALIGN,
+              "quant_mxfp8: rows must be 16-byte (input) / 8-byte (output) aligned, the scale table 4-byte aligned");
   if (M <= 0) return X2V_OK;
   const int64_t total = M * (K / 8);
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(quant_mxfp8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ldx, (unsigned char*)q, ldq,
-                     (unsigned char*)scales, lds, M, K);
+                     (unsigned*)scales, M, K);
   X2V_LAUNCH_CHECK("quant_mxfp8 launch");
   return X2V_OK;
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_gemm_mxfp8(const void* a, int64_t lda, const void* sa, int64_t ldsa, const void* b, int64_t ldb,
-                                                                    const void* sb, int64_t ldsb, const void* bias, const float* alpha, void* y, int64_t ldy,
-                                                                    int64_t M, int N, int K, void* stream) {
+static int gemm_mxfp8_impl(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
+                           int64_t ldy, int64_t M, int N, int K, int variant, void* stream) {
   X2V_REQUIRE(a && sa && b && sb && y, X2V_E_ARG, "gemm_mxfp8: null pointer");
   X2V_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 8 == 0, X2V_E_SHAPE, "gemm_mxfp8: M=%lld N=%d K=%d (K %% 128 == 0, N %% 8 == 0)", (long long)M, N, K);
-  X2V_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldsa % 4 == 0 && ldsb % 4 == 0 && ldsa >= K / 32 && ldsb >= K / 32 && ldy % 8 == 0 &&
-                  ldy >= N && aligned16(a) && aligned16(b) && aligned16(y) && ((uintptr_t)sa % 4) == 0 && ((uintptr_t)sb % 4) == 0,
-              X2V_E_ALIGN, "gemm_mxfp8: operand rows 16-byte aligned, scale rows 4-byte aligned");
+  X2V_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldy % 8 == 0 && ldy >= N && aligned16(a) && aligned16(b) && aligned16(y) &&
+                  ((uintptr_t)sa % 4) == 0 && ((uintptr_t)sb % 4) == 0,
+              X2V_E_ALIGN, "gemm_mxfp8: operand rows 16-byte aligned, scale tables 4-byte aligned");
+  X2V_REQUIRE((int64_t)(K / 128) * std::max<int64_t>(M, N) * 4 < (1ll << 32), X2V_E_SHAPE, "gemm_mxfp8: scale table of 4 GiB or more");
+  // same kernel choice as the other GEMMs (gemm.hip): the 256x256 ping-pong kernel when it fills the chip, else 128x128 tiles
+  const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+  const bool big = variant == 2 || (variant == 0 && tiles256 >= 192 && K / 128 >= 8 && lda < (1 << 24) && ldb < (1 << 24));
+  if (big) return gemm256_mx_dispatch(a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K / 128, (hipStream_t)stream);
   static bool attr_set = false;
   if (!attr_set) {
     int rc = check_hip(hipFuncSetAttribute((const void*)gemm_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES), "gemm_mxfp8 attr");
@@ -271,8 +286,22 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_mxfp8(const void*
   }
   const int ntm = (int)((M + MX_M - 1) / MX_M), ntn = (N + MX_N - 1) / MX_N;
   hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3((unsigned)ntm * (unsigned)ntn), dim3(256), MX_LDS_BYTES, (hipStream_t)stream, (const char*)a, lda,
-                     (const unsigned char*)sa, ldsa, (const char*)b, ldb, (const unsigned char*)sb, ldsb, (const unsigned short*)bias, alpha, (unsigned short*)y, ldy, M,
+                     (const unsigned*)sa, (const char*)b, ldb, (const unsigned*)sb, (const unsigned short*)bias, alpha, (unsigned short*)y, ldy, M,
                      N, K / 128, ntm, ntn);
   X2V_LAUNCH_CHECK("gemm_mxfp8 launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_mxfp8(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb,
+                                                                    const void* bias, const float* alpha, void* y, int64_t ldy, int64_t M, int N, int K,
+                                                                    void* stream) {
+  return gemm_mxfp8_impl(a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K, 0, stream);
+}
+
+// variant: 0 = automatic, 1 = 128x128-tile kernel, 2 = 256x256-tile ping-pong kernel (tests and A/B measurements)
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_mxfp8_variant(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb,
+                                                                            const void* bias, const float* alpha, void* y, int64_t ldy, int64_t M, int N, int K,
+                                                                            int variant, void* stream) {
+  X2V_REQUIRE(variant >= 0 && variant <= 2, X2V_E_ARG, "gemm_mxfp8: unknown variant %d", variant);
+  return gemm_mxfp8_impl(a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K, variant, stream);
 }

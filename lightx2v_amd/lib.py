@@ -40,8 +40,9 @@ PROTOTYPES = {
     "x2v_attn_fwd_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
-    "x2v_quant_mxfp8_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i32, _c_void_p],
-    "x2v_gemm_mxfp8": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p],
+    "x2v_quant_mxfp8_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
+    "x2v_gemm_mxfp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p],
+    "x2v_gemm_mxfp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p],
     "x2v_gemm_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_fp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
     "x2v_sinusoid_embed_bf16": [_c_void_p, _c_void_p, _i32, _i32, _c_void_p],
@@ -265,28 +266,41 @@ def quant_fp8_rowwise(x):
 
 
 def quant_mxfp8(x):
-    """bf16 [M, K] → (e4m3 [M, K], e8m0 scale bytes [M, K/32]) — see include/x2v.h::x2v_quant_mxfp8_bf16."""
+    """bf16 [M, K] → (e4m3 [M, K], e8m0 scale bytes [K/128, M, 4]) — see include/x2v.h::x2v_quant_mxfp8_bf16.
+    `mx_scales_rowmajor` turns the scale tensor into the logical [M, K/32] table."""
     x2 = _row2d(_bf16(x, "x"), "x")
     M, K = x2.shape
     q = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
-    sc = torch.empty((M, K // 32), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((max(K // 128, 1), M, 4), dtype=torch.uint8, device=x.device)
     init()
-    _check(_lib.x2v_quant_mxfp8_bf16(_p(x2), x2.stride(0), _p(q), q.stride(0), _p(sc), sc.stride(0), M, K, _stream()), "quant_mxfp8")
+    _check(_lib.x2v_quant_mxfp8_bf16(_p(x2), x2.stride(0), _p(q), q.stride(0), _p(sc), M, K, _stream()), "quant_mxfp8")
     return q, sc
 
 
-def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None):
-    """alpha * deq(a)[M,K] @ deq(b)[N,K]^T + bias → bf16 [M,N]; scales uint8/e8m0 [rows, K/32]; alpha: fp32 device tensor or None."""
+def mx_scales_rowmajor(sc):
+    """[K/128, rows, 4] (kernel layout) → logical [rows, K/32]."""
+    return sc.permute(1, 0, 2).reshape(sc.shape[1], -1)
+
+
+def mx_scales_tiled(sc_rm):
+    """logical [rows, K/32] → [K/128, rows, 4] (kernel layout)."""
+    rows, kb = sc_rm.shape
+    return sc_rm.reshape(rows, kb // 4, 4).permute(1, 0, 2).contiguous()
+
+
+def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None, variant=0):
+    """alpha * deq(a)[M,K] @ deq(b)[N,K]^T + bias → bf16 [M,N]; scales uint8/e8m0 [K/128, rows, 4] as produced by quant_mxfp8;
+    alpha: fp32 device tensor or None."""
     M, K = a.shape
     N = b.shape[0]
     for t, name in ((a, "a"), (b, "b")):
         if t.dtype not in (torch.float8_e4m3fn, torch.uint8) or not t.is_cuda or t.stride(1) != 1:
             raise X2VError(f"gemm_mxfp8: {name} must be a CUDA e4m3 (or raw uint8) matrix with unit inner stride")
-    for t, name in ((sa, "scales_a"), (sb, "scales_b")):
-        if t.element_size() != 1 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
-            raise X2VError(f"gemm_mxfp8: {name} must be a CUDA byte matrix [rows, K/32]")
-    if sa.shape != (M, K // 32) or sb.shape != (N, K // 32) or b.shape[1] != K:
-        raise X2VError(f"gemm_mxfp8: shapes a{tuple(a.shape)} sa{tuple(sa.shape)} b{tuple(b.shape)} sb{tuple(sb.shape)} do not agree")
+    for t, name, rows in ((sa, "scales_a", M), (sb, "scales_b", N)):
+        if t.element_size() != 1 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != (K // 128, rows, 4):
+            raise X2VError(f"gemm_mxfp8: {name} must be the contiguous CUDA byte tensor [K/128, {rows}, 4] of quant_mxfp8, got {tuple(t.shape)}")
+    if b.shape[1] != K or K % 128:
+        raise X2VError(f"gemm_mxfp8: shapes a{tuple(a.shape)} b{tuple(b.shape)} do not agree (K % 128 == 0)")
     if alpha is not None and (alpha.dtype != torch.float32 or not alpha.is_cuda):
         raise X2VError("gemm_mxfp8: alpha must be a float32 CUDA tensor")
     if bias is not None:
@@ -296,7 +310,7 @@ def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None):
     out2 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out is None else _row2d(out, "out")
     init()
     _check(
-        _lib.x2v_gemm_mxfp8(_p(a), a.stride(0), _p(sa), sa.stride(0), _p(b), b.stride(0), _p(sb), sb.stride(0), _p(bias), _p(alpha), _p(out2), out2.stride(0), M, N, K, _stream()),
+        _lib.x2v_gemm_mxfp8_variant(_p(a), a.stride(0), _p(sa), _p(b), b.stride(0), _p(sb), _p(bias), _p(alpha), _p(out2), out2.stride(0), M, N, K, variant, _stream()),
         "gemm_mxfp8",
     )
     return out2

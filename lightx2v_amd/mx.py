@@ -1,9 +1,10 @@
 """MXFP8 quantise + GEMM with the call signatures of the reference's `lightx2v_kernel.gemm` module
 (lightx2v_kernel/python/lightx2v_kernel/gemm.py:73-83 `scaled_fp8_quant`, :93-97 `cutlass_scaled_mxfp8_mm`), on gfx950's block-scaled
-MFMA.  One difference a caller can see: the scale tensor is the plain `[rows, K/32]` e8m0 table, not the reference's
-`[ceil128(rows), ceil4(K/32)]` sm120-swizzled int32 view — pass it straight back to the GEMM, as the reference's callers do.
+MFMA.  One difference a caller can see: the scale tensor is the `[K/128, rows, 4]` e8m0 table of this GEMM (K-tile major), not the
+reference's `[ceil128(rows), ceil4(K/32)]` sm120-swizzled int32 view — either way it is the consumer's format and callers pass it
+straight back to the GEMM (`lib.mx_scales_rowmajor` gives the logical [rows, K/32] table).  K must be a multiple of 128.
 
-    a_q, a_s = scaled_fp8_quant(activation)          # bf16 [m, k] -> e4m3 bytes [m, k], e8m0 [m, k/32]
+    a_q, a_s = scaled_fp8_quant(activation)          # bf16 [m, k] -> e4m3 bytes [m, k], e8m0 [k/128, m, 4]
     w_q, w_s = scaled_fp8_quant(weight)              # [n, k]
     y = cutlass_scaled_mxfp8_mm(a_q, w_q, a_s, w_s, alpha=alpha, bias=bias)   # bf16 [m, n]
 """

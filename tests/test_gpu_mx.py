@@ -15,7 +15,7 @@ def lib():
     return L
 
 
-@pytest.mark.parametrize("M,K", [(1, 32), (5, 96), (257, 1536), (1000, 5120), (64, 13824)])
+@pytest.mark.parametrize("M,K", [(1, 128), (5, 384), (257, 1536), (1000, 5120), (64, 13824)])
 def test_quant_bit_exact(lib, M, K):
     from oracle import mx_oracle as MX
 
@@ -26,18 +26,22 @@ def test_quant_bit_exact(lib, M, K):
         x[4, 32 : K if K < 64 else 64] = 448.0
     q, sc = lib.quant_mxfp8(x.cuda())
     rq, rs = MX.quant_mxfp8(x)
+    assert sc.shape == (K // 128, M, 4)
+    sc = lib.mx_scales_rowmajor(sc)
     assert torch.equal(sc.cpu(), rs), "scale bytes differ"
+    assert torch.equal(lib.mx_scales_tiled(rs.cuda()), lib.quant_mxfp8(x.cuda())[1])
     assert torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8)), "e4m3 elements differ"
     # strided input / output views (token stride larger than K)
     if K >= 64:
         big = torch.zeros(M, K + 64, dtype=torch.bfloat16)
         big[:, :K] = x
         q2, sc2 = lib.quant_mxfp8(big.cuda()[:, :K])
-        assert torch.equal(sc2.cpu(), rs) and torch.equal(q2.cpu().view(torch.uint8), rq.view(torch.uint8))
+        assert torch.equal(lib.mx_scales_rowmajor(sc2).cpu(), rs) and torch.equal(q2.cpu().view(torch.uint8), rq.view(torch.uint8))
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 128, 8), (130, 256, 136), (257, 1536, 1536), (512, 5120, 1280), (333, 1024, 72)])
-def test_gemm_vs_oracle(lib, M, K, N):
+@pytest.mark.parametrize("variant", [1, 2])  # 128x128-tile kernel / 256x256-tile ping-pong kernel (forced; 0 picks by shape)
+@pytest.mark.parametrize("M,K,N", [(1, 128, 8), (130, 256, 136), (257, 1536, 1536), (512, 5120, 1280), (333, 1024, 72), (700, 2176, 520)])
+def test_gemm_vs_oracle(lib, M, K, N, variant):
     """Same quantised operands on both sides: the only differences are fp32 accumulation order and the final bf16 rounding."""
     from oracle import mx_oracle as MX
     from tests.util import assert_bf16_close
@@ -54,9 +58,10 @@ def test_gemm_vs_oracle(lib, M, K, N):
     qw, sw = MX.quant_mxfp8(w)
     alpha = torch.tensor(0.75, dtype=torch.float32)
     ref = MX.gemm_mxfp8(qa, sa, qw, sw, alpha=0.75, bias=bias)
-    got = lib.gemm_mxfp8(qa.cuda(), sa.cuda(), qw.cuda(), sw.cuda(), alpha=alpha.cuda(), bias=bias.cuda())
+    sa_t, sw_t = lib.mx_scales_tiled(sa.cuda()), lib.mx_scales_tiled(sw.cuda())
+    got = lib.gemm_mxfp8(qa.cuda(), sa_t, qw.cuda(), sw_t, alpha=alpha.cuda(), bias=bias.cuda(), variant=variant)
     assert_bf16_close(got, ref, ulps=1, atol=1e-2 * ref.float().abs().mean().item(), bad_frac=1e-3, name=f"mxfp8 gemm {M}x{K}x{N}")
-    got1 = lib.gemm_mxfp8(qa.cuda(), sa.cuda(), qw.cuda(), sw.cuda())
+    got1 = lib.gemm_mxfp8(qa.cuda(), sa_t, qw.cuda(), sw_t, variant=variant)
     assert_bf16_close(got1, MX.gemm_mxfp8(qa, sa, qw, sw), ulps=1, atol=1e-2 * ref.float().abs().mean().item(), bad_frac=1e-3, name="mxfp8 gemm (no alpha/bias)")
 
 
@@ -69,8 +74,9 @@ def test_exact_on_lossless_inputs(lib):
     w[:, 128:256] *= 2.0**-10
     qa, sa = lib.quant_mxfp8(a.cuda())
     qw, sw = lib.quant_mxfp8(w.cuda())
-    y = lib.gemm_mxfp8(qa, sa, qw, sw)
-    assert torch.equal(y.float().cpu(), (a.float() @ w.float().T).to(torch.bfloat16).float())
+    for variant in (1, 2):
+        y = lib.gemm_mxfp8(qa, sa, qw, sw, variant=variant)
+        assert torch.equal(y.float().cpu(), (a.float() @ w.float().T).to(torch.bfloat16).float()), variant
 
 
 @pytest.mark.parametrize("m,k,n", [(257, 1536, 1536), (1024, 5120, 5120), (13325, 3072, 1536), (512, 8960, 1536)])
@@ -93,13 +99,13 @@ def test_reference_acceptance(m, k, n):
 
 
 def test_argument_errors(lib):
-    x = torch.zeros(4, 48, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(4, 96, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(lib.X2VError):
-        lib.quant_mxfp8(x)  # K % 32 != 0
-    q = torch.zeros(4, 64, dtype=torch.float8_e4m3fn, device="cuda")
-    s = torch.zeros(4, 2, dtype=torch.uint8, device="cuda")
+        lib.quant_mxfp8(x)  # K % 128 != 0
+    q = torch.zeros(4, 128, dtype=torch.float8_e4m3fn, device="cuda")
+    s = torch.zeros(4, 4, dtype=torch.uint8, device="cuda")
     with pytest.raises(lib.X2VError):
-        lib.gemm_mxfp8(q, s, q, s)  # K % 128 != 0
+        lib.gemm_mxfp8(q, s, q, s)  # scale tensors not in the [K/128, rows, 4] layout
 
 
 def test_scale_byte_to_k_block_association(lib):
@@ -116,5 +122,7 @@ def test_scale_byte_to_k_block_association(lib):
                 sa = torch.full((M, 4), 127, dtype=torch.uint8)
                 sb = torch.full((N, 4), 127, dtype=torch.uint8)
                 (sa if side == "a" else sb)[:, i] = 128
-                y = lib.gemm_mxfp8(a.to(torch.float8_e4m3fn).cuda(), sa.cuda(), b.to(torch.float8_e4m3fn).cuda(), sb.cuda()).float().cpu()
-                assert (y == (64.0 if i == j else 32.0)).all(), (side, j, i, y[0, 0].item())
+                for variant in (1, 2):
+                    y = lib.gemm_mxfp8(a.to(torch.float8_e4m3fn).cuda(), lib.mx_scales_tiled(sa.cuda()), b.to(torch.float8_e4m3fn).cuda(), lib.mx_scales_tiled(sb.cuda()),
+                                       variant=variant).float().cpu()
+                    assert (y == (64.0 if i == j else 32.0)).all(), (side, j, i, variant, y[0, 0].item())

@@ -35,11 +35,12 @@ def main():
         w, sw = lib.quant_mxfp8(torch.randn(N, K, dtype=torch.bfloat16, device="cuda"))
         y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         ms = timed(lambda: lib.gemm_mxfp8(a, sa, w, sw, out=y))
+        ms128 = timed(lambda: lib.gemm_mxfp8(a, sa, w, sw, out=y, variant=1))
         tf = 2.0 * M * N * K / ms / 1e9
         xq, sx = lib.quant_fp8_rowwise(torch.randn(M, K, dtype=torch.bfloat16, device="cuda"))
         swc = torch.ones(N, 1, dtype=torch.float32, device="cuda")
         ms8 = timed(lambda: lib.gemm_fp8(xq, sx, w, swc, out=y))
-        out["gemm"].append({"M": M, "K": K, "N": N, "ms": ms, "TFLOP/s": tf, "frac_of_5000": tf / 5000, "per_channel_fp8_256x256_ms": ms8,
+        out["gemm"].append({"M": M, "K": K, "N": N, "ms": ms, "TFLOP/s": tf, "frac_of_5000": tf / 5000, "tile128_ms": ms128, "per_channel_fp8_256x256_ms": ms8,
                             "per_channel_fp8_TFLOP/s": 2.0 * M * N * K / ms8 / 1e9})
     print(json.dumps(out))
 
