@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
+    ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule of config #4 (no CFG, denoising_step_list 1000/750/500/250, shift 5)")
     return ap.parse_args()
@@ -156,6 +157,8 @@ def main():
     extra = {}
     if args.fp8:
         extra["mm_config"] = {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}
+    if args.mxfp8:
+        extra["mm_config"] = {"mm_type": "W-mxfp8-A-mxfp8-dynamic-Hip", "weight_auto_quant": True}
     if args.distill:
         extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
     cfg = wan.default_config(
@@ -240,7 +243,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "fp8-e4m3 w8a8 GEMMs, bf16 attention" if args.fp8 else "bf16",
+        "dtype": "mxfp8 (e4m3 + e8m0/32) GEMMs, bf16 attention" if args.mxfp8 else "fp8-e4m3 w8a8 GEMMs, bf16 attention" if args.fp8 else "bf16",
         "data": "synthetic",
         "config": {
             "workload": args.workload,

@@ -170,6 +170,11 @@ int x2v_quant_mxfp8_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, void*
 int x2v_gemm_mxfp8(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
                    int64_t ldy, int64_t M, int N, int K, void* stream);
 
+/* x2v_gemm_mxfp8 with the fused epilogues of x2v_gemm_bf16 / x2v_gemm_fp8 (X2V_EPI_*; y = epi(alpha * a.b^T + bias)): what the fused
+ * block drivers call for a linear layer held in MXFP8 (operator class MMWeightMxfp8Hip). */
+int x2v_gemm_mxfp8_epi(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
+                       int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
+
 /* Same with a kernel selector: 0 = automatic (as x2v_gemm_mxfp8), 1 = 128x128-tile kernel, 2 = 256x256-tile ping-pong kernel. */
 int x2v_gemm_mxfp8_variant(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha,
                            void* y, int64_t ldy, int64_t M, int N, int K, int variant, void* stream);

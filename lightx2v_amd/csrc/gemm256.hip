@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
                                                          const unsigned* __restrict__ SA, const unsigned* __restrict__ SB) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(LEAD >= KW + 3 && LEAD <= 7, "see the hazard accounting in the header comment");
-  static_assert(!MX || (FP8 && EPI == X2V_EPI_NONE && SCHED == 0), "MX: block-scaled fp8, plain epilogue (alpha, bias)");
+  static_assert(!MX || (FP8 && SCHED == 0), "MX: block-scaled fp8");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -427,9 +427,15 @@ int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, i
   }
 }
 // MXFP8 (mx.hip): e4m3 operands with e8m0 block-scale tables [K/128][rows][4]; alpha = device pointer or null.  Arguments validated by the caller.
-int gemm256_mx_dispatch(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
-                        int64_t ldy, int64_t M, int N, int nk, hipStream_t st) {
-  return launch_gemm256_s<true, X2V_EPI_NONE, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+int gemm256_mx_dispatch(int epilogue, const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha,
+                        void* y, int64_t ldy, int64_t M, int N, int nk, const void* resid, int64_t ldr, const void* gate, hipStream_t st) {
+  switch (epilogue) {
+    case X2V_EPI_NONE: return launch_gemm256_s<true, X2V_EPI_NONE, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_GELU_TANH: return launch_gemm256_s<true, X2V_EPI_GELU_TANH, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_SILU: return launch_gemm256_s<true, X2V_EPI_SILU, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_RESIDUAL: return launch_gemm256_s<true, X2V_EPI_RESIDUAL, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, resid, ldr, gate, alpha, nullptr, 4, st, sa, sb);
+    default: set_error("gemm_mxfp8: unknown epilogue %d", epilogue); return X2V_E_ARG;
+  }
 }
 
 template int gemm256_dispatch<false>(int, const void*, int64_t, const void*, int64_t, const void*, void*, int64_t, int64_t, int, int, const void*, int64_t,

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const char* __restri
 }
 
 // gemm256.hip: the 256x256-tile ping-pong kernel with hardware block scales (large shapes)
-int gemm256_mx_dispatch(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
-                        int64_t ldy, int64_t M, int N, int nk, hipStream_t st);
+int gemm256_mx_dispatch(int epilogue, const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha,
+                        void* y, int64_t ldy, int64_t M, int N, int nk, const void* resid, int64_t ldr, const void* gate, hipStream_t st);
 
 }  // namespace x2v
 
@@ -267,7 +267,8 @@ extern "C" __attribute__((visibility("default"))) int x2v_quant_mxfp8_bf16(const
 }
 
 static int gemm_mxfp8_impl(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha, void* y,
-                           int64_t ldy, int64_t M, int N, int K, int variant, void* stream) {
+                           int64_t ldy, int64_t M, int N, int K, int variant, void* stream, int epilogue = X2V_EPI_NONE, const void* resid = nullptr,
+                           int64_t ldr = 0, const void* gate = nullptr) {
   X2V_REQUIRE(a && sa && b && sb && y, X2V_E_ARG, "gemm_mxfp8: null pointer");
   X2V_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0 && N % 8 == 0, X2V_E_SHAPE, "gemm_mxfp8: M=%lld N=%d K=%d (K %% 128 == 0, N %% 8 == 0)", (long long)M, N, K);
   X2V_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K && ldy % 8 == 0 && ldy >= N && aligned16(a) && aligned16(b) && aligned16(y) &&
@@ -276,8 +277,12 @@ static int gemm_mxfp8_impl(const void* a, int64_t lda, const void* sa, const voi
   X2V_REQUIRE((int64_t)(K / 128) * std::max<int64_t>(M, N) * 4 < (1ll << 32), X2V_E_SHAPE, "gemm_mxfp8: scale table of 4 GiB or more");
   // same kernel choice as the other GEMMs (gemm.hip): the 256x256 ping-pong kernel when it fills the chip, else 128x128 tiles
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = variant == 2 || (variant == 0 && tiles256 >= 192 && K / 128 >= 8 && lda < (1 << 24) && ldb < (1 << 24));
-  if (big) return gemm256_mx_dispatch(a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K / 128, (hipStream_t)stream);
+  // the fused epilogues (activation / gated residual) live in the 256x256 kernel only: any shape with one goes there
+  const bool big = variant == 2 || epilogue != X2V_EPI_NONE || (variant == 0 && tiles256 >= 192 && K / 128 >= 8 && lda < (1 << 24) && ldb < (1 << 24));
+  if (epilogue == X2V_EPI_RESIDUAL)
+    X2V_REQUIRE(resid != nullptr && ldr % 8 == 0 && ldr >= N && aligned16(resid) && (gate == nullptr || aligned16(gate)), X2V_E_ALIGN,
+                "gemm_mxfp8: residual epilogue needs a 16-byte aligned residual (and gate)");
+  if (big) return gemm256_mx_dispatch(epilogue, a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K / 128, resid, ldr, gate, (hipStream_t)stream);
   static bool attr_set = false;
   if (!attr_set) {
     int rc = check_hip(hipFuncSetAttribute((const void*)gemm_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES), "gemm_mxfp8 attr");
@@ -304,4 +309,11 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_mxfp8_variant(con
                                                                             int variant, void* stream) {
   X2V_REQUIRE(variant >= 0 && variant <= 2, X2V_E_ARG, "gemm_mxfp8: unknown variant %d", variant);
   return gemm_mxfp8_impl(a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K, variant, stream);
+}
+
+// With the fused epilogues of x2v_gemm_bf16 / x2v_gemm_fp8 (X2V_EPI_*): what the block drivers call for an MXFP8 linear layer.
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_mxfp8_epi(const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb,
+                                                                        const void* bias, const float* alpha, void* y, int64_t ldy, int64_t M, int N, int K,
+                                                                        int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+  return gemm_mxfp8_impl(a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K, 0, stream, epilogue, resid, ldr, gate);
 }

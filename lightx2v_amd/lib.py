@@ -42,6 +42,7 @@ PROTOTYPES = {
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_quant_mxfp8_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_mxfp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p],
+    "x2v_gemm_mxfp8_epi": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_mxfp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p],
     "x2v_gemm_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_fp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
@@ -288,7 +289,7 @@ def mx_scales_tiled(sc_rm):
     return sc_rm.reshape(rows, kb // 4, 4).permute(1, 0, 2).contiguous()
 
 
-def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None, variant=0):
+def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None, variant=0, epilogue=EPI_NONE, resid=None, gate=None):
     """alpha * deq(a)[M,K] @ deq(b)[N,K]^T + bias → bf16 [M,N]; scales uint8/e8m0 [K/128, rows, 4] as produced by quant_mxfp8;
     alpha: fp32 device tensor or None."""
     M, K = a.shape
@@ -307,6 +308,21 @@ def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None, variant=0):
         bias = _bf16(bias, "bias").reshape(-1)
         if bias.numel() != N:
             raise X2VError("gemm_mxfp8: bias must have N elements")
+    if epilogue != EPI_NONE:
+        if epilogue == EPI_RESIDUAL:
+            out2 = _row2d(resid if out is None else out, "out")
+            r2 = _row2d(resid, "resid")
+            gate = None if gate is None else gate.reshape(-1)
+        else:
+            out2 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out is None else _row2d(out, "out")
+            r2 = None
+        init()
+        _check(
+            _lib.x2v_gemm_mxfp8_epi(_p(a), a.stride(0), _p(sa), _p(b), b.stride(0), _p(sb), _p(bias), _p(alpha), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2),
+                                    0 if r2 is None else r2.stride(0), _p(gate), _stream()),
+            "gemm_mxfp8_epi",
+        )
+        return out2
     out2 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out is None else _row2d(out, "out")
     init()
     _check(

@@ -124,6 +124,43 @@ class MMWeightFp8Hip(_Movable):
 
 
 # ------------------------------------------------------------------------------------------------ norms
+@MM_WEIGHT_REGISTER("W-mxfp8-A-mxfp8-dynamic-Hip")
+class MMWeightMxfp8Hip(_Movable):
+    """MXFP8 linear layer (OCP microscaling: e4m3 elements, one e8m0 scale per 32 K elements for weights and activations alike) on
+    gfx950's block-scaled MFMA — the operator-API form of the reference's lightx2v_kernel pair `scaled_fp8_quant` +
+    `cutlass_scaled_mxfp8_mm` (lightx2v_kernel/python/lightx2v_kernel/gemm.py:73-97; test_mxfp8_quant.py:20-37 is its usage pattern:
+    quantise the weight once, the activation per call, alpha = 1, bias fused).  The reference ships the kernels but no MMWeight
+    class for them; the config key follows its naming scheme (mm_weight.py:287-589).  Weights arrive as bf16/fp16/fp32 [N, K] and are
+    quantised at load (the `weight_auto_quant` path of the other quantised classes, :167-173)."""
+
+    _tensor_attrs = ("weight", "weight_scale", "bias")
+
+    def __init__(self, weight_name, bias_name, lazy_load=False, lazy_load_file=None):
+        self.weight_name, self.bias_name = weight_name, bias_name
+        self.lazy_load, self.lazy_load_file = lazy_load, lazy_load_file
+        self.config = {}
+        self.weight = self.weight_scale = self.bias = None
+
+    def load(self, weight_dict):
+        w = weight_dict[self.weight_name]
+        if not w.is_cuda:
+            raise lib.X2VError(f"{self.weight_name}: MXFP8 weights are quantised by the HIP kernel at load — tensor is on {w.device}")
+        self.weight, self.weight_scale = lib.quant_mxfp8(w.to(torch.bfloat16).contiguous())
+        self.bias = weight_dict[self.bias_name] if self.bias_name is not None else None
+
+    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None):
+        xq, sx = lib.quant_mxfp8(input_tensor)
+        return lib.gemm_mxfp8(xq, sx, self.weight, self.weight_scale, bias=self.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+
+    def state_dict(self, destination=None):
+        destination = {} if destination is None else destination
+        destination[self.weight_name] = self.weight.cpu().detach().clone()
+        destination[self.weight_name + "_scale"] = self.weight_scale.cpu().detach().clone()
+        if self.bias is not None:
+            destination[self.bias_name] = self.bias.cpu().detach().clone()
+        return destination
+
+
 @RMS_WEIGHT_REGISTER("hip")
 class RMSWeightHip(_Movable):
     """reference: common/ops/norm/rms_norm_weight.py:53-118.  `round_mode`: fp32 statistics (what

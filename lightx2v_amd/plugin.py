@@ -20,6 +20,7 @@ def register_into_reference():
     for reg, key, cls in (
         (rf.MM_WEIGHT_REGISTER, "Hip-bf16", ops.MMWeightHip),
         (rf.MM_WEIGHT_REGISTER, "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", ops.MMWeightFp8Hip),
+        (rf.MM_WEIGHT_REGISTER, "W-mxfp8-A-mxfp8-dynamic-Hip", ops.MMWeightMxfp8Hip),
         (rf.ATTN_WEIGHT_REGISTER, "hip_flash", ops.HipFlashAttnWeight),
         (rf.RMS_WEIGHT_REGISTER, "hip", ops.RMSWeightHip),
         (rf.LN_WEIGHT_REGISTER, "hip", ops.LNWeightHip),

@@ -126,3 +126,50 @@ def test_scale_byte_to_k_block_association(lib):
                     y = lib.gemm_mxfp8(a.to(torch.float8_e4m3fn).cuda(), lib.mx_scales_tiled(sa.cuda()), b.to(torch.float8_e4m3fn).cuda(), lib.mx_scales_tiled(sb.cuda()),
                                        variant=variant).float().cpu()
                     assert (y == (64.0 if i == j else 32.0)).all(), (side, j, i, variant, y[0, 0].item())
+
+
+def test_epilogues_and_operator_class(lib):
+    """The fused epilogues of the MXFP8 GEMM equal the separate ops applied to the plain MXFP8 product; the operator class runs the
+    tiny Wan model within fp8 tolerance of the bf16 one."""
+    from tests.util import assert_bf16_close, assert_rel
+
+    gen = torch.Generator().manual_seed(21)
+    M, K, N = 300, 512, 264
+    x = torch.randn(M, K, generator=gen).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=gen) / K**0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=gen).to(torch.bfloat16).cuda()
+    xq, sx = lib.quant_mxfp8(x)
+    wq, sw = lib.quant_mxfp8(w)
+    y = lib.gemm_mxfp8(xq, sx, wq, sw, bias=b)
+    g = lib.gemm_mxfp8(xq, sx, wq, sw, bias=b, epilogue=lib.EPI_GELU_TANH)
+    y2 = lib.gemm_mxfp8(xq, sx, wq, sw, bias=b, variant=2)
+    assert_bf16_close(g, torch.nn.functional.gelu(y2.float(), approximate="tanh").to(torch.bfloat16), ulps=1, atol=2e-3, bad_frac=2e-3, name="mx gemm+gelu")
+    res = torch.randn(M, N, generator=gen).to(torch.bfloat16).cuda()
+    gate = (torch.randn(1, N, generator=gen) * 0.5).to(torch.bfloat16).cuda()
+    want = res.clone()
+    want.add_(y2 * gate.squeeze(0))
+    r = res.clone()
+    out = lib.gemm_mxfp8(xq, sx, wq, sw, bias=b, epilogue=lib.EPI_RESIDUAL, resid=r, gate=gate)
+    assert out.data_ptr() == r.data_ptr()
+    assert_bf16_close(r, want, ulps=1, atol=6e-3, bad_frac=2e-3, name="mx gemm+gate-residual")
+
+    from lightx2v_amd import scheduler, synth, wan
+
+    dims, wl = synth.WAN_DIMS["wan-tiny"], synth.WORKLOADS["wan-tiny"]
+    wd = {k: v.cuda() for k, v in synth.synth_wan_weights(dims, seed=0).items()}
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    outs = []
+    for mm in ({"mm_type": "Hip-bf16"}, {"mm_type": "W-mxfp8-A-mxfp8-dynamic-Hip", "weight_auto_quant": True}):
+        cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=4, mm_config=mm)
+        model = wan.WanModel(cfg, wd)
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=lat)
+        model.set_scheduler(sch)
+        sch.step_pre(0)
+        model.infer(inputs)
+        outs.append(sch.noise_pred.float().cpu())
+    assert_rel(outs[1], outs[0], 1e-1, "wan-tiny forward, MXFP8 linears vs bf16")
+    from tests.util import rel_l2
+
+    assert rel_l2(outs[1], outs[0]) > 1e-4
