@@ -154,6 +154,9 @@ class WanPreInfer:
         self.text_len = config["text_len"]
         self.freqs = None  # float32 (cos,sin) table, created on first use on the right device
         self.head_dim = d
+        # step-invariant text path: the text MLP output per input context list, see _text_context
+        self.cache_text_context = bool(_cfg(config, "cache_cross_kv", True))
+        self._text_cache = {}
 
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler
@@ -183,10 +186,28 @@ class WanPreInfer:
         embed0 = lib.activation(embed, lib.EPI_SILU)
         embed0 = weights.time_projection_1.apply(embed0).unflatten(1, (6, self.dim))
 
+        context = self._text_context(weights, context)
+        return embed, grid_sizes, (x, embed0.squeeze(0), seq_lens, self.freqs, context)
+
+    def _text_context(self, weights, context):
+        """pre_infer.py:86-96: pad the T5 rows to text_len, Linear + GELU-tanh + Linear.  The prompt embeddings do not change during a
+        denoise loop, so with `cache_cross_kv` the result is computed once per input tensor list and the SAME output tensor object is
+        handed to the block stack on every step — which is what lets the transformer reuse each block's cross-attention K/V.  Cache
+        entries pin their input tensors (so an id cannot be recycled) and check the version counters; at most 4 contexts are kept."""
+        key = None
+        if self.cache_text_context:
+            key = (id(weights),) + tuple(id(u) for u in context)
+            hit = self._text_cache.get(key)
+            if hit is not None and all(u._version == ver for u, ver in zip(hit[0], hit[1])):
+                return hit[2]
         stacked = torch.stack([torch.cat([u, u.new_zeros(self.text_len - u.size(0), u.size(1))]) for u in context]).squeeze(0)
         out = weights.text_embedding_0.apply(stacked, epilogue=lib.EPI_GELU_TANH)
-        context = weights.text_embedding_2.apply(out)
-        return embed, grid_sizes, (x, embed0.squeeze(0), seq_lens, self.freqs, context)
+        out = weights.text_embedding_2.apply(out)
+        if key is not None:
+            if len(self._text_cache) >= 4:
+                self._text_cache.pop(next(iter(self._text_cache)))
+            self._text_cache[key] = (list(context), [u._version for u in context], out)
+        return out
 
 
 class WanTransformerInfer:
@@ -208,6 +229,8 @@ class WanTransformerInfer:
         self.infer_conditional = True
         self._rope_cs = None
         self.attn_time_hook = None  # bench.py: callable(kind) -> context manager timing the attention launch
+        self.cache_cross_kv = bool(_cfg(config, "cache_cross_kv", True))
+        self._cross_kv_cache = {}  # (id(block weights), id(context)) -> (context, version, k, v); see _cross_kv
 
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler
@@ -270,11 +293,35 @@ class WanTransformerInfer:
         n3 = lib.layernorm(x, weights.norm3.weight, weights.norm3.bias, eps=weights.norm3.eps)
         q = weights.cross_attn_q.apply(n3)
         lib.rmsnorm(q, weights.cross_attn_norm_q.weight, weights.cross_attn_norm_q.eps, out=q, round_mode=self.round_mode)
-        k = weights.cross_attn_k.apply(context)
-        lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
-        v = weights.cross_attn_v.apply(context)
+        k, v = self._cross_kv(weights, context)
         attn = self._timed("cross", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim))
         return weights.cross_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=None)
+
+    def _cross_kv(self, weights, context):
+        """k = RMSNorm(W_k context), v = W_v context (transformer_infer.py:419-424).  The text context and the weights do not change
+        between denoise steps, so with config `cache_cross_kv` (default on) each block's pair is computed once per context
+        tensor OBJECT (WanPreInfer hands the same object over on every step) and reused — the same values the reference recomputes
+        every step (0.8 GB for Wan-14B with CFG).  An entry pins its context tensor (its id cannot be recycled) and checks the version
+        counter; contexts other than the two most recent ones (cond / uncond) are evicted, so a caller that passes fresh tensors
+        every step gets the reference behaviour without growth."""
+        if not self.cache_cross_kv:
+            k = weights.cross_attn_k.apply(context)
+            lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
+            return k, weights.cross_attn_v.apply(context)
+        per_ctx = self._cross_kv_cache.get(id(context))
+        if per_ctx is None or per_ctx["ctx"] is not context or per_ctx["version"] != context._version:
+            while len(self._cross_kv_cache) >= 2:
+                self._cross_kv_cache.pop(next(iter(self._cross_kv_cache)))
+            per_ctx = self._cross_kv_cache[id(context)] = {"ctx": context, "version": context._version, "kv": {}}
+        hit = per_ctx["kv"].get(id(weights))
+        if hit is None:
+            k = weights.cross_attn_k.apply(context)
+            lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
+            hit = per_ctx["kv"][id(weights)] = (k, weights.cross_attn_v.apply(context))
+        return hit
+
+    def clear_cross_kv(self):
+        self._cross_kv_cache.clear()
 
     def infer_ffn(self, weights, x, c_shift_msa, c_scale_msa, c_gate_msa):
         """transformer_infer.py:467-508: LN+modulate, ffn_0 (+GELU-tanh), ffn_2 (+`x.add_(y * c_gate)`)."""

@@ -205,3 +205,55 @@ def test_quantized_checkpoint_roundtrip_forward(tmp_path):
     ref = forward(wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=4), _to_dev(wd))
     assert_rel(a, ref, 1e-1, "fp8 checkpoint forward vs bf16 forward")  # w8a8 on a random 2-block model: 6.4e-2 measured
     assert rel_l2(a, ref) > 1e-4  # it really is the quantised path
+
+
+def test_cross_kv_cache_is_transparent():
+    """reusing the step-invariant text-MLP output and per-block cross-attention K/V gives bit-identical latents over a
+    denoise loop, really skips the recomputation, and follows a changed prompt."""
+    from lightx2v_amd import scheduler, synth, wan
+
+    dims, wl = synth.WAN_DIMS["wan-tiny"], synth.WORKLOADS["wan-tiny"]
+    wd = _to_dev(synth.synth_wan_weights(dims, seed=0))
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+
+    def run(cache, inp):
+        cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=3, cache_cross_kv=cache)
+        model = wan.WanModel(cfg, wd)
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=lat)
+        model.set_scheduler(sch)
+        scheduler.run_denoise_loop(model, sch, inp)
+        return model, sch.latents.float().cpu()
+
+    m_on, on = run(True, inputs)
+    m_off, off = run(False, inputs)
+    assert torch.equal(on, off)
+    tr = m_on.transformer_infer
+    assert len(tr._cross_kv_cache) == 2 and all(len(e["kv"]) == dims["num_layers"] for e in tr._cross_kv_cache.values())
+    assert len(m_on.pre_infer._text_cache) == 2 and not m_off.transformer_infer._cross_kv_cache and not m_off.pre_infer._text_cache
+    # the cached K really is what a fresh computation gives
+    entry = next(iter(tr._cross_kv_cache.values()))
+    blk = m_on.transformer_weights.blocks[0].compute_phases[2] if hasattr(m_on.transformer_weights.blocks[0], "compute_phases") else None
+    if blk is not None and id(blk) in entry["kv"]:
+        k_cached = entry["kv"][id(blk)][0]
+        tr.cache_cross_kv = False
+        k_fresh, _ = tr._cross_kv(blk, entry["ctx"])
+        tr.cache_cross_kv = True
+        assert torch.equal(k_cached, k_fresh)
+    # a different prompt (new tensors) is not served from the cache; an in-place edit of the same tensor is noticed too
+    inputs2 = {"text_encoder_output": {"context": [c.cuda() * 0.5 for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    _, other = run(True, inputs2)
+    assert not torch.equal(other, on)
+    cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=3)
+    model = wan.WanModel(cfg, wd)
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    model.set_scheduler(sch)
+    mutable = {"text_encoder_output": {"context": [c.cuda().clone() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    sch.step_pre(0)
+    model.infer(mutable)
+    first = sch.noise_pred.clone()
+    mutable["text_encoder_output"]["context"][0].mul_(0.5)
+    model.infer(mutable)
+    assert not torch.equal(sch.noise_pred, first)
