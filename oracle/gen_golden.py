@@ -351,6 +351,43 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
     print("hunyuan_tiny.safetensors:", len(out), "tensors; noise_pred", tuple(out["noise_pred"].shape), out["noise_pred"].dtype)
 
 
+def gen_hunyuan_vae(seed=1):
+    """HunyuanVideo VAE decode fixture: the reference's own AutoencoderKLCausal3D (autoencoder_kl_causal_3d.py) built at a reduced
+    width and tile size (synth.HUNYUAN_VAE_TINY_CFG: 32/64/128/128 channels, 8 groups, 64-px / 16-frame tiles) and driven exactly as
+    VideoEncoderKLCausal3DModel.decode does (model.py:33-44: scale, enable_tiling, decode, x/2+0.5, clamp) on z [1,16,6,12,10] — the
+    temporal tiling path with 2x2 spatial tiles inside each temporal tile and every blend — plus one untiled decoder call.
+    fp32 on CPU (the reference runs fp16 on the GPU).  `diffusers` is absent: oracle/ref_shims/diffusers supplies plumbing and a
+    restated `Attention` (the mid block's single attention op) — everything else in the fixture is the reference's code."""
+    ref_import.patch_and_import()
+    from lightx2v.models.video_encoders.hf.autoencoder_kl_causal_3d.autoencoder_kl_causal_3d import AutoencoderKLCausal3D
+
+    cfg = synth.HUNYUAN_VAE_TINY_CFG
+    vae = AutoencoderKLCausal3D(
+        in_channels=3, out_channels=3, down_block_types=("DownEncoderBlockCausal3D",) * 4, up_block_types=("UpDecoderBlockCausal3D",) * 4,
+        block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], latent_channels=cfg["latent_channels"],
+        norm_num_groups=cfg["norm_num_groups"], sample_size=cfg["sample_size"], sample_tsize=cfg["sample_tsize"], scaling_factor=cfg["scaling_factor"],
+        time_compression_ratio=cfg["time_compression_ratio"], spatial_compression_ratio=cfg["spatial_compression_ratio"], mid_block_add_attention=True,
+    )
+    sd = synth.synth_hunyuan_vae_weights(cfg, seed=seed)
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("encoder.", "quant_conv.")) for k in missing), (missing[:3], unexpected[:3])
+    vae.requires_grad_(False)
+    vae.eval()
+    out = {}
+    with torch.no_grad():
+        z = torch.randn(1, 16, 6, 12, 10, generator=torch.Generator().manual_seed(3)) * 0.5
+        latents = z / vae.config.scaling_factor
+        vae.enable_tiling()
+        image = vae.decode(latents, return_dict=False, generator=None)[0]
+        out["z_tiled"], out["image_tiled"] = z, (image / 2 + 0.5).clamp(0, 1).float()
+        z1 = torch.randn(1, 16, 3, 6, 5, generator=torch.Generator().manual_seed(5)) * 0.5  # fits one tile: plain decoder
+        out["z_single"] = z1
+        out["image_single"] = (vae.decode(z1 / vae.config.scaling_factor, return_dict=False)[0] / 2 + 0.5).clamp(0, 1).float()
+    out["weights_checksum"] = weights_checksum(sd).reshape(1)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "hunyuan_vae_tiny.safetensors"))
+    print("hunyuan vae fixture:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 CONVERTER_DIMS = dict(dim=64, ffn_dim=128, num_heads=1, num_layers=2, text_len=8, text_dim=64)
 CONVERTER_CASES = {
     "fp8_by_block": dict(linear_dtype="torch.float8_e4m3fn", save_by_block=True, chunk_size=100),
@@ -400,7 +437,7 @@ def gen_converter():
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "converter"]
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "converter", "hunyuan_vae"]
     if "ops" in which:
         gen_ops()
     if "model" in which:
@@ -415,3 +452,5 @@ if __name__ == "__main__":
         gen_teacache()
     if "converter" in which:
         gen_converter()
+    if "hunyuan_vae" in which:
+        gen_hunyuan_vae()

@@ -114,6 +114,26 @@ def test_vae_decode_oracle_bit_exact():
     assert torch.equal(out, gld["decoded"])
 
 
+def test_hunyuan_vae_oracle_bit_exact():
+    """oracle/hunyuan_vae_oracle.py reproduces the fixture generated by running the reference's AutoencoderKLCausal3D
+    (gen_golden.py::gen_hunyuan_vae): the tiled decode (temporal + spatial tiles, all blends) and the plain decoder."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import synth
+    from oracle import hunyuan_vae_oracle as V
+
+    gld = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hunyuan_vae_tiny.safetensors"))
+    cfg = synth.HUNYUAN_VAE_TINY_CFG
+    sd = synth.synth_hunyuan_vae_weights(cfg, seed=1)
+    chk = sum(v.double().abs().sum() for _, v in sorted(sd.items()))
+    assert torch.allclose(chk.reshape(1), gld["weights_checksum"], rtol=1e-12), "synthetic Hunyuan VAE weights drifted from the fixture's"
+    with torch.no_grad():
+        assert torch.equal(V.vae_decode(sd, gld["z_single"], cfg), gld["image_single"])
+        assert torch.equal(V.vae_decode(sd, gld["z_tiled"], cfg), gld["image_tiled"])
+
+
 def test_hunyuan_oracle_bit_exact():
     """oracle/hunyuan_oracle.py reproduces the fixture generated from the reference's Hunyuan pre/transformer/post infer
     objects and scheduler functions (tests/golden/hunyuan_tiny.safetensors)."""
