@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const unsigned s
     }
   }
   amax = block_max<4>(amax, red);
-  const float s = fmaxf(amax, 1e-12f) / 448.0f;  // reference: amax/448 (mm_weight.py:236-245 → vllm/sgl per-token quant)
+  // reference: mm_weight.py:236-245 → vllm dynamic per-token quant: scale = max(amax / 448, 1 / (448 * 512))
+  const float s = fmaxf(amax / 448.0f, 1.0f / (448.0f * 512.0f));
   if (t == 0) scale[row] = s;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {

@@ -102,7 +102,9 @@ class MMWeightFp8Hip(_Movable):
         w = weight_dict[self.weight_name]
         if self.config.get("weight_auto_quant", False) or w.dtype != torch.float8_e4m3fn:
             wf = w.to(torch.float32)
-            scale = wf.abs().amax(dim=1, keepdim=True).clamp(min=1e-12) / 448.0
+            # quant_utils.py:46-48.  A tensor divisor on purpose: dividing by a Python scalar becomes a multiplication by its rounded
+            # reciprocal on the device, one ulp off for most rows — and w / scale hits exact e4m3 ties often (bf16 weights)
+            scale = wf.abs().amax(dim=1, keepdim=True).clamp(min=1e-5) / torch.tensor(448.0, dtype=torch.float32, device=wf.device)
             self.weight = (wf / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).contiguous()
             self.weight_scale = scale.to(torch.float32)
         else:

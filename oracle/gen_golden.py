@@ -388,6 +388,39 @@ def gen_hunyuan_vae(seed=1):
     print("hunyuan vae fixture:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_fp8():
+    """w8a8-fp8 fixture (BASELINE config #4's GEMM leg): the reference's own operator class
+    MMWeightWfp8channelAfp8channeldynamicVllm (common/ops/mm/mm_weight.py:287-319) — `weight_auto_quant` load from a bf16 weight and
+    load of a converter-format pair, then apply() — executed on CPU over the restated vLLM kernels of oracle/ref_shims/vllm."""
+    ref_import.patch_and_import()
+    from lightx2v.utils.registry_factory import MM_WEIGHT_REGISTER
+
+    gen = torch.Generator().manual_seed(12)
+    M, K, N = 96, 256, 160
+    x = torch.randn(M, K, generator=gen).to(torch.bfloat16)
+    x[3] = 0  # an all-zero token: the scale floor of the dynamic quantiser
+    x[5] *= 40
+    w = (torch.randn(N, K, generator=gen) / K**0.5).to(torch.bfloat16)
+    w[7] = 0  # an all-zero out channel: the 1e-5 clamp of the weight quantiser
+    b = (torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16)
+    out = {"x": x, "w": w, "b": b}
+    cls = MM_WEIGHT_REGISTER["W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Vllm"]
+    op = cls("w.weight", "w.bias")
+    op.set_config({"weight_auto_quant": True})
+    op.load({"w.weight": w.clone(), "w.bias": b.clone()})
+    out["auto_wq"] = op.weight.t().contiguous().view(torch.uint8)  # stored [N, K]
+    out["auto_wscale"] = op.weight_scale.clone()
+    out["auto_y"] = op.apply(x.clone())
+    xq, sx = op.act_quant_func(x.clone())
+    out["xq"], out["sx"] = xq.view(torch.uint8), sx
+    op2 = cls("w.weight", "w.bias")
+    op2.set_config({})
+    op2.load({"w.weight": op.weight.t().contiguous().clone(), "w.weight_scale": op.weight_scale.to(torch.bfloat16), "w.bias": b.clone()})  # as a loader hands it over
+    out["ckpt_y"] = op2.apply(x.clone())
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "fp8_mm.safetensors"))
+    print("fp8 fixture:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 CONVERTER_DIMS = dict(dim=64, ffn_dim=128, num_heads=1, num_layers=2, text_len=8, text_dim=64)
 CONVERTER_CASES = {
     "fp8_by_block": dict(linear_dtype="torch.float8_e4m3fn", save_by_block=True, chunk_size=100),
@@ -437,7 +470,7 @@ def gen_converter():
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "converter", "hunyuan_vae"]
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "converter", "hunyuan_vae", "fp8"]
     if "ops" in which:
         gen_ops()
     if "model" in which:
@@ -454,3 +487,5 @@ if __name__ == "__main__":
         gen_converter()
     if "hunyuan_vae" in which:
         gen_hunyuan_vae()
+    if "fp8" in which:
+        gen_fp8()

@@ -225,6 +225,31 @@ def test_fp8_path_vs_oracle(lib):
     assert err < 1e-2
 
 
+def test_fp8_vs_reference_class_fixture(lib):
+    """tests/golden/fp8_mm.safetensors: the reference's own fp8 operator class (auto-quantised and checkpoint-loaded weights)."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import ops
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp8_mm.safetensors"))
+    xq, sx = lib.quant_fp8_rowwise(dev(g["x"]))
+    assert torch.allclose(sx.cpu(), g["sx"], rtol=1e-6, atol=0), "per-token scales (incl. the floor of an all-zero token)"
+    mism = (xq.cpu().view(torch.uint8) != g["xq"]).float().mean().item()
+    assert mism <= 1e-3, f"{mism} of e4m3 codes differ"
+    for auto in (True, False):
+        op = ops.MMWeightFp8Hip("w.weight", "w.bias")
+        op.set_config({"weight_auto_quant": auto})
+        if auto:
+            op.load({"w.weight": dev(g["w"]), "w.bias": dev(g["b"])})
+            assert torch.equal(op.weight_scale.cpu(), g["auto_wscale"]) and torch.equal(op.weight.cpu().view(torch.uint8), g["auto_wq"])
+        else:
+            op.load({"w.weight": dev(g["auto_wq"]).view(torch.float8_e4m3fn), "w.weight_scale": dev(g["auto_wscale"].to(torch.bfloat16)), "w.bias": dev(g["b"])})
+        y = op.apply(dev(g["x"]))
+        assert_bf16_close(y, g["auto_y" if auto else "ckpt_y"], ulps=1, atol=4e-3, bad_frac=2e-3, name=f"fp8 operator class (auto={auto})")
+
+
 def test_causal_conv3d_vs_torch(lib):
     """CausalConv3d.forward semantics (vae.py:19-44): left time padding 2 minus the cached frames, zero 'same'
     spatial padding, fp32."""

@@ -194,3 +194,21 @@ def test_teacache_oracle_bit_exact():
         assert [int(c) for c in tea.records[False]] == g[f"{tag}_records_uncond"].tolist()
         assert not bad, (tag, bad)
         assert 0 < sum(tea.records[True]) < steps  # the fixture exercises both paths
+
+
+def test_fp8_oracle_reproduces_reference_class_outputs():
+    """oracle/wan_oracle.py's w8a8 functions against the fixture produced by the reference's own fp8 operator class
+    (gen_golden.py::gen_fp8; the two vLLM kernels under it are restated stubs, everything else is the reference's code)."""
+    import os
+
+    from safetensors.torch import load_file
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp8_mm.safetensors"))
+    wq, sw = O.quant_fp8_weight_per_channel(g["w"])
+    assert torch.equal(wq.view(torch.uint8), g["auto_wq"]) and torch.equal(sw, g["auto_wscale"])
+    assert sw[7].item() == (torch.tensor(1e-5) / 448.0).item()  # all-zero channel: the quantiser's clamp
+    xq, sx = O.quant_fp8_per_token(g["x"])
+    assert torch.equal(xq.view(torch.uint8), g["xq"]) and torch.equal(sx, g["sx"])
+    assert sx[3].item() == torch.tensor(1.0 / (448.0 * 512.0), dtype=torch.float32).item()  # all-zero token: the dynamic quantiser's scale floor
+    assert torch.equal(O.mm_fp8(g["x"], wq, sw, g["b"]), g["auto_y"])
+    assert torch.equal(O.mm_fp8(g["x"], wq, sw.to(torch.bfloat16).float(), g["b"]), g["ckpt_y"])
