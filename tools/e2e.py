@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""End-to-end wall clock of the hot path on one GPU: the full denoise loop (all infer_steps, CFG) followed by the VAE decode of the
+final latents — the quantity BASELINE.json's north star asks for next to the per-step number ("end-to-end wall-clock and frames/sec").
+Synthetic weights and inputs of the named shape (no text encoder: its output is an input here, as in bench.py).  One JSON line.
+    python tools/e2e.py [--workload wan14b_720px81f] [--steps 50] [--fp8|--mxfp8] [--distill] [--teacache T]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lightx2v_amd import lib, scheduler, synth, vae, wan  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="wan14b_720px81f")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--mxfp8", action="store_true")
+    ap.add_argument("--distill", action="store_true", help="4-step distilled schedule, no CFG (BASELINE config #4)")
+    ap.add_argument("--teacache", type=float, default=0.0, help="TeaCache threshold (0 = off); uses the released 14B 720p coefficients")
+    a = ap.parse_args()
+    lib.init(0)
+    wl = synth.WORKLOADS[a.workload]
+    dims = synth.WAN_DIMS[wl["model"]]
+    steps = 4 if a.distill else a.steps
+    extra = {}
+    if a.fp8:
+        extra["mm_config"] = {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}
+    if a.mxfp8:
+        extra["mm_config"] = {"mm_type": "W-mxfp8-A-mxfp8-dynamic-Hip", "weight_auto_quant": True}
+    if a.distill:
+        extra.update(enable_cfg=False, denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
+    if a.teacache > 0:
+        # configs/caching/teacache/wan_t2v_tea_720p.json of the reference: coefficients for Wan2.1-T2V-14B 720p
+        extra.update(feature_caching="Tea", teacache_thresh=a.teacache, use_ret_steps=False,
+                     coefficients=[[8.10705460e03, 2.13393892e03, -3.72934672e02, 1.66203073e01, -4.17769401e-02],
+                                   [-114.36346466, 65.26524496, -18.82220707, 4.91518089, -0.23412683]])
+    cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=steps, **extra)
+    model = wan.WanModel(cfg, synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda"))
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    sch = (scheduler.WanStepDistillScheduler if a.distill else scheduler.WanScheduler)(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    model.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    decoder = vae.WanVAE(synth.synth_wan_vae_weights(dim=96, seed=0), dim=96)
+    # warm-up outside the clock: one step on a scratch scheduler state (allocator pools, lazy tables) and a short decode
+    sch.step_pre(0)
+    model.infer(inputs)
+    decoder.decode(torch.zeros(16, 2, wl["target_shape"][2], wl["target_shape"][3], device="cuda"))
+    sch.reset() if hasattr(sch, "reset") else None
+    sch.prepare(latents=lat)
+    if a.teacache > 0:
+        model.transformer_infer.cnt = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scheduler.run_denoise_loop(model, sch, inputs)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    video = decoder.decode(sch.latents.float())
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert torch.isfinite(video).all() and torch.isfinite(sch.latents).all()
+    frames = wl["frames"]
+    rec = {"workload": a.workload, "steps": steps, "cfg": bool(cfg["enable_cfg"]), "gemm_dtype": "mxfp8" if a.mxfp8 else "fp8" if a.fp8 else "bf16",
+           "teacache_thresh": a.teacache, "denoise_s": t1 - t0, "ms_per_step": (t1 - t0) * 1e3 / steps, "vae_decode_s": t2 - t1, "total_s": t2 - t0,
+           "frames": frames, "video_shape": list(video.shape), "fps_denoise_only": frames / (t1 - t0), "fps_with_vae": frames / (t2 - t0),
+           "hbm_gb_peak": torch.cuda.max_memory_allocated() / 1e9, "data": "synthetic weights / latents / text embeddings"}
+    if a.teacache > 0:
+        rec_c, rec_u = list(getattr(sch, "caching_records", [])), list(getattr(sch, "caching_records_2", []))
+        rec["teacache_forwards_computed"] = int(sum(bool(v) for v in rec_c + rec_u))
+        rec["teacache_forwards_total"] = len(rec_c) + len(rec_u)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()

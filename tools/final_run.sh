@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-end validation batch (one gpurun call): checks, the whole GPU test suite, smoke, the default bench line, the rocprof
+# summary of the same command, and the secondary measurements quoted in DESIGN.md.  Every stage has its own timeout.
+set +e
+OUT=gpurun_out/${RUN_TAG:-final}
+mkdir -p "$OUT"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 PYTHONPATH=.
+run() { name=$1; shift; t0=$(date +%s); "$@"; echo "$name rc=$? ($(( $(date +%s) - t0 )) s)" | tee -a "$OUT/summary.txt"; }
+for m in probe misc norm rope gemm attn fp8 conv; do run "check_$m" timeout 200 tools/x2v_check $m > "$OUT/check_$m.log" 2>&1; tail -1 "$OUT/check_$m.log" >> "$OUT/summary.txt"; done
+run pytest timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > "$OUT/pytest.log" 2>&1; tail -5 "$OUT/pytest.log" >> "$OUT/summary.txt"
+run smoke timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" >> "$OUT/summary.txt"
+run bench_default timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cat "$OUT/bench_default.json" >> "$OUT/summary.txt"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err"); echo "prof rc=$?" | tee -a "$OUT/summary.txt"
+find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+run bench13 timeout 600 python bench.py --workload wan1.3b_480px49f --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench13.json" 2> "$OUT/bench13.err"; cat "$OUT/bench13.json" >> "$OUT/summary.txt"
+run bench_fp8_distill timeout 600 python bench.py --fp8 --distill --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench14_fp8_distill.json" 2> "$OUT/bench14_fp8_distill.err"; cat "$OUT/bench14_fp8_distill.json" >> "$OUT/summary.txt"
+run hunyuan timeout 600 python tools/hunyuan_bench.py > "$OUT/hunyuan13b.json" 2> "$OUT/hunyuan13b.err"; cat "$OUT/hunyuan13b.json" >> "$OUT/summary.txt"
+run e2e_13b timeout 300 python tools/e2e.py --workload wan1.3b_480px49f --steps 50 > "$OUT/e2e_wan13b_480p.json" 2> "$OUT/e2e13.err"; cat "$OUT/e2e_wan13b_480p.json" >> "$OUT/summary.txt"
+run e2e_fp8_distill timeout 400 python tools/e2e.py --fp8 --distill > "$OUT/e2e_wan14b_fp8_distill.json" 2> "$OUT/e2e_fp8.err"; cat "$OUT/e2e_wan14b_fp8_distill.json" >> "$OUT/summary.txt"
+if [ "${E2E14:-1}" = "1" ]; then
+  run e2e_14b timeout 900 python tools/e2e.py --steps 50 > "$OUT/e2e_wan14b_720p.json" 2> "$OUT/e2e14.err"; cat "$OUT/e2e_wan14b_720p.json" >> "$OUT/summary.txt"
+fi
+cat "$OUT/summary.txt"
