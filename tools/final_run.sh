@@ -5,7 +5,7 @@ set +e
 OUT=gpurun_out/${RUN_TAG:-final}
 mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 PYTHONPATH=.
-run() { name=$1; shift; t0=$(date +%s); "$@"; echo "$name rc=$? ($(( $(date +%s) - t0 )) s)" | tee -a "$OUT/summary.txt"; }
+run() { name=$1; shift; t0=$(date +%s); "$@"; echo "$name rc=$? ($(( $(date +%s) - t0 )) s)" >> "$OUT/summary.txt"; }  # (stdout of "$@" may be redirected by the caller)
 for m in probe misc norm rope gemm attn fp8 conv; do run "check_$m" timeout 200 tools/x2v_check $m > "$OUT/check_$m.log" 2>&1; tail -1 "$OUT/check_$m.log" >> "$OUT/summary.txt"; done
 run pytest timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > "$OUT/pytest.log" 2>&1; tail -5 "$OUT/pytest.log" >> "$OUT/summary.txt"
 run smoke timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" >> "$OUT/summary.txt"
