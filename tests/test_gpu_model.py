@@ -257,3 +257,32 @@ def test_cross_kv_cache_is_transparent():
     mutable["text_encoder_output"]["context"][0].mul_(0.5)
     model.infer(mutable)
     assert not torch.equal(sch.noise_pred, first)
+
+
+def test_baseline_config1_full_run_vs_oracle():
+    """BASELINE config #1 in full — Wan2.1-T2V-1.3B (30 layers), 256x256x17f (S = 1280), 4 steps, CFG, shift 8, guide 6 — the whole denoise
+    loop on the HIP path against the CPU oracle on identical noise / text embeddings / weights.  The oracle's 240 block evaluations take
+    tens of seconds on the box's host cores.  Tolerance: relative L2 of the final latents <= 5e-2 (bf16 chains of 30 blocks x 8
+    forwards; the per-forward error measured by the 2-block test is ~1e-2), and the first step's noise prediction <= 3e-2."""
+    from lightx2v_amd import scheduler, synth, wan
+    from oracle import wan_oracle as O
+
+    dims = synth.WAN_DIMS["wan2.1-1.3b"]
+    wl = synth.WORKLOADS["wan1.3b_256x256x17f"]
+    ts = wl["target_shape"]
+    wd = synth.synth_wan_weights(dims, seed=0)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    steps, shift, guide = 4, 8.0, 6.0
+    ref_steps = []
+    ref = O.denoise_loop(wd, dims, lat, ctx, ctx_null, steps, shift, guide, step_callback=lambda i, x: ref_steps.append(x.clone()))
+    cfg = wan.default_config(dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=steps, sample_shift=shift, sample_guide_scale=guide)
+    model = wan.WanModel(cfg, _to_dev(wd))
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    model.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    got_steps = []
+    scheduler.run_denoise_loop(model, sch, inputs, step_callback=lambda i: got_steps.append(sch.latents.float().cpu().clone()))
+    assert len(got_steps) == len(ref_steps) == steps
+    assert_rel(got_steps[0], ref_steps[0], 3e-2, "config #1: latents after step 1")
+    assert_rel(got_steps[-1], ref, 5e-2, "config #1: final latents after 4 CFG steps")
