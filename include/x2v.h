@@ -229,6 +229,16 @@ int x2v_softmax_rows_f32(float* s, int64_t ld, int64_t M, int N, float scale, vo
 int x2v_vae_prep_ex_f32(const float* x, float* y, int T, int Hh, int Ww, int C, const float* mul, const float* add, int silu, int clamp01, int up_hw, int up_t,
                         int64_t y_frame_stride, int64_t y_row_stride, void* stream);
 
+/* 16-bit-operand form of x2v_vae_conv_f32 for the HunyuanVideo VAE, which the reference runs in fp16 (hunyuan_runner.py:40): xp and w
+ * are fp16 (strides in halves, Cin % 64 == 0), accumulation fp32 on v_mfma_f32_32x32x16_f16, bias / residual / output fp32 — the residual
+ * stream and the normalisation statistics keep fp32, only the convolution operands are rounded.  Same flags and layouts as the fp32 entry. */
+int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w, int64_t w_row_stride, const float* bias,
+                     const float* resid, float* y, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream);
+
+/* x2v_vae_prep_ex_f32 writing fp16: fills the operand buffer of x2v_vae_conv_f16 (y strides in halves, C % 8 == 0). */
+int x2v_vae_prep_ex_f16(const float* x, void* y, int T, int H, int W, int C, const float* mul, const float* add, int silu, int clamp01, int up_hw, int up_t,
+                        int64_t y_frame_stride, int64_t y_row_stride, void* stream);
+
 /* Fill the borders of a conv input buffer [frames][Hp][Wp][C] by replication: spatial borders (width `pad`) from the
  * nearest interior pixel, the `lead` leading frames from frame `lead` — F.pad(mode="replicate") of CausalConv3d
  * (unet_causal_3d_blocks.py:84-91). */

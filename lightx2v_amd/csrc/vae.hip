@@ -196,6 +196,167 @@ __global__ __launch_bounds__(256) void vae_conv_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16-bit-input variant of the implicit-GEMM convolution: activations and weights in fp16 (the precision the reference runs the
+// HunyuanVideo VAE in, hunyuan_runner.py:40), fp32 accumulate on v_mfma_f32_32x32x16_f16, fp32 bias / residual / output — the residual
+// stream and the GroupNorm statistics stay fp32, only the operands of the big convolutions are rounded.  Same tile (256 pixels x 32 NF
+// couts per workgroup, wave = 64 px), same LDS-DMA staging and swizzle as the fp32 kernel; a K step is one tap x 64 channels
+// (128-byte rows) = 4 k-steps of 16: 8 NF MFMAs of 32 cycles per wave and step against 12 + NF LDS-DMA pieces per workgroup —
+// MFMA-bound no longer, the staging path sets the pace (measured in DESIGN.md §4.4).
+typedef _Float16 vc_half8_t __attribute__((ext_vector_type(8)));
+
+template <int NF>
+__global__ __launch_bounds__(256) void vae_conv16_kernel(const _Float16* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
+                                                         const _Float16* __restrict__ w, int64_t w_row_stride, const float* __restrict__ bias,
+                                                         const float* __restrict__ resid, float* __restrict__ y, int T, int Hh, int Ww, int Cin, int Cout,
+                                                         int kt, int kh, int kw, int flags, int ncol) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KC = 64;                         // channels per K step
+  constexpr int ROWB = KC * 2;                   // bytes per staged row
+  constexpr int CPR = 8, RPI = 8;                // 16-byte chunks per row, rows per wave-instruction
+  constexpr int BN = 32 * NF;
+  constexpr int A_BYTES = VC_PIX * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = 64 / RPI;
+  constexpr int B_INSTR = (BN / 4 + RPI - 1) / RPI;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fl = lane & 31, fh = lane >> 5;
+  const int HW = Hh * Ww;
+  const int tiles_per_frame = (HW + VC_PIX - 1) / VC_PIX;
+  const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+  const int ptile = (int)(v / (unsigned)ncol), ctile = (int)(v % (unsigned)ncol);
+  const int frame = ptile / tiles_per_frame;
+  const int p0 = (ptile % tiles_per_frame) * VC_PIX;
+  const int co0 = ctile * BN;
+  const int taps = kt * kh * kw;
+
+  const int64_t fbytes = x_frame_stride * 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xp + (int64_t)frame * x_frame_stride), 0, (unsigned)(fbytes * kt), 0x00020000);
+  const int wrows = min(BN, Cout - co0);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(w + (int64_t)co0 * w_row_stride), 0, (unsigned)(((int64_t)(wrows - 1) * w_row_stride + (int64_t)taps * Cin) * 2), 0x00020000);
+
+  unsigned a_voff[A_INSTR], b_voff[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int r = wid * 64 + i * RPI + lane / CPR;
+    const int c = (lane % CPR) ^ ((r >> 1) & (CPR - 1));
+    const int p = p0 + r;
+    const int ph = p / Ww, pw = p - ph * Ww;
+    a_voff[i] = p < HW ? (unsigned)(((int64_t)ph * x_row_stride + (int64_t)pw * x_px_stride) * 2) + (unsigned)(c << 4) : VC_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int rl = i * RPI + lane / CPR;
+    const int r = wid * (BN / 4) + rl;
+    const int c = (lane % CPR) ^ ((r >> 1) & (CPR - 1));
+    b_voff[i] = (rl < BN / 4 && r < wrows) ? (unsigned)((int64_t)r * w_row_stride * 2) + (unsigned)(c << 4) : VC_OOB;
+  }
+  const int kchunks = Cin / KC;
+  const int nsteps = taps * kchunks;
+  auto stage = [&](int s, int step) {
+    const int tap = step / kchunks, kc = step - tap * kchunks;
+    const int dt = tap / (kh * kw), dh = (tap / kw) % kh, dw = tap % kw;
+    const unsigned xso = (unsigned)(((int64_t)dt * x_frame_stride + (int64_t)dh * x_row_stride + (int64_t)dw * x_px_stride + (int64_t)kc * KC) * 2);
+    const unsigned wso = (unsigned)(((int64_t)tap * Cin + (int64_t)kc * KC) * 2);
+    char* as = smem + s * STAGE + wid * (64 * ROWB);
+    char* bs = smem + s * STAGE + A_BYTES + wid * ((BN / 4) * ROWB);
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (v_lds_ptr_t)(as + i * 1024), 16, a_voff[i], xso, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      if ((i + 1) * RPI <= BN / 4 || lane / CPR + i * RPI < BN / 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (v_lds_ptr_t)(bs + i * 1024), 16, b_voff[i], wso, 0, 0);
+  };
+
+  // fragment read offsets: row (32-row block + fl), k-step ks reads chunk (ks*2 + fh) ^ swizzle (8 halves = the lane's k values)
+  int rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rd[ks] = fl * ROWB + ((((ks << 1) | fh) ^ ((fl >> 1) & (CPR - 1))) << 4);
+
+  f32x16_t acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps) stage(cur ^ 1, step + 1);
+    const char* ab = smem + cur * STAGE + wid * (64 * ROWB);
+    const char* bb = smem + cur * STAGE + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      vc_half8_t xa[2], wb[NF];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xa[i] = *reinterpret_cast<const vc_half8_t*>(ab + i * 32 * ROWB + rd[ks]);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) wb[n] = *reinterpret_cast<const vc_half8_t*>(bb + n * 32 * ROWB + rd[ks]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[n], xa[i], acc[i][n], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: identical to the fp32 kernel (fp32 bias / residual / output)
+  const bool vec_ok = (Cout & 3) == 0;
+  const int csplit = (flags & VCF_TSPLIT) ? Cout / 2 : Cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = p0 + wid * 64 + i * 32 + fl;
+    if (p >= HW) continue;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + n * 32 + 8 * g + 4 * fh;
+        if (co >= Cout) continue;
+        float vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = acc[i][n][4 * g + e];
+        int64_t oidx;
+        if (flags & VCF_TSPLIT) {
+          const int hi = co >= csplit ? 1 : 0;
+          oidx = ((int64_t)(2 * frame + hi) * HW + p) * csplit + (co - hi * csplit);
+        } else {
+          oidx = ((int64_t)frame * HW + p) * Cout + co;
+        }
+        if (vec_ok) {
+          if (bias != nullptr) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + co);
+            vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w;
+          }
+          if (resid != nullptr) {
+            const float4 r4 = *reinterpret_cast<const float4*>(resid + oidx);
+            vv[0] += r4.x; vv[1] += r4.y; vv[2] += r4.z; vv[3] += r4.w;
+          }
+          if (flags & VCF_CLAMP) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = fminf(fmaxf(vv[e], -1.f), 1.f);
+          }
+          *reinterpret_cast<float4*>(y + oidx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < Cout) {
+              float o = vv[e] + (bias != nullptr ? bias[co + e] : 0.f) + (resid != nullptr ? resid[oidx + e] : 0.f);
+              if (flags & VCF_CLAMP) o = fminf(fmaxf(o, -1.f), 1.f);
+              y[oidx + e] = o;
+            }
+        }
+      }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pixel-wise producer of convolution input buffers:
 //   v = x[t,h,w,:];  norm: v = v / max(||v||_2, 1e-12) * sqrt(C) * gamma   (RMS_norm, vae.py:47-59: F.normalize * scale * gamma)
 //   else affine: v = v / a + b (per channel, either may be NULL)                 (z un-normalisation, vae.py:716-719)
@@ -302,8 +463,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
 // General pixel-wise producer (superset of vae_prep_kernel's affine path): v = x*mul[c] + add[c] (GroupNorm applied as a
 // per-channel affine), optional SiLU, optional clamp to [0,1], nearest upsampling x2 in H,W and/or in T where the FIRST
 // frame is not duplicated (UpsampleCausal3D.forward :168-187: frame 0 -> 0, frame t>=1 -> 2t-1 and 2t).
-template <int LPP>
-__global__ __launch_bounds__(256) void vae_prep_ex_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
+template <int LPP, typename OT = float>
+__global__ __launch_bounds__(256) void vae_prep_ex_kernel(const float* __restrict__ x, OT* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
                                                           const float* __restrict__ mul, const float* __restrict__ add, int silu, int clamp01, int up_hw,
                                                           int up_t, int64_t y_frame_stride, int64_t y_row_stride) {
   constexpr int GPB = 256 / LPP;
@@ -331,14 +492,16 @@ __global__ __launch_bounds__(256) void vae_prep_ex_kernel(const float* __restric
         if (silu) o[e] = o[e] / (1.f + __expf(-o[e]));
         if (clamp01) o[e] = fminf(fmaxf(o[e], 0.f), 1.f);
       }
-      const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+      // 4 channels per lane: a float4 or, for the fp16 conv operand buffers, 4 halves (strides are in elements of the output type)
+      struct alignas(sizeof(OT) * 4) Out4 { OT e[4]; };
+      const Out4 ov = {{(OT)o[0], (OT)o[1], (OT)o[2], (OT)o[3]}};
       for (int dt = 0; dt < nt; ++dt) {
-        float* yb = y + (t0 + dt) * y_frame_stride + (int64_t)(up_hw ? 2 * h : h) * y_row_stride + (int64_t)(up_hw ? 2 * wq : wq) * C + c4 * 4;
-        *reinterpret_cast<float4*>(yb) = ov;
+        OT* yb = y + (t0 + dt) * y_frame_stride + (int64_t)(up_hw ? 2 * h : h) * y_row_stride + (int64_t)(up_hw ? 2 * wq : wq) * C + c4 * 4;
+        *reinterpret_cast<Out4*>(yb) = ov;
         if (up_hw) {
-          *reinterpret_cast<float4*>(yb + C) = ov;
-          *reinterpret_cast<float4*>(yb + y_row_stride) = ov;
-          *reinterpret_cast<float4*>(yb + y_row_stride + C) = ov;
+          *reinterpret_cast<Out4*>(yb + C) = ov;
+          *reinterpret_cast<Out4*>(yb + y_row_stride) = ov;
+          *reinterpret_cast<Out4*>(yb + y_row_stride + C) = ov;
         }
       }
     }
@@ -549,6 +712,70 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_ex_f32(const 
   }
   X2V_LAUNCH_CHECK("vae_prep_ex launch");
   return X2V_OK;
+}
+
+// fp32 in, fp16 out: the operand buffer of x2v_vae_conv_f16 (strides in halves)
+extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_ex_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* mul, const float* add, int silu,
+                                                                          int clamp01, int up_hw, int up_t, int64_t y_frame_stride, int64_t y_row_stride, void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "vae_prep_ex_f16: null pointer");
+  X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 8 == 0, X2V_E_SHAPE, "vae_prep_ex_f16: bad shape (C %% 8 == 0)");
+  X2V_REQUIRE(y_frame_stride % 8 == 0 && y_row_stride % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(mul) && aligned16(add), X2V_E_ALIGN,
+              "vae_prep_ex_f16: 16-byte alignment");
+  const int64_t npix = (int64_t)T * Hh * Ww;
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 128) {
+    const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_ex_kernel<32, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, mul, add, silu, clamp01, up_hw, up_t,
+                       y_frame_stride, y_row_stride);
+  } else {
+    const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_ex_kernel<64, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, mul, add, silu, clamp01, up_hw, up_t,
+                       y_frame_stride, y_row_stride);
+  }
+  X2V_LAUNCH_CHECK("vae_prep_ex_f16 launch");
+  return X2V_OK;
+}
+
+template <int NF>
+static int launch_vconv16(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
+                          int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, hipStream_t st) {
+  constexpr int lds = 2 * (VC_PIX + 32 * NF) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)vae_conv16_kernel<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "vae conv16 attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  const int64_t ptiles = (int64_t)T * (((int64_t)Hh * Ww + VC_PIX - 1) / VC_PIX);
+  const int ncol = (Cout + 32 * NF - 1) / (32 * NF);
+  X2V_REQUIRE(ptiles * ncol < (1ll << 31), X2V_E_SHAPE, "vae_conv_f16: too many tiles");
+  hipLaunchKernelGGL((vae_conv16_kernel<NF>), dim3((unsigned)(ptiles * ncol)), dim3(256), lds, st, (const _Float16*)xp, fs, rs, ps, (const _Float16*)w, wrs, bias, resid,
+                     y, T, Hh, Ww, Cin, Cout, kt, kh, kw, flags, ncol);
+  X2V_LAUNCH_CHECK("vae_conv_f16 launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w,
+                                                                       int64_t w_row_stride, const float* bias, const float* resid, float* y, int T, int Hh, int Ww,
+                                                                       int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream) {
+  X2V_REQUIRE(xp && w && y, X2V_E_ARG, "vae_conv_f16: null pointer");
+  X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && Cin > 0 && Cout > 0, X2V_E_SHAPE, "vae_conv_f16: bad shape");
+  X2V_REQUIRE(kt >= 1 && kt <= 3 && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3, X2V_E_SHAPE, "vae_conv_f16: kernel %dx%dx%d unsupported", kt, kh, kw);
+  X2V_REQUIRE(Cin % 64 == 0, X2V_E_SHAPE, "vae_conv_f16: Cin=%d must be a multiple of 64 (one 128-byte row per K step)", Cin);
+  X2V_REQUIRE(x_px_stride % 8 == 0 && x_row_stride % 8 == 0 && x_frame_stride % 8 == 0 && w_row_stride % 8 == 0 && x_px_stride >= Cin &&
+                  w_row_stride >= (int64_t)kt * kh * kw * Cin,
+              X2V_E_ALIGN, "vae_conv_f16: strides must be multiples of 8 halves and cover the extents");
+  X2V_REQUIRE(aligned16(xp) && aligned16(w) && aligned16(y) && aligned16(resid) && aligned16(bias), X2V_E_ALIGN, "vae_conv_f16: pointers must be 16-byte aligned");
+  X2V_REQUIRE(x_frame_stride * 2 * kt < (1ll << 31) && w_row_stride * 2 * 128 < (1ll << 31), X2V_E_SHAPE,
+              "vae_conv_f16: a kt-frame input window / 128 weight rows must stay below 2 GiB (32-bit buffer offsets)");
+  X2V_REQUIRE(!(flags & VCF_TSPLIT) || (Cout % 8 == 0 && resid == nullptr), X2V_E_ARG, "vae_conv_f16: time-split output needs Cout %% 8 == 0 and no residual");
+  hipStream_t st = (hipStream_t)stream;
+#define X2V_VC16(NF_) return launch_vconv16<NF_>(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, kh, kw, flags, st)
+  if (Cout <= 32) X2V_VC16(1);
+  else if (Cout % 128 != 0 && Cout % 96 == 0) X2V_VC16(3);
+  else if (Cout <= 64) X2V_VC16(2);
+  else X2V_VC16(4);
+#undef X2V_VC16
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_vae_replicate_border_f32(float* buf, int frames, int lead, int Hp, int Wp, int C, int pad, void* stream) {

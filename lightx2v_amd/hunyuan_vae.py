@@ -33,8 +33,11 @@ def _cl(w):
 class DecoderCausal3D:
     """reference: autoencoder_kl_causal_3d/vae.py:133-283."""
 
-    def __init__(self, sd, cfg, device):
+    def __init__(self, sd, cfg, device, conv16=True):
         self.cfg, self.device = cfg, device
+        # 3x3x3 convolutions with Cin % 64 == 0 (all but conv_in) take fp16 operands when conv16 — the reference's precision for this VAE
+        # (hunyuan_runner.py:40: dtype fp16); accumulation, bias, residual stream, GroupNorm statistics and the attention stay fp32
+        self.conv16 = conv16
         self.groups = cfg["norm_num_groups"]
         self.plan = synth.hunyuan_vae_up_plan(cfg)
         self.w = {}
@@ -47,6 +50,7 @@ class DecoderCausal3D:
         self.w[a + "qkv.weight"] = torch.cat([self.w[a + f"to_{n}.weight"] for n in "qkv"], 0).contiguous()  # load-time fusion of the three projections
         self.w[a + "qkv.bias"] = torch.cat([self.w[a + f"to_{n}.bias"] for n in "qkv"], 0).contiguous()
         self._bufs = {}
+        self.w16 = {k: v.to(torch.float16).contiguous() for k, v in self.w.items() if conv16 and v.dim() == 5 and v.shape[1:4] == (3, 3, 3) and v.shape[4] % 64 == 0}
 
     # ---- building blocks ----------------------------------------------------------------------------------------------
     def _conv3(self, name, x, affine=None, silu=False, up_t=False, up_hw=False, resid=None):
@@ -54,17 +58,21 @@ class DecoderCausal3D:
         t, h, w, c = x.shape
         to = 2 * t - 1 if up_t else t
         ho, wo = (2 * h, 2 * w) if up_hw else (h, w)
-        key = (to, ho, wo, c)
+        w16 = self.w16.get(name + ".weight")
+        key = (to, ho, wo, c, w16 is not None)
         buf = self._bufs.get(key)
         if buf is None:
-            buf = self._bufs[key] = torch.empty((2 + to, ho + 2, wo + 2, c), dtype=torch.float32, device=x.device)
+            buf = self._bufs[key] = torch.empty((2 + to, ho + 2, wo + 2, c), dtype=torch.float16 if w16 is not None else torch.float32, device=x.device)
         strides = ((ho + 2) * (wo + 2) * c, (wo + 2) * c, c)
         mul, add = affine if affine is not None else (None, None)
         lib.vae_prep_ex(x, buf[2:, 1:, 1:, :], strides[:2], mul=mul, add=add, silu=silu, up_hw=up_hw, up_t=up_t)
         lib.vae_replicate_border_(buf, 2, 1)
         wt = self.w[name + ".weight"]
         out = torch.empty((to, ho, wo, wt.shape[0]), dtype=torch.float32, device=x.device)
-        lib.vae_conv(buf, strides, wt, out, to, ho, wo, bias=self.w[name + ".bias"], resid=resid)
+        if w16 is not None:
+            lib.vae_conv16(buf, strides, w16, out, to, ho, wo, bias=self.w[name + ".bias"], resid=resid)
+        else:
+            lib.vae_conv(buf, strides, wt, out, to, ho, wo, bias=self.w[name + ".bias"], resid=resid)
         return out
 
     def _conv1(self, name, x, resid=None):
@@ -123,10 +131,10 @@ class DecoderCausal3D:
 class AutoencoderKLCausal3D:
     """reference: autoencoder_kl_causal_3d.py:58-518 (decode side, tiling enabled as model.py:38 always does)."""
 
-    def __init__(self, sd, cfg=None, device="cuda"):
+    def __init__(self, sd, cfg=None, device="cuda", conv16=True):
         self.cfg = cfg or synth.HUNYUAN_VAE_CFG
         self.device = device
-        self.decoder = DecoderCausal3D(sd, self.cfg, device)
+        self.decoder = DecoderCausal3D(sd, self.cfg, device, conv16=conv16)
         zc = self.cfg["latent_channels"]
         self.pq_w = sd["post_quant_conv.weight"].to(device=device, dtype=torch.float32).reshape(zc, zc).contiguous()
         self.pq_b = sd["post_quant_conv.bias"].to(device=device, dtype=torch.float32).contiguous()
@@ -217,8 +225,9 @@ class AutoencoderKLCausal3D:
 class VideoEncoderKLCausal3DModel:
     """reference: autoencoder_kl_causal_3d/model.py:6-44 (decode side)."""
 
-    def __init__(self, sd, cfg=None, device="cuda"):
-        self.model = AutoencoderKLCausal3D(sd, cfg, device)
+    def __init__(self, sd, cfg=None, device="cuda", conv16=True):
+        """conv16 (default): fp16 operands for the 3x3x3 convolutions — the reference's precision for this VAE; False: everything fp32."""
+        self.model = AutoencoderKLCausal3D(sd, cfg, device, conv16=conv16)
         self.device = device
 
     def decode(self, latents, generator=None, config=None):

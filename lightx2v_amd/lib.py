@@ -51,6 +51,8 @@ PROTOTYPES = {
     "x2v_vae_conv_f32": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "x2v_vae_prep_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_softmax_rows_f32": [_c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
+    "x2v_vae_conv_f16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+    "x2v_vae_prep_ex_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_vae_prep_ex_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_vae_replicate_border_f32": [_c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "x2v_groupnorm_affine_f32": [_c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p, _f32, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
@@ -402,6 +404,18 @@ def vae_conv(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0, 
     return out
 
 
+def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0):
+    """x2v_vae_conv_f16: fp16 operand buffer `xp` (strides in halves) and fp16 weight [Cout,kt,kh,kw,Cin], fp32 bias / resid / out."""
+    if xp.dtype != torch.float16 or weight.dtype != torch.float16 or not xp.is_cuda or not weight.is_contiguous():
+        raise X2VError("vae_conv16: operand buffer and weight must be CUDA float16 (weight contiguous)")
+    _f32c(out, "vae_conv16 out")
+    Cout, kt, kh, kw, Cin = weight.shape
+    fs, rs, ps = strides
+    init()
+    _check(_lib.x2v_vae_conv_f16(_p(xp), fs, rs, ps, _p(weight), weight.stride(0), _p(bias), _p(resid), _p(out), T, H, W, Cin, Cout, kt, kh, kw, flags, _stream()), "vae_conv16")
+    return out
+
+
 def vae_prep(x, y_view, y_strides, gamma=None, a=None, b=None, silu=False, upsample=False):
     """x [T,H,W,C] contiguous fp32 -> y_view (first element = destination of pixel (0,0,0)); y_strides = (frame, row) in floats."""
     _f32c(x, "vae_prep x"), _f32c(y_view, "vae_prep y")
@@ -428,14 +442,21 @@ def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mo
 
 
 def vae_prep_ex(x, y_view, y_strides, mul=None, add=None, silu=False, clamp01=False, up_hw=False, up_t=False):
+    """fp32 x [T,H,W,C] → y_view (fp32, or fp16 for the 16-bit convolution's operand buffer; strides in elements of y)."""
     T, H, W, C = x.shape
     init()
+    if y_view.dtype == torch.float16:
+        _check(_lib.x2v_vae_prep_ex_f16(_p(x), _p(y_view), T, H, W, C, _p(mul), _p(add), int(silu), int(clamp01), int(up_hw), int(up_t), y_strides[0], y_strides[1], _stream()),
+               "vae_prep_ex_f16")
+        return
     _check(_lib.x2v_vae_prep_ex_f32(_p(x), _p(y_view), T, H, W, C, _p(mul), _p(add), int(silu), int(clamp01), int(up_hw), int(up_t), y_strides[0], y_strides[1], _stream()),
            "vae_prep_ex")
 
 
 def vae_replicate_border_(buf, lead, pad):
     frames, hp, wp, c = buf.shape
+    if buf.dtype == torch.float16:  # the kernel moves whole pixels: a pixel of C halves is C/2 floats
+        c //= 2
     init()
     _check(_lib.x2v_vae_replicate_border_f32(_p(buf), frames, lead, hp, wp, c, pad, _stream()), "vae_replicate_border")
 
