@@ -131,9 +131,12 @@ class DecoderCausal3D:
 class AutoencoderKLCausal3D:
     """reference: autoencoder_kl_causal_3d.py:58-518 (decode side, tiling enabled as model.py:38 always does)."""
 
-    def __init__(self, sd, cfg=None, device="cuda", conv16=True):
+    def __init__(self, sd, cfg=None, device="cuda", conv16=True, group=None):
+        """group: a torch.distributed process group (e.g. the sequence-parallel group of the denoise loop) — the independent tiles of
+        the tiled decode are then shared out over its ranks (not in the reference, whose `parallel_vae` covers the Wan VAE only)."""
         self.cfg = cfg or synth.HUNYUAN_VAE_CFG
         self.device = device
+        self.group = group
         self.decoder = DecoderCausal3D(sd, self.cfg, device, conv16=conv16)
         zc = self.cfg["latent_channels"]
         self.pq_w = sd["post_quant_conv.weight"].to(device=device, dtype=torch.float32).reshape(zc, zc).contiguous()
@@ -160,19 +163,56 @@ class AutoencoderKLCausal3D:
     def blend_t(self, a, b, extent):
         return lib.blend_axis_(a, b, 0, extent)
 
-    def spatial_tiled_decode(self, z):
-        """reference :405-451.  z [T, H, W, 16]."""
-        lat, smp = self.tile_latent_min_size, self.tile_sample_min_size
+    # The reference decodes tile after tile inside the tiling loops.  Here the loops run twice over the same tile order: once to list
+    # the latent tiles, once to blend the decoded ones — in between, the tiles are decoded either serially or, with a process group,
+    # one share per rank (tiles are independent; every rank then holds all of them and blends redundantly: bit-identical output).
+    def _spatial_tiles(self, z):
+        lat = self.tile_latent_min_size
         overlap = int(lat * (1 - self.tile_overlap_factor))
+        return [[z[:, i : i + lat, j : j + lat, :].contiguous() for j in range(0, z.shape[2], overlap)] for i in range(0, z.shape[1], overlap)]
+
+    def _temporal_tiles(self, z):
+        lat_t = self.tile_latent_min_tsize
+        overlap = int(lat_t * (1 - self.tile_overlap_factor))
+        return [z[i : i + lat_t + 1] for i in range(0, z.shape[0], overlap)]
+
+    def _needs_spatial(self, z):
+        return z.shape[1] > self.tile_latent_min_size or z.shape[2] > self.tile_latent_min_size
+
+    def _jobs(self, z):
+        """Latent tiles in the order the blending loops consume their decodes."""
+        if z.shape[0] > self.tile_latent_min_tsize:
+            out = []
+            for tt in self._temporal_tiles(z):
+                out += [t for row in self._spatial_tiles(tt) for t in row] if self._needs_spatial(tt) else [tt.contiguous()]
+            return out
+        if self._needs_spatial(z):
+            return [t for row in self._spatial_tiles(z) for t in row]
+        return [z]
+
+    def _decode_jobs(self, jobs):
+        one = lambda tile: self.decoder.forward(self.post_quant_conv(tile))  # noqa: E731
+        if self.group is None:
+            return [one(t) for t in jobs]
+        import torch.distributed as dist
+
+        n, r = dist.get_world_size(self.group), dist.get_rank(self.group)
+        tc, sc = self.cfg["time_compression_ratio"], self.cfg["spatial_compression_ratio"]
+        outs = [one(t) if k % n == r else torch.empty((tc * (t.shape[0] - 1) + 1, sc * t.shape[1], sc * t.shape[2], 3), dtype=torch.float32, device=t.device)
+                for k, t in enumerate(jobs)]  # own share first (all ranks compute concurrently) ...
+        for k, o in enumerate(outs):  # ... then every tile travels from its owner to everyone
+            dist.broadcast(o, src=dist.get_global_rank(self.group, k % n) if self.group is not dist.group.WORLD else k % n, group=self.group)
+        return outs
+
+    def spatial_tiled_decode(self, z, decoded=None):
+        """reference :405-451.  z [T, H, W, 16]; `decoded`: iterator over the decoded tiles in `_spatial_tiles` order."""
+        smp = self.tile_sample_min_size
         extent = int(smp * self.tile_overlap_factor)
         limit = smp - extent
-        rows = []
-        for i in range(0, z.shape[1], overlap):
-            row = []
-            for j in range(0, z.shape[2], overlap):
-                tile = z[:, i : i + lat, j : j + lat, :].contiguous()
-                row.append(self.decoder.forward(self.post_quant_conv(tile)))
-            rows.append(row)
+        tiles = self._spatial_tiles(z)
+        if decoded is None:
+            decoded = iter(self._decode_jobs([t for row in tiles for t in row]))
+        rows = [[next(decoded) for _ in row] for row in tiles]
         out_rows = []
         for i, row in enumerate(rows):
             out = []
@@ -185,19 +225,16 @@ class AutoencoderKLCausal3D:
             out_rows.append(torch.cat(out, dim=2))
         return torch.cat(out_rows, dim=1)
 
-    def temporal_tiled_decode(self, z):
+    def temporal_tiled_decode(self, z, decoded=None):
         """reference :487-518."""
-        lat, lat_t, smp_t = self.tile_latent_min_size, self.tile_latent_min_tsize, self.tile_sample_min_tsize
-        overlap = int(lat_t * (1 - self.tile_overlap_factor))
+        smp_t = self.tile_sample_min_tsize
         extent = int(smp_t * self.tile_overlap_factor)
         t_limit = smp_t - extent
+        if decoded is None:
+            decoded = iter(self._decode_jobs(self._jobs(z)))
         row = []
-        for i in range(0, z.shape[0], overlap):
-            tile = z[i : i + lat_t + 1]
-            if tile.shape[1] > lat or tile.shape[2] > lat:
-                dec = self.spatial_tiled_decode(tile)
-            else:
-                dec = self.decoder.forward(self.post_quant_conv(tile.contiguous()))
+        for i, tile in enumerate(self._temporal_tiles(z)):
+            dec = self.spatial_tiled_decode(tile, decoded) if self._needs_spatial(tile) else next(decoded)
             if i > 0:
                 dec = dec[1:]
             row.append(dec.contiguous())
@@ -214,7 +251,7 @@ class AutoencoderKLCausal3D:
         """reference :286-301 (both tilings enabled)."""
         if z.shape[0] > self.tile_latent_min_tsize:
             return self.temporal_tiled_decode(z)
-        if z.shape[1] > self.tile_latent_min_size or z.shape[2] > self.tile_latent_min_size:
+        if self._needs_spatial(z):
             return self.spatial_tiled_decode(z)
         return self.decoder.forward(self.post_quant_conv(z))
 
@@ -225,9 +262,10 @@ class AutoencoderKLCausal3D:
 class VideoEncoderKLCausal3DModel:
     """reference: autoencoder_kl_causal_3d/model.py:6-44 (decode side)."""
 
-    def __init__(self, sd, cfg=None, device="cuda", conv16=True):
-        """conv16 (default): fp16 operands for the 3x3x3 convolutions — the reference's precision for this VAE; False: everything fp32."""
-        self.model = AutoencoderKLCausal3D(sd, cfg, device, conv16=conv16)
+    def __init__(self, sd, cfg=None, device="cuda", conv16=True, group=None):
+        """conv16 (default): fp16 operands for the 3x3x3 convolutions — the reference's precision for this VAE; False: everything fp32.
+        group: process group whose ranks share the tiles of the tiled decode (see AutoencoderKLCausal3D)."""
+        self.model = AutoencoderKLCausal3D(sd, cfg, device, conv16=conv16, group=group)
         self.device = device
 
     def decode(self, latents, generator=None, config=None):

@@ -35,3 +35,12 @@ def test_wan_vae_decode_dist_world2_on_one_gpu():
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_GPU_VAE_OK" in p.stdout
+
+
+def test_hunyuan_vae_tile_parallel_world2_on_one_gpu():
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "tests", "_dist_gpu_worker_hunyuan_vae.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "DIST_GPU_HUNYUAN_VAE_OK" in p.stdout
