@@ -235,6 +235,11 @@ int x2v_vae_prep_ex_f32(const float* x, float* y, int T, int Hh, int Ww, int C, 
 int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w, int64_t w_row_stride, const float* bias,
                      const float* resid, float* y, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream);
 
+/* x2v_vae_prep_f32 writing fp16 with an explicit pixel stride y_px_stride >= C (the Wan decoder's 96-channel stage pads its operand
+ * buffers to 128 channels for x2v_vae_conv_f16's 64-channel K steps; pad channels are never written and stay zero). */
+int x2v_vae_prep_f16(const float* x, void* y, int T, int H, int W, int C, const float* gamma, const float* a, const float* b, int silu, int upsample,
+                     int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, void* stream);
+
 /* x2v_vae_prep_ex_f32 writing fp16: fills the operand buffer of x2v_vae_conv_f16 (y strides in halves, C % 8 == 0). */
 int x2v_vae_prep_ex_f16(const float* x, void* y, int T, int H, int W, int C, const float* mul, const float* add, int silu, int clamp01, int up_hw, int up_t,
                         int64_t y_frame_stride, int64_t y_row_stride, void* stream);

@@ -364,10 +364,10 @@ __global__ __launch_bounds__(256) void vae_conv16_kernel(const _Float16* __restr
 //   up: the result is written to the 2x2 output pixels (2h+{0,1}, 2w+{0,1})       (Upsample nearest-exact x2, vae.py:62-67,87-95)
 // Output addressing: y + t*y_frame_stride + h*y_row_stride + w*C (the caller passes y already offset to the
 // interior origin of a zero-bordered buffer).  One group of LPP lanes per pixel, 16-byte accesses.
-template <int LPP>
-__global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
+template <int LPP, typename OT = float>
+__global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__ x, OT* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ a, const float* __restrict__ b,
-                                                       int silu, int up, int64_t y_frame_stride, int64_t y_row_stride) {
+                                                       int silu, int up, int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride) {
   constexpr int GPB = 256 / LPP;  // pixel groups per block
   const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
   const int nch = C / 4;
@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
     const int64_t t = pix / ((int64_t)Hh * Ww);
     const int rem = (int)(pix - t * (int64_t)Hh * Ww);
     const int h = rem / Ww, wq = rem - h * Ww;
-    float* yb = y + t * y_frame_stride + (int64_t)(up ? 2 * h : h) * y_row_stride + (int64_t)(up ? 2 * wq : wq) * C;
+    // y_px_stride >= C: the fp16 operand buffers pad the channel axis to a multiple of 64 (pad channels stay zero)
+    OT* yb = y + t * y_frame_stride + (int64_t)(up ? 2 * h : h) * y_row_stride + (int64_t)(up ? 2 * wq : wq) * y_px_stride;
+    struct alignas(sizeof(OT) * 4) Out4 { OT e[4]; };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c4 = l + k * LPP;
@@ -417,12 +419,12 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = o[e] / (1.f + __expf(-o[e]));
       }
-      const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(yb + c4 * 4) = ov;
+      const Out4 ov = {{(OT)o[0], (OT)o[1], (OT)o[2], (OT)o[3]}};
+      *reinterpret_cast<Out4*>(yb + c4 * 4) = ov;
       if (up) {
-        *reinterpret_cast<float4*>(yb + C + c4 * 4) = ov;
-        *reinterpret_cast<float4*>(yb + y_row_stride + c4 * 4) = ov;
-        *reinterpret_cast<float4*>(yb + y_row_stride + C + c4 * 4) = ov;
+        *reinterpret_cast<Out4*>(yb + y_px_stride + c4 * 4) = ov;
+        *reinterpret_cast<Out4*>(yb + y_row_stride + c4 * 4) = ov;
+        *reinterpret_cast<Out4*>(yb + y_row_stride + y_px_stride + c4 * 4) = ov;
       }
     }
   }
@@ -676,10 +678,12 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_f32(const flo
   hipStream_t st = (hipStream_t)stream;
   if (C <= 128) {
     const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
-    hipLaunchKernelGGL((vae_prep_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride);
+    hipLaunchKernelGGL((vae_prep_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride,
+                       (int64_t)C);
   } else {
     const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
-    hipLaunchKernelGGL((vae_prep_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride);
+    hipLaunchKernelGGL((vae_prep_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride,
+                       (int64_t)C);
   }
   X2V_LAUNCH_CHECK("vae_prep launch");
   return X2V_OK;
@@ -711,6 +715,30 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_ex_f32(const 
     hipLaunchKernelGGL((vae_prep_ex_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, npix, Hh, Ww, C, mul, add, silu, clamp01, up_hw, up_t, y_frame_stride, y_row_stride);
   }
   X2V_LAUNCH_CHECK("vae_prep_ex launch");
+  return X2V_OK;
+}
+
+// x2v_vae_prep_f32 writing fp16 with an explicit pixel stride (channel axis padded to a multiple of 64 for x2v_vae_conv_f16); strides in halves
+extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a,
+                                                                       const float* b, int silu, int upsample, int64_t y_frame_stride, int64_t y_row_stride,
+                                                                       int64_t y_px_stride, void* stream) {
+  X2V_REQUIRE(x && y, X2V_E_ARG, "vae_prep_f16: null pointer");
+  X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 4 == 0 && C <= 1024, X2V_E_SHAPE, "vae_prep_f16: bad shape (C %% 4 == 0, C <= 1024)");
+  X2V_REQUIRE(y_frame_stride % 8 == 0 && y_row_stride % 8 == 0 && y_px_stride % 8 == 0 && y_px_stride >= C && aligned16(x) && aligned16(y) && aligned16(gamma) &&
+                  aligned16(a) && aligned16(b),
+              X2V_E_ALIGN, "vae_prep_f16: 16-byte alignment (strides multiples of 8 halves)");
+  const int64_t npix = (int64_t)T * Hh * Ww;
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 128) {
+    const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_kernel<32, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
+                       y_frame_stride, y_row_stride, y_px_stride);
+  } else {
+    const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_kernel<64, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
+                       y_frame_stride, y_row_stride, y_px_stride);
+  }
+  X2V_LAUNCH_CHECK("vae_prep_f16 launch");
   return X2V_OK;
 }
 

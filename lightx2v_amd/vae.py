@@ -26,11 +26,15 @@ from . import lib, synth
 class _ConvInput:
     """Zero-bordered, cache-carrying input buffer of one convolution: [lead + t_max][H + 2p][W + 2p][C]."""
 
-    def __init__(self, t_max, h, w, c, kt, pad, device):
-        self.lead, self.pad, self.h, self.w, self.c = kt - 1, pad, h, w, c
+    def __init__(self, t_max, h, w, c, kt, pad, device, dtype=torch.float32):
+        self.lead, self.pad, self.h, self.w = kt - 1, pad, h, w
+        # fp16 operand buffers (opt-in 16-bit convolution) pad the channel axis to the kernel's 64-channel K step; the pad channels are
+        # never written and stay zero (as do the matching weight columns)
+        self.c = c if dtype == torch.float32 else (c + 63) // 64 * 64
+        c = self.c
         self.hp, self.wp = h + 2 * pad, w + 2 * pad
-        self.buf = torch.zeros((self.lead + t_max, self.hp, self.wp, c), dtype=torch.float32, device=device)
-        self.strides = (self.hp * self.wp * c, self.wp * c, c)  # frame, row, pixel (floats)
+        self.buf = torch.zeros((self.lead + t_max, self.hp, self.wp, c), dtype=dtype, device=device)
+        self.strides = (self.hp * self.wp * c, self.wp * c, c)  # frame, row, pixel (elements)
 
     def interior(self):
         """View whose first element is where pixel (t=0, h=0, w=0) of the new frames goes."""
@@ -61,8 +65,9 @@ def _cl(weight):
 class Decoder3d:
     """reference: vae.py:377-489."""
 
-    def __init__(self, sd, dim, latent_hw, device):
+    def __init__(self, sd, dim, latent_hw, device, conv16=False):
         self.device = device
+        self.conv16 = conv16  # opt-in: fp16 operands for the 3x3(x3) convolutions (the reference runs this VAE in fp32: default off)
         self.dims, self.plan = synth.wan_vae_decoder_plan(dim)
         self.w = {}
         for k, v in sd.items():
@@ -70,15 +75,23 @@ class Decoder3d:
                 continue
             v = v.to(device=device, dtype=torch.float32)
             self.w[k] = _cl(v) if (k.endswith(".weight") and v.dim() >= 4) else v.reshape(-1).contiguous()
+        self.w16 = {}
+        if conv16:
+            for k, v in self.w.items():
+                if k.endswith(".weight") and v.dim() == 5 and v.shape[1] * v.shape[2] * v.shape[3] > 1 and v.shape[4] >= 32:
+                    cp = (v.shape[4] + 63) // 64 * 64
+                    w16 = torch.zeros((*v.shape[:4], cp), dtype=torch.float16, device=device)
+                    w16[..., : v.shape[4]] = v
+                    self.w16[k] = w16
         self.h0, self.w0 = latent_hw
         self._bufs = {}
         self._rep = {}  # upsample3d time-conv state: False until the first chunk has passed (the reference's "Rep", vae.py:113-115)
 
     # ---- buffers ------------------------------------------------------------------------------------------------------
-    def _input(self, key, t, h, w, c, kt, pad):
+    def _input(self, key, t, h, w, c, kt, pad, dtype=torch.float32):
         b = self._bufs.get(key)
         if b is None or b.buf.shape[0] < b.lead + t:
-            nb = _ConvInput(max(t, 4 if kt == 3 else t), h, w, c, kt, pad, self.device)
+            nb = _ConvInput(max(t, 4 if kt == 3 else t), h, w, c, kt, pad, self.device, dtype)
             if b is not None and b.lead:
                 nb.buf[: b.lead].copy_(b.buf[: b.lead])
             self._bufs[key] = b = nb
@@ -97,13 +110,17 @@ class Decoder3d:
         wt = self.w[name + ".weight"]
         cout, wkt, kh, kw, _ = wt.shape
         ho, wo = (2 * h, 2 * w) if upsample else (h, w)
-        b = self._input(key, t, ho, wo, c, wkt, kh // 2)
+        w16 = self.w16.get(name + ".weight")
+        b = self._input(key, t, ho, wo, c, wkt, kh // 2, torch.float16 if w16 is not None else torch.float32)
         lib.vae_prep(x, b.interior(), b.strides[:2], gamma=gamma, silu=silu, upsample=upsample)
         if flags & lib.VCONV_TSPLIT:
             out = torch.empty((2 * t, ho, wo, cout // 2), dtype=torch.float32, device=x.device)
         else:
             out = torch.empty((t, ho, wo, cout), dtype=torch.float32, device=x.device)
-        lib.vae_conv(b.buf, b.strides, wt, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
+        if w16 is not None:
+            lib.vae_conv16(b.buf, b.strides, w16, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
+        else:
+            lib.vae_conv(b.buf, b.strides, wt, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
         b.roll(t)
         return out
 
@@ -171,8 +188,8 @@ class Decoder3d:
 class WanVAE_:
     """reference: vae.py:640-760 (decode side)."""
 
-    def __init__(self, sd, dim=96, z_dim=16, device="cuda"):
-        self.dim, self.z_dim, self.device = dim, z_dim, device
+    def __init__(self, sd, dim=96, z_dim=16, device="cuda", conv16=False):
+        self.dim, self.z_dim, self.device, self.conv16 = dim, z_dim, device, conv16
         self.sd = sd
         self.conv2_w = sd["conv2.weight"].to(device=device, dtype=torch.float32).reshape(z_dim, z_dim).contiguous()
         self.conv2_b = sd["conv2.bias"].to(device=device, dtype=torch.float32).contiguous()
@@ -182,7 +199,7 @@ class WanVAE_:
         """z [1, 16, T, h, w] fp32; scale = [mean, inv_std] → [1, 3, 1 + 4 (T-1), 8h, 8w], clamped to [-1, 1]."""
         zc, t, h, w = z.shape[1:]
         if self.decoder is None or (self.decoder.h0, self.decoder.w0) != (h, w):
-            self.decoder = Decoder3d(self.sd, self.dim, (h, w), self.device)
+            self.decoder = Decoder3d(self.sd, self.dim, (h, w), self.device, conv16=self.conv16)
         self.decoder.clear_cache()
         zl = z[0].permute(1, 2, 3, 0).contiguous().float()  # [T, h, w, 16]
         zn = torch.empty_like(zl)
@@ -198,12 +215,14 @@ class WanVAE_:
 class WanVAE:
     """reference: vae.py:789-957 (decode side; `use_tiling` is not built)."""
 
-    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False):
+    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False, conv16=False):
+        """conv16: opt-in fast decode — fp16 operands for the 3x3(x3) convolutions on the 16-bit MFMA (fp32 accumulation, residual
+        stream, norms and attention).  Off by default: the reference decodes in fp32 (vae.py:794) and so does this class."""
         self.device, self.parallel = device, parallel
         self.mean = torch.tensor(synth.WAN_VAE_MEAN, dtype=torch.float32, device=device)
         self.inv_std = 1.0 / torch.tensor(synth.WAN_VAE_STD, dtype=torch.float32, device=device)
         self.scale = [self.mean, self.inv_std]
-        self.model = WanVAE_(sd, dim=dim, z_dim=z_dim, device=device)
+        self.model = WanVAE_(sd, dim=dim, z_dim=z_dim, device=device, conv16=conv16)
 
     def decode_dist(self, zs, world_size, cur_rank, split_dim):
         """reference: vae.py:883-929 — each rank decodes its slab of the latent (split along H = dim 2 or W = dim 3) plus a

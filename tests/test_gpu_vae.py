@@ -103,6 +103,56 @@ def test_vae_decode_matches_reference_fixture():
     assert torch.equal(out, out2)
 
 
+def test_vae_decode_fp16_operands_opt_in():
+    """Opt-in fast decode (WanVAE(conv16=True)): fp16 operands for the 3x3(x3) convolutions, everything else fp32 — against the fp32
+    fixture generated from the reference.  Stated tolerance on outputs in [-1, 1]: |d| <= 2e-2, relative L2 <= 1e-2.  The tiny model's
+    32- and 128-channel stages exercise the channel padding (32 -> 64) of the 16-bit kernel's operand buffers; dim = 96 does 96 -> 128."""
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import lib, synth, vae
+    from oracle import wan_vae_oracle as V
+
+    # the 16-bit convolution itself against conv3d on fp16-rounded operands (fp32 accumulate): tight
+    g = torch.Generator().manual_seed(2)
+    T, H, W, Cin, Cout = 2, 9, 11, 96, 160
+    x = torch.randn(T, H, W, Cin, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    xin = F.pad(x.float().permute(3, 0, 1, 2), (1, 1, 1, 1, 2, 0))
+    ref = F.conv3d(xin.unsqueeze(0), w.float(), b)[0].permute(1, 2, 3, 0)
+    cp = 128
+    buf = torch.zeros(2 + T, H + 2, W + 2, cp, dtype=torch.float16, device="cuda")
+    buf[2:, 1 : 1 + H, 1 : 1 + W, :Cin] = x.cuda()
+    w16 = torch.zeros(Cout, 3, 3, 3, cp, dtype=torch.float16, device="cuda")
+    w16[..., :Cin] = w.permute(0, 2, 3, 4, 1).cuda()
+    out = torch.empty(T, H, W, Cout, device="cuda")
+    lib.vae_conv16(buf, ((H + 2) * (W + 2) * cp, (W + 2) * cp, cp), w16, out, T, H, W, bias=b.cuda())
+    _check(out, ref, "fp16-operand conv vs conv3d on the same rounded operands", atol=2e-4, rel=1e-5)
+    # norm + SiLU written as fp16 into a channel-padded buffer
+    C = 96
+    xx = torch.randn(2, 5, 6, C, generator=g) * 2
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    y = torch.zeros(2, 7, 8, 128, dtype=torch.float16, device="cuda")
+    lib.vae_prep(xx.cuda(), y[:, 1:, 1:], (7 * 8 * 128, 8 * 128), gamma=gamma.cuda(), silu=True)
+    refp = F.silu(F.normalize(xx, dim=-1) * C**0.5 * gamma)
+    _check(y[:, 1:6, 1:7, :C], refp.half(), "norm+silu -> fp16 padded buffer", atol=2e-3, rel=1e-3)
+    assert y[..., C:].abs().max() == 0 and y[:, 0].abs().max() == 0
+    # whole decodes
+    gld = load_file(os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
+    dim, seed = int(gld["dim"]), int(gld["seed"])
+    m = vae.WanVAE(synth.synth_wan_vae_weights(dim=dim, seed=seed), dim=dim, conv16=True)
+    out = m.decode(gld["z"].cuda())
+    assert m.model.decoder.w16, "no convolution took the 16-bit path"
+    _check(out[0], gld["decoded"], "WanVAE.decode (fp16 conv operands) vs reference fixture", atol=2e-2, rel=1e-2)
+    sd = synth.synth_wan_vae_weights(dim=96, seed=3)
+    z = torch.randn(16, 2, 6, 8, generator=torch.Generator().manual_seed(6))
+    mean, inv_std = torch.tensor(synth.WAN_VAE_MEAN), 1.0 / torch.tensor(synth.WAN_VAE_STD)
+    with torch.no_grad():
+        ref96 = V.wan_vae_decode(sd, z, mean, inv_std, dim=96)
+    out96 = vae.WanVAE(sd, dim=96, conv16=True).decode(z.cuda())
+    _check(out96[0], ref96, "WanVAE.decode dim 96 (fp16 conv operands) vs oracle", atol=2e-2, rel=1e-2)
+
+
 def test_vae_decode_real_widths_vs_oracle():
     """dim = 96 (384/384/384/192/96 channels, the released Wan2.1 VAE widths) on a small latent; checker = CPU oracle."""
     from lightx2v_amd import synth, vae
