@@ -161,6 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   if constexpr (!FP8) {                                                                                                        \
     _Pragma("unroll") for (int idx_ = 0; idx_ < 8; ++idx_) {                                                                   \
       const int ks_ = idx_ >> 1, i_ = idx_ & 1;                                                                                \
+      if (SCHED == 2 && (idx_ & 2)) continue; /* timing probe: half of the MFMAs (results invalid) */                            \
       acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WB_[ks_]),                  \
                                                                       __builtin_bit_cast(bf16x8_t, xa[i_][ks_]), acc[(MI0_) + i_][NJ_], 0, 0, 0); \
       if (SCHED == 1 && (idx_ == 1 || idx_ == 4)) {                                                                            \
@@ -405,10 +406,15 @@ template <bool FP8, int EPI>
 static int launch_gemm256(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N,
                           int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st) {
   // gm_tiles bits 8..: schedule selector (tuning hook): 0 = default (DMA issued in the load segment; measured 1-2 %
-  // ahead on the Wan-14B shapes), 1 = DMA issued from inside the MFMA cluster
+  // ahead on the Wan-14B shapes), 1 = DMA issued from inside the MFMA cluster; timing probes with INVALID results (bf16, plain
+  // epilogue only): 2 = half of the MFMAs, 3 = no operand DMA after the prologue
   const int sched = gm_tiles >> 8;
   gm_tiles &= 0xff;
   if (gm_tiles == 0) gm_tiles = 4;
+  if constexpr (!FP8 && EPI == X2V_EPI_NONE) {
+    if (sched == 2) return launch_gemm256_s<FP8, EPI, 2>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
+    if (sched == 3) return launch_gemm256_s<FP8, EPI, 3>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
+  }
   if (sched == 1) return launch_gemm256_s<FP8, EPI, 1>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
   return launch_gemm256_s<FP8, EPI, 0>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
 }
