@@ -1445,11 +1445,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   // Written out per role (straight-line loops keep the accumulator tuples in place; a single loop with a phase switch made
   // the register allocator copy and spill them).  Every wave passes 2 nt + 2 barriers.
   int t = 0;
-#define A8_ISSUE(TG_) /* even half-step g = 2 TG_ */            \
-  if ((TG_) + 1 < nt) {                                        \
+#define A8_ISSUE(TG_) /* even half-step g = 2 TG_; PROBE 3: no operand movement after the first tile (timing only) */ \
+  if ((TG_) + 1 < nt && (PROBE != 3 || (TG_) == 0)) {          \
     A8_DMA_K((TG_) + 1, ((TG_) + 1) & 1)                       \
   }                                                            \
-  if ((TG_) < nt) {                                            \
+  if ((TG_) < nt && (PROBE != 3 || (TG_) == 0)) {              \
     A8_DMA_V((TG_), (TG_) & 1)                                 \
   }                                                            \
   A8_SB();
@@ -1651,6 +1651,7 @@ template <int KIND> struct V8Cfg { static constexpr int prio = 1, depth = 4, pro
 template <> struct V8Cfg<2> { static constexpr int prio = 1, depth = 4, probe = 0; static constexpr bool late = false; };
 template <> struct V8Cfg<3> { static constexpr int prio = 0, depth = 4, probe = 0; static constexpr bool late = true; };
 template <> struct V8Cfg<4> { static constexpr int prio = 1, depth = 2, probe = 0; static constexpr bool late = true; };
+template <> struct V8Cfg<5> { static constexpr int prio = 1, depth = 4, probe = 3; static constexpr bool late = true; };
 template <> struct V8Cfg<6> { static constexpr int prio = 1, depth = 4, probe = 1; static constexpr bool late = true; };
 template <> struct V8Cfg<7> { static constexpr int prio = 1, depth = 4, probe = 2; static constexpr bool late = true; };
 template <int NW, int THR, bool PRESCALED, int KIND>
@@ -1695,14 +1696,14 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
   if (scale <= 0.f) scale = 0.08838834764831845f;
   // bits 1-3 of the flag word pick a kernel for A/B measurements: 0 default (ping-pong, s_setprio in the matrix half-step, fragment
   // prefetch depth 4, DMA issued by the vector-phase waves), 1 in-phase v6, 2 every wave issues DMA, 3 no s_setprio, 4 prefetch depth 2,
-  // 6/7 timing probes (no softmax / no matrix half-step: results invalid)
+  // 5/6/7 timing probes (no K/V movement after the first tile / no softmax / no matrix half-step: results invalid)
   const int pre = q_prescaled & 1, kind = (q_prescaled >> 1) & 7;
 #define X2V_VT(K_)                                                                                                              \
   case K_:                                                                                                                      \
     return pre ? launch_attn_v6<8, 8, true, K_>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, (hipStream_t)stream)         \
                : launch_attn_v6<8, 8, false, K_>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, (hipStream_t)stream);
   switch (kind) {
-    X2V_VT(0) X2V_VT(1) X2V_VT(2) X2V_VT(3) X2V_VT(4) X2V_VT(6) X2V_VT(7)
+    X2V_VT(0) X2V_VT(1) X2V_VT(2) X2V_VT(3) X2V_VT(4) X2V_VT(5) X2V_VT(6) X2V_VT(7)
   }
 #undef X2V_VT
   return X2V_E_ARG;
