@@ -38,7 +38,7 @@ constexpr int VCF_CLAMP = 1;   // clamp the result to [-1, 1] (WanVAE.decode, va
 constexpr int VCF_TSPLIT = 2;  // Cout = 2C: channel block j of frame t -> frame 2t + j (Resample upsample3d, vae.py:136-138)
 
 template <int NF, int KC>
-__global__ __launch_bounds__(256) void vae_conv_kernel(const float* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
+__global__ __launch_bounds__(256, 2) void vae_conv_kernel(const float* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
                                                        const float* __restrict__ w, int64_t w_row_stride, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ y, int T, int Hh, int Ww, int Cin, int Cout,
                                                        int kt, int kh, int kw, int flags, int ncol) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void vae_conv_kernel(const float* __restrict__
 typedef _Float16 vc_half8_t __attribute__((ext_vector_type(8)));
 
 template <int NF>
-__global__ __launch_bounds__(256) void vae_conv16_kernel(const _Float16* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
+__global__ __launch_bounds__(256, 2) void vae_conv16_kernel(const _Float16* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
                                                          const _Float16* __restrict__ w, int64_t w_row_stride, const float* __restrict__ bias,
                                                          const float* __restrict__ resid, float* __restrict__ y, int T, int Hh, int Ww, int Cin, int Cout,
                                                          int kt, int kh, int kw, int flags, int ncol) {
@@ -614,6 +614,215 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Halo-tiled form of the 16-bit convolution for 3x3 spatial kernels (kt = 1 or 3).  vae_conv16_kernel stages a fresh 256-pixel
+// input block for every tap — 48 KB from the L2 per 4.2 MFLOP, and the PMC profile shows it pinned at the L2's aggregate request
+// rate (11 TB/s, matrix pipe 32 % busy).  Here a workgroup owns an 8 x 32 pixel tile of one output frame and stages, per input
+// frame tap dt and 64-channel slab, the 10 x 34 pixel HALO block once (44 KB); the nine spatial taps then read their shifted
+// 8 x 32 windows out of that one LDS image, so only the weights (16 KB per tap) stream per step: 187 KB per 37.7 MFLOP, 2.3x fewer
+// L2 bytes per FLOP.  Same MFMA tiling as vae_conv16_kernel (wave = 2 image rows x 32 px = two 32-row MFMA blocks, 32 NF couts).
+//   * LDS: halo image [352 rows][128 B] x 2 (row r = hy*34 + hx, chunk ^= (r >> 1) & 7 applied on the DMA source as everywhere),
+//     weight slab [32 NF][128 B] x 2.  Fragment row of lane fl for tap (dh, dw), image row 2 wid + mi: r = (2 wid + mi + dh)*34 + dw + fl;
+//     the swizzle depends on r, so the 8 fragment addresses are recomputed per tap (a few VALU against 8 NF MFMAs).
+//   * schedule: step = (slab, tap), one barrier per step, 4 compute waves + 4 loader waves (one of each per SIMD).  A loader's tap 0
+//     issues the next step's weights, then the next slab's halo (11 pieces per loader wave, padded rows masked) and waits vmcnt(11):
+//     the weights have landed, the halo flies on; later taps issue weights only and wait vmcnt(0) (the halo has had more than a whole
+//     step by then).
+constexpr int VH_TH = 8, VH_TW = 32, VH_HW = VH_TW + 2, VH_ROWS = 352, VH_A_BYTES = VH_ROWS * 128, VH_A_PIECES = VH_ROWS / 8 / 4;
+
+template <int NF>
+__global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride,
+                                                          const _Float16* __restrict__ w, int64_t w_row_stride, const float* __restrict__ bias,
+                                                          const float* __restrict__ resid, float* __restrict__ y, int T, int Hh, int Ww, int Cin, int Cout,
+                                                          int kt, int flags, int ncol, int tiles_x, int tiles_y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = 128, CPR = 8, RPI = 8;
+  constexpr int BN = 32 * NF;
+  constexpr int B_BYTES = BN * ROWB;
+  constexpr int B_INSTR = (BN / 4 + RPI - 1) / RPI;
+  constexpr int B_OFF = 2 * VH_A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // 8 waves, two per SIMD: waves 0..3 compute (MFMAs + fragment reads only), waves 4..7 move data (every LDS-DMA piece of the
+  // workgroup).  An LDS-DMA issue costs 60-185 cycles of a wave's issue stream; with the four compute waves issuing their own 5-12
+  // pieces per step the matrix pipe sat idle two thirds of the time — a partner wave per SIMD that does nothing else hides it.
+  const bool loader = wave >= 4;
+  const int wid = wave & 3;
+  const int fl = lane & 31, fh = lane >> 5;
+  const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+  const int ctile = (int)(v % (unsigned)ncol);
+  unsigned pt = v / (unsigned)ncol;
+  const int tx = (int)(pt % (unsigned)tiles_x);
+  pt /= (unsigned)tiles_x;
+  const int ty = (int)(pt % (unsigned)tiles_y);
+  const int frame = (int)(pt / (unsigned)tiles_y);
+  const int y0 = ty * VH_TH, x0 = tx * VH_TW;
+  const int co0 = ctile * BN;
+  const int taps = kt * 9;
+
+  const int64_t fbytes = x_frame_stride * 2;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xp + (int64_t)frame * x_frame_stride), 0, (unsigned)(fbytes * kt), 0x00020000);
+  const int wrows = min(BN, Cout - co0);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(w + (int64_t)co0 * w_row_stride), 0, (unsigned)(((int64_t)(wrows - 1) * w_row_stride + (int64_t)taps * Cin) * 2), 0x00020000);
+
+  // halo DMA: wave wid moves pieces wid*11 .. wid*11+10 (8 halo rows each); source = padded-buffer pixel (y0 + hy, x0 + hx)
+  unsigned a_voff[VH_A_PIECES], b_voff[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < VH_A_PIECES; ++i) {
+    const int r = (wid * VH_A_PIECES + i) * 8 + lane / CPR;
+    const int c = (lane % CPR) ^ ((r >> 1) & (CPR - 1));
+    const int hy = r / VH_HW, hx = r - hy * VH_HW;
+    a_voff[i] = r < (VH_TH + 2) * VH_HW ? (unsigned)(((int64_t)(y0 + hy) * x_row_stride + (int64_t)(x0 + hx) * x_px_stride) * 2) + (unsigned)(c << 4) : VC_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int rl = i * RPI + lane / CPR;
+    const int r = wid * (BN / 4) + rl;
+    const int c = (lane % CPR) ^ ((r >> 1) & (CPR - 1));
+    b_voff[i] = (rl < BN / 4 && r < wrows) ? (unsigned)((int64_t)r * w_row_stride * 2) + (unsigned)(c << 4) : VC_OOB;
+  }
+  const int kchunks = Cin / 64;
+  const int nslabs = kt * kchunks;  // (dt, kc)
+  auto stage_a = [&](int buf, int slab) {
+    const int dt = slab / kchunks, kc = slab - dt * kchunks;
+    const unsigned xso = (unsigned)(((int64_t)dt * x_frame_stride + (int64_t)kc * 64) * 2);
+    char* as = smem + buf * VH_A_BYTES + wid * (VH_A_PIECES * 1024);
+#pragma unroll
+    for (int i = 0; i < VH_A_PIECES; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (v_lds_ptr_t)(as + i * 1024), 16, a_voff[i], xso, 0, 0);
+  };
+  auto stage_b = [&](int buf, int slab, int tap9) {
+    const int dt = slab / kchunks, kc = slab - dt * kchunks;
+    const unsigned wso = (unsigned)(((int64_t)(dt * 9 + tap9) * Cin + (int64_t)kc * 64) * 2);
+    char* bs = smem + B_OFF + buf * B_BYTES + wid * ((BN / 4) * ROWB);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      if ((i + 1) * RPI <= BN / 4 || lane / CPR + i * RPI < BN / 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (v_lds_ptr_t)(bs + i * 1024), 16, b_voff[i], wso, 0, 0);
+  };
+
+  int rd_b[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rd_b[ks] = fl * ROWB + ((((ks << 1) | fh) ^ ((fl >> 1) & (CPR - 1))) << 4);
+
+  f32x16_t acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (loader) {
+    stage_b(0, 0, 0);
+    stage_a(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  int bbuf = 0;
+  if (loader) {
+    // same step structure as the compute waves (one barrier per step): issue the next step's weights (and, on a slab's first tap, the
+    // next slab's halo), wait for the weights (the halo may fly for another step), meet the compute waves at the barrier
+    for (int slab = 0; slab < nslabs; ++slab) {
+#pragma unroll 1
+      for (int tap9 = 0; tap9 < 9; ++tap9) {
+        const bool last_step = slab + 1 == nslabs && tap9 == 8;
+        if (!last_step) {
+          if (tap9 == 8) stage_b(bbuf ^ 1, slab + 1, 0);
+          else stage_b(bbuf ^ 1, slab, tap9 + 1);
+        }
+        const bool halo = tap9 == 0 && slab + 1 < nslabs;
+        if (halo) stage_a((slab + 1) & 1, slab + 1);
+        if (halo) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VH_A_PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        bbuf ^= 1;
+      }
+    }
+    return;
+  }
+  for (int slab = 0; slab < nslabs; ++slab) {
+    const char* ab = smem + (slab & 1) * VH_A_BYTES;
+#pragma unroll 1
+    for (int tap9 = 0; tap9 < 9; ++tap9) {
+      const int dh = tap9 / 3, dw = tap9 - dh * 3;
+      const char* bb = smem + B_OFF + bbuf * B_BYTES;
+      int ra[2], sw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wid + i + dh) * VH_HW + dw + fl;
+        ra[i] = r * ROWB;
+        sw[i] = (r >> 1) & (CPR - 1);
+      }
+      // fragments of k-step ks+1 are read before the MFMAs of k-step ks are issued (pinned: left to itself hipcc reads a k-step's
+      // fragments right in front of its MFMAs and the LDS latency is paid four times per step — 45 % matrix-pipe busy)
+      vc_half8_t xa[2][2], wb[2][NF];
+#define VH_LOAD(P_, KS_)                                                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) xa[P_][i] = *reinterpret_cast<const vc_half8_t*>(ab + ra[i] + (((((KS_) << 1) | fh) ^ sw[i]) << 4)); \
+  _Pragma("unroll") for (int n = 0; n < NF; ++n) wb[P_][n] = *reinterpret_cast<const vc_half8_t*>(bb + n * 32 * ROWB + rd_b[KS_]);
+      VH_LOAD(0, 0)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) { VH_LOAD((ks + 1) & 1, ks + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef VH_LOAD
+      __syncthreads();
+      bbuf ^= 1;
+    }
+  }
+
+  // epilogue.  acc[i][n][r]: pixel (y0 + 2 wid + i, x0 + fl), cout co0 + n*32 + (r&3) + 8*(r>>2) + 4*fh
+  const bool vec_ok = (Cout & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int py = y0 + 2 * wid + i, px = x0 + fl;
+    if (py >= Hh || px >= Ww) continue;
+    const int64_t pbase = ((int64_t)frame * Hh + py) * Ww + px;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + n * 32 + 8 * g + 4 * fh;
+        if (co >= Cout) continue;
+        float vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = acc[i][n][4 * g + e];
+        const int64_t oidx = pbase * Cout + co;
+        if (vec_ok) {
+          if (bias != nullptr) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + co);
+            vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w;
+          }
+          if (resid != nullptr) {
+            const float4 r4 = *reinterpret_cast<const float4*>(resid + oidx);
+            vv[0] += r4.x; vv[1] += r4.y; vv[2] += r4.z; vv[3] += r4.w;
+          }
+          if (flags & VCF_CLAMP) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = fminf(fmaxf(vv[e], -1.f), 1.f);
+          }
+          *reinterpret_cast<float4*>(y + oidx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < Cout) {
+              float o = vv[e] + (bias != nullptr ? bias[co + e] : 0.f) + (resid != nullptr ? resid[oidx + e] : 0.f);
+              if (flags & VCF_CLAMP) o = fminf(fmaxf(o, -1.f), 1.f);
+              y[oidx + e] = o;
+            }
+        }
+      }
+  }
+#endif
+}
+
 }  // namespace x2v
 
 using namespace x2v;
@@ -783,6 +992,26 @@ static int launch_vconv16(const void* xp, int64_t fs, int64_t rs, int64_t ps, co
   return X2V_OK;
 }
 
+template <int NF>
+static int launch_vconv16h(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
+                           int Ww, int Cin, int Cout, int kt, int flags, hipStream_t st) {
+  constexpr int lds = 2 * VH_A_BYTES + 2 * 32 * NF * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)vae_conv16h_kernel<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "vae conv16h attr");
+    if (rc != X2V_OK) return rc;
+    attr_set = true;
+  }
+  const int tiles_x = (Ww + VH_TW - 1) / VH_TW, tiles_y = (Hh + VH_TH - 1) / VH_TH;
+  const int ncol = (Cout + 32 * NF - 1) / (32 * NF);
+  const int64_t blocks = (int64_t)T * tiles_x * tiles_y * ncol;
+  X2V_REQUIRE(blocks < (1ll << 31), X2V_E_SHAPE, "vae_conv_f16: too many tiles");
+  hipLaunchKernelGGL((vae_conv16h_kernel<NF>), dim3((unsigned)blocks), dim3(512), lds, st, (const _Float16*)xp, fs, rs, ps, (const _Float16*)w, wrs, bias, resid, y, T,
+                     Hh, Ww, Cin, Cout, kt, flags, ncol, tiles_x, tiles_y);
+  X2V_LAUNCH_CHECK("vae_conv_f16 (halo) launch");
+  return X2V_OK;
+}
+
 extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w,
                                                                        int64_t w_row_stride, const float* bias, const float* resid, float* y, int T, int Hh, int Ww,
                                                                        int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream) {
@@ -798,6 +1027,16 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16(const voi
               "vae_conv_f16: a kt-frame input window / 128 weight rows must stay below 2 GiB (32-bit buffer offsets)");
   X2V_REQUIRE(!(flags & VCF_TSPLIT) || (Cout % 8 == 0 && resid == nullptr), X2V_E_ARG, "vae_conv_f16: time-split output needs Cout %% 8 == 0 and no residual");
   hipStream_t st = (hipStream_t)stream;
+  // 3x3 spatial kernels take the halo-tiled kernel (2.3x fewer L2 bytes per FLOP) unless the image is narrower than half a tile or the
+  // caller asks for the per-tap kernel (flag 4: A/B measurements and tests)
+  if (kh == 3 && kw == 3 && !(flags & (VCF_TSPLIT | 4)) && Ww >= 16) {
+#define X2V_VC16H(NF_) return launch_vconv16h<NF_>(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, st)
+    if (Cout <= 32) X2V_VC16H(1);
+    else if (Cout % 128 != 0 && Cout % 96 == 0) X2V_VC16H(3);
+    else if (Cout <= 64) X2V_VC16H(2);
+    else X2V_VC16H(4);
+#undef X2V_VC16H
+  }
 #define X2V_VC16(NF_) return launch_vconv16<NF_>(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, kh, kw, flags, st)
   if (Cout <= 32) X2V_VC16(1);
   else if (Cout % 128 != 0 && Cout % 96 == 0) X2V_VC16(3);

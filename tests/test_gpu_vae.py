@@ -112,22 +112,28 @@ def test_vae_decode_fp16_operands_opt_in():
     from lightx2v_amd import lib, synth, vae
     from oracle import wan_vae_oracle as V
 
-    # the 16-bit convolution itself against conv3d on fp16-rounded operands (fp32 accumulate): tight
+    # the 16-bit convolutions themselves (halo-tiled kernel for 3x3 spatial taps, per-tap kernel otherwise or with flag 4) against conv3d
+    # on the same fp16-rounded operands (fp32 accumulate): tight.  Shapes: ragged tiles in H and W, padded channels, Cout 3, 2-D kernels.
     g = torch.Generator().manual_seed(2)
-    T, H, W, Cin, Cout = 2, 9, 11, 96, 160
-    x = torch.randn(T, H, W, Cin, generator=g).half()
-    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5).half()
-    b = torch.randn(Cout, generator=g)
-    xin = F.pad(x.float().permute(3, 0, 1, 2), (1, 1, 1, 1, 2, 0))
-    ref = F.conv3d(xin.unsqueeze(0), w.float(), b)[0].permute(1, 2, 3, 0)
-    cp = 128
-    buf = torch.zeros(2 + T, H + 2, W + 2, cp, dtype=torch.float16, device="cuda")
-    buf[2:, 1 : 1 + H, 1 : 1 + W, :Cin] = x.cuda()
-    w16 = torch.zeros(Cout, 3, 3, 3, cp, dtype=torch.float16, device="cuda")
-    w16[..., :Cin] = w.permute(0, 2, 3, 4, 1).cuda()
-    out = torch.empty(T, H, W, Cout, device="cuda")
-    lib.vae_conv16(buf, ((H + 2) * (W + 2) * cp, (W + 2) * cp, cp), w16, out, T, H, W, bias=b.cuda())
-    _check(out, ref, "fp16-operand conv vs conv3d on the same rounded operands", atol=2e-4, rel=1e-5)
+    for (T, H, W, Cin, Cout, kt, kh, kw) in [(2, 9, 11, 96, 160, 3, 3, 3), (2, 9, 40, 96, 160, 3, 3, 3), (1, 17, 33, 64, 3, 3, 3, 3), (2, 8, 32, 128, 96, 1, 3, 3),
+                                             (1, 21, 70, 64, 64, 3, 3, 3), (2, 6, 20, 64, 32, 3, 1, 1)]:
+        x = torch.randn(T, H, W, Cin, generator=g).half()
+        w = (torch.randn(Cout, Cin, kt, kh, kw, generator=g) / (kt * kh * kw * Cin) ** 0.5).half()
+        b = torch.randn(Cout, generator=g)
+        res = torch.randn(T, H, W, Cout, generator=g)
+        ph, pw = kh // 2, kw // 2
+        xin = F.pad(x.float().permute(3, 0, 1, 2), (pw, pw, ph, ph, kt - 1, 0))
+        ref = F.conv3d(xin.unsqueeze(0), w.float(), b)[0].permute(1, 2, 3, 0) + res
+        cp = (Cin + 63) // 64 * 64
+        buf = torch.zeros(kt - 1 + T, H + 2 * ph, W + 2 * pw, cp, dtype=torch.float16, device="cuda")
+        buf[kt - 1 :, ph : ph + H, pw : pw + W, :Cin] = x.cuda()
+        w16 = torch.zeros(Cout, kt, kh, kw, cp, dtype=torch.float16, device="cuda")
+        w16[..., :Cin] = w.permute(0, 2, 3, 4, 1).cuda()
+        strides = ((H + 2 * ph) * (W + 2 * pw) * cp, (W + 2 * pw) * cp, cp)
+        for flags in (0, 4):
+            out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
+            lib.vae_conv16(buf, strides, w16, out, T, H, W, bias=b.cuda(), resid=res.cuda(), flags=flags)
+            _check(out, ref, f"fp16-operand conv {(kt, kh, kw)} {H}x{W} Cin={Cin} Cout={Cout} flags={flags}", atol=3e-4, rel=1e-5)
     # norm + SiLU written as fp16 into a channel-padded buffer
     C = 96
     xx = torch.randn(2, 5, 6, C, generator=g) * 2

@@ -31,7 +31,11 @@ def main():
 
     orig16 = lib.vae_conv16
 
+    per_tap = "--per-tap" in sys.argv  # force the per-tap 16-bit kernel (flag 4) instead of the halo-tiled one
+
     def counted16(xp, strides, weight, out, T, H, W, **kw):
+        if per_tap:
+            kw["flags"] = kw.get("flags", 0) | 4
         flops[0] += 2.0 * T * H * W * weight.shape[0] * weight.shape[4] * 27
         flops16[0] += 2.0 * T * H * W * weight.shape[0] * weight.shape[4] * 27
         return orig16(xp, strides, weight, out, T, H, W, **kw)
