@@ -17,6 +17,10 @@ run bench_fp8_distill timeout 600 python bench.py --fp8 --distill --steps 2 --wa
 run hunyuan timeout 600 python tools/hunyuan_bench.py > "$OUT/hunyuan13b.json" 2> "$OUT/hunyuan13b.err"; cat "$OUT/hunyuan13b.json" >> "$OUT/summary.txt"
 run e2e_13b timeout 300 python tools/e2e.py --workload wan1.3b_480px49f --steps 50 > "$OUT/e2e_wan13b_480p.json" 2> "$OUT/e2e13.err"; cat "$OUT/e2e_wan13b_480p.json" >> "$OUT/summary.txt"
 run e2e_fp8_distill timeout 400 python tools/e2e.py --fp8 --distill > "$OUT/e2e_wan14b_fp8_distill.json" 2> "$OUT/e2e_fp8.err"; cat "$OUT/e2e_wan14b_fp8_distill.json" >> "$OUT/summary.txt"
+run vae_wan_fp32 timeout 300 python tools/vae_bench.py --latent 16,21,90,160 > "$OUT/vae_wan_720p81f_fp32.json" 2> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_fp32.json" >> "$OUT/summary.txt"
+run vae_wan_fp16 timeout 300 python tools/vae_bench.py --latent 16,21,90,160 --conv16 > "$OUT/vae_wan_720p81f_fp16ops.json" 2>> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_fp16ops.json" >> "$OUT/summary.txt"
+run vae_hunyuan_tile timeout 300 python tools/hunyuan_vae_bench.py > "$OUT/vae_hunyuan_tile_fp16ops.json" 2> "$OUT/vae_hy.err"; cat "$OUT/vae_hunyuan_tile_fp16ops.json" >> "$OUT/summary.txt"
+run vae_hunyuan_full timeout 400 python tools/hunyuan_vae_bench.py --full > "$OUT/vae_hunyuan_720p129f_fp16ops.json" 2>> "$OUT/vae_hy.err"; cat "$OUT/vae_hunyuan_720p129f_fp16ops.json" >> "$OUT/summary.txt"
 if [ "${E2E14:-1}" = "1" ]; then
   run e2e_14b timeout 900 python tools/e2e.py --steps 50 > "$OUT/e2e_wan14b_720p.json" 2> "$OUT/e2e14.err"; cat "$OUT/e2e_wan14b_720p.json" >> "$OUT/summary.txt"
 fi
