@@ -651,7 +651,12 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
   const bool loader = wave >= 4;
   const int wid = wave & 3;
   const int fl = lane & 31, fh = lane >> 5;
-  const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+  // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; after a tile's last barrier nothing reads LDS any more, so the
+  // loader waves stage the next tile's first halo and weights while the compute waves are still in the previous tile's fp32 epilogue
+  // (128 KB out + 128 KB residual in per tile: 13-23 % of a tile's life, unhidden when a tile is a workgroup)
+  const unsigned ntiles = (unsigned)T * (unsigned)tiles_y * (unsigned)tiles_x * (unsigned)ncol;
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const unsigned v = xcd_remap(tile, ntiles);
   const int ctile = (int)(v % (unsigned)ncol);
   unsigned pt = v / (unsigned)ncol;
   const int tx = (int)(pt % (unsigned)tiles_x);
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         bbuf ^= 1;
       }
     }
-    return;
+    continue;
   }
   for (int slab = 0; slab < nslabs; ++slab) {
     const char* ab = smem + (slab & 1) * VH_A_BYTES;
@@ -820,6 +825,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         }
       }
   }
+  }  // persistent tile loop
 #endif
 }
 
@@ -1006,7 +1012,15 @@ static int launch_vconv16h(const void* xp, int64_t fs, int64_t rs, int64_t ps, c
   const int ncol = (Cout + 32 * NF - 1) / (32 * NF);
   const int64_t blocks = (int64_t)T * tiles_x * tiles_y * ncol;
   X2V_REQUIRE(blocks < (1ll << 31), X2V_E_SHAPE, "vae_conv_f16: too many tiles");
-  hipLaunchKernelGGL((vae_conv16h_kernel<NF>), dim3((unsigned)blocks), dim3(512), lds, st, (const _Float16*)xp, fs, rs, ps, (const _Float16*)w, wrs, bias, resid, y, T,
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return check_hip(hipErrorUnknown, "vae conv16h device query");
+    n_cu = prop.multiProcessorCount;
+  }
+  const unsigned grid = (unsigned)std::min<int64_t>(blocks, n_cu);  // one workgroup per CU (120 KiB of LDS each)
+  hipLaunchKernelGGL((vae_conv16h_kernel<NF>), dim3(grid), dim3(512), lds, st, (const _Float16*)xp, fs, rs, ps, (const _Float16*)w, wrs, bias, resid, y, T,
                      Hh, Ww, Cin, Cout, kt, flags, ncol, tiles_x, tiles_y);
   X2V_LAUNCH_CHECK("vae_conv_f16 (halo) launch");
   return X2V_OK;
