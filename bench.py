@@ -247,7 +247,6 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": args.workload,
-            "arch": wl["model"],
             "tokens": S,
             "latent_shape": list(ts),
             "frames": wl["frames"],
