@@ -199,6 +199,24 @@ def gen_scheduler_only():
             sch.noise_pred = torch.sin(sch.latents.float() * 1.3 + 0.1 * i) + 0.05 * i
             sch.step_post()
         out[f"{tag}_final"] = sch.latents.clone()
+    # step-distill scheduler (BASELINE config #4): the reference re-noises with the unseeded global RNG (step_distill/scheduler.py:55);
+    # the fixture seeds it (torch.manual_seed(100 + i)) right before each step_post so that the draw is reproducible
+    from lightx2v.models.schedulers.wan.step_distill.scheduler import WanStepDistillScheduler
+
+    cfg = ref_import.make_config(synth.WAN_DIMS["wan-tiny"], infer_steps=4, sample_shift=5.0, target_shape=(16, 2, 4, 4))
+    cfg["denoising_step_list"] = [1000, 750, 500, 250]
+    sch = WanStepDistillScheduler(cfg)
+    sch.device = torch.device("cpu")
+    sch.prepare(None)
+    lat0 = torch.randn(16, 2, 4, 4, generator=torch.Generator().manual_seed(8))
+    sch.latents = lat0.clone()
+    out["distill_lat0"], out["distill_timesteps"], out["distill_sigmas"] = lat0, sch.timesteps.clone(), sch.sigmas.clone()
+    for i in range(4):
+        sch.step_pre(i)
+        sch.noise_pred = torch.cos(sch.latents.float() * 0.7 + 0.2 * i)
+        torch.manual_seed(100 + i)
+        sch.step_post()
+        out[f"distill_lat{i + 1}"] = sch.latents.clone()
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "scheduler.safetensors"))
     print("scheduler.safetensors:", len(out), "tensors")
 

@@ -66,3 +66,31 @@ def test_step_distill_schedule_and_update():
             s1 = sch.sigmas[i + 1].item()
             x0 = (1 - s1) * x0 + s1 * noise[i]
         assert torch.equal(sch.latents, x0.to(torch.bfloat16))
+
+
+def test_step_distill_matches_reference_fixture():
+    """tests/golden/scheduler.safetensors `distill_*`: the reference's own WanStepDistillScheduler (gen_golden.py::gen_scheduler_only) with
+    the global RNG seeded before every step_post; same sigma table, timesteps and latents after every step, bit for bit."""
+    import os
+
+    from safetensors.torch import load_file
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scheduler.safetensors"))
+    cfg = _cfg(4, 5.0, (16, 2, 4, 4))
+    cfg["denoising_step_list"] = [1000, 750, 500, 250]
+    step = [0]
+
+    def noise_fn(x):
+        torch.manual_seed(100 + step[0])
+        return torch.randn_like(x)
+
+    sch = WanStepDistillScheduler(cfg, device="cpu", noise_fn=noise_fn)
+    sch.prepare(latents=g["distill_lat0"])
+    assert torch.equal(sch.sigmas, g["distill_sigmas"]) and torch.equal(sch.timesteps, g["distill_timesteps"])
+    for i in range(4):
+        step[0] = i
+        sch.step_pre(i)
+        sch.noise_pred = torch.cos(sch.latents.float() * 0.7 + 0.2 * i)
+        sch.step_post()
+        assert sch.latents.dtype == g[f"distill_lat{i + 1}"].dtype
+        assert torch.equal(sch.latents, g[f"distill_lat{i + 1}"]), f"latents after step {i + 1}"
