@@ -287,6 +287,36 @@ def gen_vae(dim=32, seed=1):
         raw = m.decode(z.unsqueeze(0), [mean, inv_std])[0]
     out = dict(z=z, mean=mean, inv_std=inv_std, decoded_raw=raw.clone(), decoded=raw.float().clamp_(-1, 1), dim=torch.tensor([dim]), seed=torch.tensor([seed]),
                weights_checksum=weights_checksum(sd))
+    # decode_dist (vae.py:883-929), world size 2 and 3, split along W and along H: the reference's own slab / halo / crop code, run once
+    # per rank in this process — torch.distributed.all_gather is replaced by a recorder (first pass: every rank's cropped slab is
+    # captured; second pass: the gather is served from the captured slabs) and torch.cuda.synchronize by a no-op
+    import lightx2v.models.video_encoders.hf.wan.vae as ref_vae
+
+    wv = object.__new__(ref_vae.WanVAE)  # the constructor reads a checkpoint file; everything decode_dist touches is set here
+    wv.model, wv.scale, wv.device, wv.dtype, wv.parallel, wv.use_tiling = m, [mean, inv_std], "cpu", torch.float32, True, False
+    zd = torch.randn(16, 2, 6, 12, generator=torch.Generator().manual_seed(9))
+    out["z_dist"] = zd
+    real_gather, real_sync = ref_vae.dist.all_gather, torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        for world, split_dim in ((2, 3), (3, 3), (2, 2), (3, 2)):
+            slabs = {}
+
+            def record(full, img, _slabs=slabs):
+                _slabs[record.rank] = img.clone()
+                for i, t in enumerate(full):
+                    t.copy_(_slabs.get(i, torch.zeros_like(t)) if _slabs.get(i, t).shape == t.shape else torch.zeros_like(t))
+
+            ref_vae.dist.all_gather = record
+            with torch.no_grad():
+                for r in range(world):
+                    record.rank = r
+                    wv.decode_dist(zd, world, r, split_dim)
+                record.rank = 0
+                full = wv.decode_dist(zd, world, 0, split_dim)
+            out[f"decoded_dist_w{world}_d{split_dim}"] = full[0].clone()
+    finally:
+        ref_vae.dist.all_gather, torch.cuda.synchronize = real_gather, real_sync
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
     print("wan_vae_tiny.safetensors:", len(out), "tensors")
 

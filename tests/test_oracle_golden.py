@@ -112,6 +112,11 @@ def test_vae_decode_oracle_bit_exact():
         out = V.wan_vae_decode(sd, gld["z"], gld["mean"], gld["inv_std"], dim=int(gld["dim"]))
     assert torch.equal(raw, gld["decoded_raw"])
     assert torch.equal(out, gld["decoded"])
+    # decode_dist (vae.py:883-929): the reference's own slab / halo / crop / gather code at world sizes 2 and 3, both split axes
+    for world, split_dim in ((2, 3), (3, 3), (2, 2), (3, 2)):
+        with torch.no_grad():
+            got = V.wan_vae_decode_dist(sd, gld["z_dist"], gld["mean"], gld["inv_std"], world, split_dim, dim=int(gld["dim"]))
+        assert torch.equal(got, gld[f"decoded_dist_w{world}_d{split_dim}"]), (world, split_dim)
 
 
 def test_hunyuan_vae_oracle_bit_exact():
