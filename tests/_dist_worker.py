@@ -39,6 +39,27 @@ def main():
     g = ulysses.post_process(xs)
     assert torch.equal(g[: S + 1], x) and torch.equal(g[S + 1 :], torch.zeros(1, 8))
 
+    # against the reference's own functions in this real 2-process run (authoring container only: /root/reference is absent elsewhere):
+    # comm/all2all.py:6-89 (seq<->head all-to-all layouts) and utils/wan/processor.py:9-37 (shard / gather)
+    from oracle import ref_import
+
+    if ref_import.reference_available():
+        ref_import.patch_and_import()
+        from lightx2v.attentions.distributed.comm.all2all import all2all_head2seq, all2all_seq2head
+        from lightx2v.attentions.distributed.utils.wan import processor as ref_proc
+
+        mine = ulysses.seq2head(q[sl].contiguous())
+        theirs = all2all_seq2head(q[sl].contiguous().view(-1, H, d))
+        assert torch.equal(mine.view(S, H // n, d), theirs), "seq2head differs from the reference's all2all_seq2head"
+        o_h = torch.randn(S, (H // n) * d, generator=torch.Generator().manual_seed(5 + r)).to(torch.bfloat16)
+        assert torch.equal(ulysses.head2seq(o_h).view(-1, H, d), all2all_head2seq(o_h.view(S, H // n, d))), "head2seq differs from all2all_head2seq"
+        xr = torch.randn(S + 1, 8, generator=torch.Generator().manual_seed(3))
+        a, b = ulysses.pre_process(xr), ref_proc.pre_process(xr)
+        assert torch.equal(a, b)
+        assert torch.equal(ulysses.post_process(a), ref_proc.post_process(b.contiguous()))
+        if r == 0:
+            print("REFERENCE_EXCHANGE_OK")
+
     # distributed oracle forward == single-process oracle forward (pins compute_freqs_dist + sharding; S % N == 0)
     from lightx2v_amd import synth
 
