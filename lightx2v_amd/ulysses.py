@@ -50,6 +50,7 @@ class UlyssesAttention:
 
     def __init__(self, group=None, attn_fn=None, overlap=True):
         self.group = group
+        self._default_attn = attn_fn is None
         self.attn_fn = attn_fn or (lambda q, k, v, h, d, variant=0: lib.attention(q, k, v, h, d, variant=variant))
         self.overlap = overlap and torch.cuda.is_available()
         self.comm_stream = None
@@ -86,14 +87,23 @@ class UlyssesAttention:
             with torch.cuda.stream(self.comm_stream):
                 qh, kh = seq2head(q, self.group), seq2head(k, self.group)
                 vh = v.out if isinstance(v, self._Pending) else seq2head(v, self.group)
-            for t in (q, k, qh, kh, vh) + (() if isinstance(v, self._Pending) else (v,)):
-                t.record_stream(self.comm_stream)
+            for t in (q, k) + (() if isinstance(v, self._Pending) else (v,)):
+                t.record_stream(self.comm_stream)  # produced on the compute stream, read by the exchange
             cur.wait_stream(self.comm_stream)
+            for t in (qh, kh, vh):
+                t.record_stream(cur)  # allocated under the communication stream, read by the attention kernel
         else:
             if isinstance(v, self._Pending):
                 v = v.src
             qh, kh, vh = seq2head(q, self.group), seq2head(k, self.group), seq2head(v, self.group)
-        fn = (lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim, variant=variant)) if variant else (lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim))
+        if self._default_attn and (variant & 0xFF) == lib.ATTN_FAST:
+            # the ping-pong kernel reads V^T: transposed before the timed launch, as on the single-GPU path (wan.py)
+            vt = lib.transpose_heads(vh, num_heads // n)
+            fn = lambda: lib.attention(qh, kh, vh, num_heads // n, head_dim, variant=variant, vt=vt)
+        elif variant:
+            fn = lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim, variant=variant)
+        else:
+            fn = lambda: self.attn_fn(qh, kh, vh, num_heads // n, head_dim)
         o = timer("self", fn) if timer is not None else fn()
         return head2seq(o, self.group)
 

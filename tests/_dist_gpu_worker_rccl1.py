@@ -1,0 +1,54 @@
+"""world_size-1 worker for tests/test_gpu_dist.py: the process group is the real RCCL backend ("nccl" on ROCm) on the one GPU of
+the box, so the collectives ulysses.py issues (all_to_all_single / all_gather_into_tensor on bf16 device tensors, on the
+communication stream, joined by events) go through RCCL itself rather than the host-staged test shim of the world-2 workers.
+With one rank every exchange is the identity, so the Ulysses-wrapped forward must equal the plain forward bit for bit."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    from lightx2v_amd import lib, scheduler, synth, ulysses, wan
+
+    lib.init(0)
+    # the exchange primitives on their own
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(96, 4 * 128, generator=g).to(torch.bfloat16).cuda()
+    assert torch.equal(ulysses.seq2head(x), x) and torch.equal(ulysses.head2seq(x), x)
+    assert torch.equal(ulysses.post_process(ulysses.pre_process(x)), x)
+
+    dims = dict(synth.WAN_DIMS["wan-tiny"], dim=512, num_heads=4, ffn_dim=1024, num_layers=2)
+    ts = (16, 3, 12, 10)
+    wd = synth.synth_wan_weights(dims, seed=3)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    outs = {}
+    for mode in ("single", "ulysses"):
+        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type="ulysses" if mode == "ulysses" else None)
+        model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=lat)
+        model.set_scheduler(sch)
+        for i in range(2):
+            sch.step_pre(i)
+            model.infer(inputs)
+            sch.step_post()
+        outs[mode] = sch.latents.float().cpu()
+    assert torch.isfinite(outs["single"]).all()
+    assert torch.equal(outs["single"], outs["ulysses"]), "world-1 Ulysses over RCCL differs from the plain forward"
+    dist.barrier()
+    torch.cuda.synchronize()
+    print("DIST_GPU_RCCL1_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,3 +44,13 @@ def test_hunyuan_vae_tile_parallel_world2_on_one_gpu():
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_GPU_HUNYUAN_VAE_OK" in p.stdout
+
+
+def test_ulysses_over_rccl_world1():
+    """The real RCCL backend on the box's one GPU (world size 1): same collectives, streams and events as the N-GPU run."""
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29549",
+           os.path.join(ROOT, "tests", "_dist_gpu_worker_rccl1.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "DIST_GPU_RCCL1_OK" in p.stdout
