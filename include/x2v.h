@@ -62,6 +62,13 @@ int x2v_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t
 int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* y, int64_t ldy,
                        int64_t M, int D, float eps, void* stream);
 
+/* Same, selecting the kernel form (tuning / validation hook): 0 = by shape (what x2v_layernorm_bf16 does: the persistent
+ * "streaming" kernel — next row prefetched under the current row's reductions, per-channel operands resident in registers —
+ * when 512 < D <= 8192 and M is at least twice the resident grid, else one block per row), 1 = one block per row,
+ * 2 = streaming (X2V_E_SHAPE outside 512 < D <= 8192).  The forms are bit-identical. */
+int x2v_layernorm_bf16_variant(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* y, int64_t ldy,
+                               int64_t M, int D, float eps, int variant, void* stream);
+
 /* In-place q,k <- RoPE3D(RMSNorm_D(q|k)) for Wan self-attention — replaces rms_norm_weight.py apply on
  * q and k (transformer_infer.py:341-342) + compute_freqs/apply_rotary_emb (wan/infer/utils.py:7-20,
  * 107-115).  q,k: [S, H*128] bf16 with token stride ldq/ldk; wq,wk: [H*128] bf16 (NULL = skip the norm);
@@ -77,6 +84,13 @@ int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void
  * (X2V_ATTN_Q_PRESCALED): numerically one rounding of the scaled value instead of one rounding of the unscaled one. */
 int x2v_rmsnorm_rope_scaled_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S, int H,
                                  int64_t s0, int gf, int gh, int gw, float eps, int round_mode, float q_out_scale, void* stream);
+
+/* Same, selecting the kernel form (tuning / validation hook; bit-identical results): 0 = by shape, 1 = one block per (token, q|k)
+ * row, 2 = persistent streaming kernel (a token's q and k rows back to back, its 64 rotation factors gathered once into LDS, the
+ * next row prefetched under the reduction; D <= 8192). */
+int x2v_rmsnorm_rope_scaled_bf16_variant(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S,
+                                         int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode, float q_out_scale, int variant,
+                                         void* stream);
 
 /* In-place per-head RMSNorm (d = 128) of q and k [L, H*128] (token strides ldq/ldk, e.g. the column blocks of a fused
  * QKV GEMM output), followed for tokens < l_rope by the real-valued RoPE x*cos + rotate_half(x)*sin with bf16 tables
@@ -111,7 +125,8 @@ int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw
 /* Dense non-causal attention, head_dim 128: o[Sq, H*128] = softmax(q k^T * scale) v per head —
  * replaces FlashAttn2Weight/FlashAttn3Weight/TorchSDPAWeight.apply (common/ops/attn/attn_weight.py:71-126,
  * 209-239) for one sequence (cu_seqlens = [0, S]).  q/k/v: token stride in elements (ldq/ldk/ldv), head h
- * at column offset h*128; fp32 softmax, bf16 P, fp32 accumulate.  scale <= 0 selects 1/sqrt(128). */
+ * at column offset h*128; fp32 softmax, bf16 P, fp32 accumulate.  scale <= 0 selects 1/sqrt(128).
+ * Sq == 0 (an empty query shard) is a no-op returning X2V_OK; Sk == 0 is X2V_E_SHAPE (softmax over nothing). */
 int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                       int64_t Sk, int H, int head_dim, float scale, void* stream);
 

@@ -1687,6 +1687,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_transpose_heads_bf16(c
 
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo,
                                                                            int64_t Sq, int64_t Sk, int H, int head_dim, float scale, int q_prescaled, void* stream) {
+  if (Sq == 0 && Sk > 0 && H > 0) return X2V_OK;  // no query rows: nothing to write (empty shard)
   X2V_REQUIRE(q && k && vt && o, X2V_E_ARG, "attn_vt: null pointer");
   X2V_REQUIRE(head_dim == AT_D, X2V_E_SHAPE, "attn_vt: head_dim=%d (only 128 is built)", head_dim);
   X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535, X2V_E_SHAPE, "attn_vt: bad shape Sq=%lld Sk=%lld H=%d", (long long)Sq, (long long)Sk, H);
@@ -1714,6 +1715,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
 // v3 (scale folded into Q, running max as the MFMA C operand, x2-unrolled tile loop): 8 = THR 8, 9 = THR 4
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                                          int64_t Sk, int H, int head_dim, float scale, int variant, void* stream) {
+  if (Sq == 0 && Sk > 0 && H > 0) return X2V_OK;  // no query rows: nothing to write (empty shard)
   X2V_REQUIRE(q && k && v && o, X2V_E_ARG, "attn: null pointer");
   X2V_REQUIRE(head_dim == AT_D, X2V_E_SHAPE, "attn: head_dim=%d (only 128 is built)", head_dim);
   X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535, X2V_E_SHAPE, "attn: bad shape Sq=%lld Sk=%lld H=%d", (long long)Sq, (long long)Sk, H);

@@ -5,6 +5,7 @@
 // achievable HBM.  Structure: a row lives entirely in registers between its single 16-byte-vector read
 // and its single write (two-pass statistics cost no extra HBM traffic); NW waves cooperate on one row
 // (NW=4 for the model dim, NW=1 for short rows so a 256-thread block carries 4 rows).
+#include <algorithm>
 #include <type_traits>
 
 #include "x2v_common.h"
@@ -150,6 +151,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
   }
 }
 
+// One complex rotation (a + i b) * (co + i si), then the optional output scale — written with explicit fused multiply-adds so every
+// kernel that rotates (per-row and streaming forms) rounds identically whatever the optimiser would contract on its own.
+__device__ __forceinline__ void rope_pair(float a, float bb, float co, float si, float oscale, float& o0, float& o1) {
+  o0 = __builtin_fmaf(a, co, -(bb * si)) * oscale;
+  o1 = __builtin_fmaf(a, si, bb * co) * oscale;
+}
+
 // Fused q/k RMSNorm over the full model dim + 3-axis RoPE.  blockIdx.y selects q (0) or k (1).
 // One block per token row; D = H*128 so every 16-byte chunk holds 4 (re,im) pairs of one head.
 template <int CH, int ROUND>
@@ -217,11 +225,220 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(unsigned short* __res
         co = f.x;
         si = f.y;
       }
-      const float a = xn[2 * p], bb = xn[2 * p + 1];
-      o[2 * p] = (a * co - bb * si) * oscale;
-      o[2 * p + 1] = (a * si + bb * co) * oscale;
+      rope_pair(xn[2 * p], xn[2 * p + 1], co, si, oscale, o[2 * p], o[2 * p + 1]);
     }
     *reinterpret_cast<uint4*>(base + e) = pack8(o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming forms of the two kernels above for long inputs (M >> #CUs; the DiT's [S, D] activations).
+// One block per row pays the whole load -> reduce -> reduce -> store chain once per 20 KB and re-fetches / re-unpacks the
+// per-channel operands for every row; with ~11 VALU operations per element (three bf16 rounding points) these kernels sit at
+// 62-70 % of the achievable bandwidth, issue-bound as much as latency-bound.  Here a block is persistent (grid = what fits the
+// chip at once), walks rows blockIdx.x, +gridDim.x, ..., issues the NEXT row's 16-byte loads before the current row's
+// reductions, and keeps the per-channel operands (affine / modulation rows with 1 + scale already rounded, norm weights) in
+// registers and the token's rotation factors in LDS, fetched once per block / per token instead of once per row.  (A deeper
+// prefetch — two rows ahead — measured slower: more registers, fewer resident blocks, and the hoisted operand math gone.)  The arithmetic (order of every sum and rounding) is exactly that of the kernels above: the two forms
+// give bit-identical outputs, which tools/x2v_check and tests/test_gpu_edge.py assert.
+template <int CH>
+__device__ __forceinline__ void load_row_raw(uint4 (&dst)[CH], const unsigned short* row, int D, int t) {
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int e = (c * 256 + t) * 8;
+    if (e < D) dst[c] = *reinterpret_cast<const uint4*>(row + e);
+    else dst[c] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <int CH, bool AFF, bool MOD>
+__global__ __launch_bounds__(256) void layernorm_stream_kernel(const unsigned short* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ w,
+                                                               const unsigned short* __restrict__ b, const unsigned short* __restrict__ scale,
+                                                               const unsigned short* __restrict__ shift, unsigned short* __restrict__ y, int64_t ldy,
+                                                               int64_t M, int D, float eps) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  // per-channel operands, resident for every row of this block (absent w -> 1.0, absent b -> 0: unused placeholders); the optimiser
+  // hoists their unpacking and the rounding of 1 + scale out of the row loop, which is where most of the gain over the per-row form
+  // comes from: at 6 TB/s these kernels are as much VALU-issue bound (~11 operations per element) as they are latency bound
+  uint4 wv[AFF ? CH : 1], bv[AFF ? CH : 1], scv[MOD ? CH : 1], shv[MOD ? CH : 1];
+  bool ok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int e = (c * 256 + t) * 8;
+    ok[c] = e < D;
+    if constexpr (AFF) {
+      wv[c] = (ok[c] && w != nullptr) ? *reinterpret_cast<const uint4*>(w + e) : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      bv[c] = (ok[c] && b != nullptr) ? *reinterpret_cast<const uint4*>(b + e) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if constexpr (MOD) {
+      scv[c] = ok[c] ? *reinterpret_cast<const uint4*>(scale + e) : make_uint4(0u, 0u, 0u, 0u);
+      shv[c] = ok[c] ? *reinterpret_cast<const uint4*>(shift + e) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  const int64_t stride = gridDim.x;
+  int64_t row = blockIdx.x;
+  uint4 cur[CH], nxt[CH];
+  if (row < M) load_row_raw<CH>(cur, x + row * ldx, D, t);
+  for (; row < M; row += stride) {
+    if (row + stride < M) load_row_raw<CH>(nxt, x + (row + stride) * ldx, D, t);  // in flight across this row's reductions
+    float v[CH][8];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) unpack8(cur[c], v[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    s = block_sum<4>(s, red);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (ok[c]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float d = v[c][j] - mean;
+          q += d * d;
+        }
+      }
+    q = block_sum<4>(q, red);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    unsigned short* yr = y + row * ldy;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!ok[c]) continue;
+      const int e = (c * 256 + t) * 8;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd;
+      if constexpr (AFF) {
+        float wf[8], bf[8];
+        unpack8(wv[c], wf);
+        unpack8(bv[c], bf);
+        if (w != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] *= wf[j];
+        }
+        if (b != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += bf[j];
+        }
+      }
+      if constexpr (MOD) {  // norm_out.mul_(1 + scale).add_(shift): three bf16 roundings
+        float sc[8], sh[8];
+        unpack8(scv[c], sc);
+        unpack8(shv[c], sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float ln = rbf(o[j]);
+          float m = rbf(ln * rbf(1.0f + sc[j]));
+          o[j] = m + sh[j];
+        }
+      }
+      *reinterpret_cast<uint4*>(yr + e) = pack8(o);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) cur[c] = nxt[c];
+  }
+}
+
+// q and k rows of one token are handled back to back by the same block, so the token's 64 rotation factors are gathered once
+// (64 lanes, into LDS) instead of 4 scalar 8-byte gathers per 16-byte chunk for q and again for k.
+template <int CH, int ROUND>
+__global__ __launch_bounds__(256) void rmsnorm_rope_stream_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
+                                                                  const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
+                                                                  const float2* __restrict__ cs, int64_t S, int D, int64_t s0, int gf, int gh, int gw,
+                                                                  float eps, float q_out_scale) {
+  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float2 tab[2][64];  // by row parity: staging row n+1 never races readers of row n
+  const int t = threadIdx.x;
+  const bool has_w = wq != nullptr;
+  uint4 wqv[CH], wkv[CH];
+  bool ok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int e = (c * 256 + t) * 8;
+    ok[c] = e < D;
+    wqv[c] = (ok[c] && has_w) ? *reinterpret_cast<const uint4*>(wq + e) : make_uint4(0u, 0u, 0u, 0u);
+    wkv[c] = (ok[c] && has_w) ? *reinterpret_cast<const uint4*>(wk + e) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  const int64_t stride = gridDim.x;
+  const int64_t ntok = (int64_t)gf * gh * gw;
+  int64_t row = blockIdx.x;
+  uint4 cur[CH], nxt[CH];
+  if (row < S) load_row_raw<CH>(cur, q + row * ldq, D, t);
+  int par = 0;
+  for (; row < S; row += stride, par ^= 1) {
+    if (t < 64) {  // this token's rotation factors; beyond the grid -> identity rotation
+      const int64_t g = s0 + row;
+      float2 f = make_float2(1.f, 0.f);
+      if (g < ntok) {
+        const int pw = (int)(g % gw), ph = (int)((g / gw) % gh), pf = (int)(g / ((int64_t)gw * gh));
+        const int pos = t < 22 ? pf : (t < 43 ? ph : pw);
+        f = cs[pos * 64 + t];
+      }
+      tab[par][t] = f;
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      unsigned short* base = which == 0 ? q + row * ldq : k + row * ldk;
+      // the next item (this token's k row, then the next token's q row) is in flight across this item's reduction
+      if (which == 0) load_row_raw<CH>(nxt, k + row * ldk, D, t);
+      else if (row + stride < S) load_row_raw<CH>(nxt, q + (row + stride) * ldq, D, t);
+      const float oscale = which == 0 ? q_out_scale : 1.f;
+      float v[CH][8];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) unpack8(cur[c], v[c]);
+      float rs = 1.f;
+      if (has_w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float p = v[c][j] * v[c][j];
+            ss += (ROUND == X2V_ROUND_REF) ? rbf(p) : p;
+          }
+        ss = block_sum<4>(ss, red);  // its barriers also publish tab[par]
+        if (ROUND == X2V_ROUND_REF) {
+          float mean = rbf(ss / (float)D);
+          rs = rbf(1.0f / sqrtf(rbf(mean + eps)));
+        } else {
+          rs = 1.0f / sqrtf(ss / (float)D + eps);
+        }
+      } else if (which == 0) {
+        __syncthreads();  // publish tab[par]
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (!ok[c]) continue;
+        const int e = (c * 256 + t) * 8;
+        float xn[8], o[8];
+        if (has_w) {
+          float wf[8];
+          unpack8(which == 0 ? wqv[c] : wkv[c], wf);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (ROUND == X2V_ROUND_REF)
+              xn[j] = rbf(rbf(v[c][j] * rs) * wf[j]);
+            else
+              xn[j] = rbf(v[c][j] * rs * wf[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xn[j] = v[c][j];
+        }
+        const int pair0 = (e & 127) >> 1;
+        const float4 f01 = *reinterpret_cast<const float4*>(&tab[par][pair0]);
+        const float4 f23 = *reinterpret_cast<const float4*>(&tab[par][pair0 + 2]);
+        const float co[4] = {f01.x, f01.z, f23.x, f23.z}, si[4] = {f01.y, f01.w, f23.y, f23.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rope_pair(xn[2 * p], xn[2 * p + 1], co[p], si[p], oscale, o[2 * p], o[2 * p + 1]);
+        *reinterpret_cast<uint4*>(base + e) = pack8(o);
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) cur[c] = nxt[c];
+    }
   }
 }
 
@@ -363,6 +580,22 @@ static int dispatch_ch(int ch, int D, F&& f) {
   }
 }
 
+// Blocks of a 256-thread kernel that are resident on the whole chip at once (occupancy x CUs), queried once per kernel: the grid of
+// the persistent "stream" kernels.  0 = query failed (callers fall back to the one-block-per-row form).
+template <auto KERNEL>
+static int resident_blocks() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, nb = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)KERNEL, 256, 0) != hipSuccess || nb <= 0)
+      return 0;
+    cached = nb * prop.multiProcessorCount;
+  }
+  return cached;
+}
+
 extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int D, float eps, int round_mode,
                                 void* stream) {
   X2V_REQUIRE(x && w && y, X2V_E_ARG, "rmsnorm: null pointer");
@@ -395,9 +628,10 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_bf16(const voi
   return X2V_OK;
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* y,
-                                  int64_t ldy, int64_t M, int D, float eps, void* stream) {
+extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16_variant(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift,
+                                                                                 void* y, int64_t ldy, int64_t M, int D, float eps, int variant, void* stream) {
   X2V_REQUIRE(x && y, X2V_E_ARG, "layernorm: null pointer");
+  X2V_REQUIRE(variant >= 0 && variant <= 2, X2V_E_ARG, "layernorm: unknown variant %d", variant);
   X2V_REQUIRE((scale == nullptr) == (shift == nullptr), X2V_E_ARG, "layernorm: scale and shift must be given together");
   X2V_REQUIRE(D > 0 && D % 8 == 0 && D <= 16384, X2V_E_SHAPE, "layernorm: D=%d must be a multiple of 8 and <= 16384", D);
   X2V_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w) && aligned16(b) && aligned16(scale) && aligned16(shift),
@@ -408,19 +642,40 @@ extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16(const v
   auto ys = (unsigned short*)y;
   hipStream_t st = (hipStream_t)stream;
   if (D <= 512) {
+    X2V_REQUIRE(variant != 2, X2V_E_SHAPE, "layernorm: the streaming kernel covers 512 < D <= 8192 (D=%d)", D);
     const unsigned grid = (unsigned)((M + 3) / 4);
     hipLaunchKernelGGL((layernorm_kernel<1, 1>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, bs, scs, shs, ys, ldy, M, D, eps);
   } else {
     const int ch = chunks_for(D, 4);
     const unsigned grid = (unsigned)M;
+    const bool aff = ws != nullptr || bs != nullptr, mod = scs != nullptr;
+    bool streamed = false;
     int rc = dispatch_ch(ch, D, [&](auto chc) {
       constexpr int CH = decltype(chc)::value;
-      hipLaunchKernelGGL((layernorm_kernel<CH, 4>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, bs, scs, shs, ys, ldy, M, D, eps);
+      if constexpr (CH <= 4) {
+        // persistent form for long inputs (bit-identical results; see layernorm_stream_kernel)
+        auto go = [&](auto kern, int resident) {
+          if (variant == 1 || resident <= 0 || (variant == 0 && M < 2 * (int64_t)resident)) return;
+          hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(M, resident)), dim3(256), 0, st, xs, ldx, ws, bs, scs, shs, ys, ldy, M, D, eps);
+          streamed = true;
+        };
+        if (aff && mod) go(layernorm_stream_kernel<CH, true, true>, resident_blocks<layernorm_stream_kernel<CH, true, true>>());
+        else if (aff) go(layernorm_stream_kernel<CH, true, false>, resident_blocks<layernorm_stream_kernel<CH, true, false>>());
+        else if (mod) go(layernorm_stream_kernel<CH, false, true>, resident_blocks<layernorm_stream_kernel<CH, false, true>>());
+        else go(layernorm_stream_kernel<CH, false, false>, resident_blocks<layernorm_stream_kernel<CH, false, false>>());
+      }
+      if (!streamed) hipLaunchKernelGGL((layernorm_kernel<CH, 4>), dim3(grid), dim3(256), 0, st, xs, ldx, ws, bs, scs, shs, ys, ldy, M, D, eps);
     });
     if (rc != X2V_OK) return rc;
+    X2V_REQUIRE(variant != 2 || streamed, X2V_E_SHAPE, "layernorm: the streaming kernel covers 512 < D <= 8192 (D=%d)", D);
   }
   X2V_LAUNCH_CHECK("layernorm launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* y,
+                                  int64_t ldy, int64_t M, int D, float eps, void* stream) {
+  return x2v_layernorm_bf16_variant(x, ldx, w, b, scale, shift, y, ldy, M, D, eps, 0, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S,
@@ -428,10 +683,11 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_bf16(void
   return x2v_rmsnorm_rope_scaled_bf16(q, ldq, k, ldk, wq, wk, rope_cs, S, H, s0, gf, gh, gw, eps, round_mode, 1.0f, stream);
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs,
-                                                                                   int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode,
-                                                                                   float q_out_scale, void* stream) {
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16_variant(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk,
+                                                                                           const void* rope_cs, int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps,
+                                                                                           int round_mode, float q_out_scale, int variant, void* stream) {
   X2V_REQUIRE(q && k && rope_cs, X2V_E_ARG, "rmsnorm_rope: null pointer");
+  X2V_REQUIRE(variant >= 0 && variant <= 2, X2V_E_ARG, "rmsnorm_rope: unknown variant %d", variant);
   X2V_REQUIRE(q_out_scale > 0.f, X2V_E_ARG, "rmsnorm_rope: q_out_scale must be positive");
   X2V_REQUIRE((wq == nullptr) == (wk == nullptr), X2V_E_ARG, "rmsnorm_rope: wq and wk must be given together");
   const int D = H * 128;
@@ -447,16 +703,35 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf
   auto qs = (unsigned short*)q, ks = (unsigned short*)k;
   auto wqs = (const unsigned short*)wq, wks = (const unsigned short*)wk;
   auto cs = (const float2*)rope_cs;
+  bool streamed = false;
   int rc = dispatch_ch(ch, D, [&](auto chc) {
     constexpr int CH = decltype(chc)::value;
+    if constexpr (CH <= 4) {
+      // persistent form for long inputs (bit-identical results; see rmsnorm_rope_stream_kernel)
+      auto go = [&](auto kern, int resident) {
+        if (variant == 1 || resident <= 0 || (variant == 0 && S < 2 * (int64_t)resident)) return;
+        hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(S, resident)), dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
+        streamed = true;
+      };
+      if (round_mode == X2V_ROUND_REF) go(rmsnorm_rope_stream_kernel<CH, X2V_ROUND_REF>, resident_blocks<rmsnorm_rope_stream_kernel<CH, X2V_ROUND_REF>>());
+      else go(rmsnorm_rope_stream_kernel<CH, X2V_ROUND_FP32>, resident_blocks<rmsnorm_rope_stream_kernel<CH, X2V_ROUND_FP32>>());
+    }
+    if (streamed) return;
     if (round_mode == X2V_ROUND_REF)
       hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_REF>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
     else
       hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_FP32>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
   });
   if (rc != X2V_OK) return rc;
+  X2V_REQUIRE(variant != 2 || streamed, X2V_E_SHAPE, "rmsnorm_rope: the streaming kernel covers D <= 8192 (D=%d)", D);
   X2V_LAUNCH_CHECK("rmsnorm_rope launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs,
+                                                                                   int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode,
+                                                                                   float q_out_scale, void* stream) {
+  return x2v_rmsnorm_rope_scaled_bf16_variant(q, ldq, k, ldk, wq, wk, rope_cs, S, H, s0, gf, gh, gw, eps, round_mode, q_out_scale, 0, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_gate_residual_bf16(void* x, int64_t ldx, const void* y, int64_t ldy, const void* gate, int64_t M, int D, void* stream) {

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "x2v_device_info": [_i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32],
     "x2v_rmsnorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
     "x2v_layernorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
+    "x2v_layernorm_bf16_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
+    "x2v_rmsnorm_rope_scaled_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _i32, _c_void_p],
     "x2v_rmsnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_rmsnorm_rope_scaled_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _c_void_p],
     "x2v_headnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _f32, _c_void_p],
@@ -124,27 +126,47 @@ def _bf16(t, name):
     return t
 
 
+def _vec(t, name, n=None, dtype=torch.bfloat16):
+    """A per-channel operand (bias / norm weight / gate / scale row): None passes through; otherwise a contiguous device vector of
+    `dtype` with `n` elements (any leading unit dims) — the C side only sees a pointer, so a wrong dtype would be silent."""
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        raise X2VError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise X2VError(f"{name}: tensor is on {t.device}; the x2v HIP path has no CPU fallback")
+    if n is not None and t.numel() != n:
+        raise X2VError(f"{name}: expected {n} elements, got shape {tuple(t.shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
 # ----------------------------------------------------------------------------------------------------
 def rmsnorm(x, weight, eps=1e-6, out=None, round_mode=ROUND_FP32):
     shape = x.shape
     x2 = _row2d(_bf16(x.reshape(-1, shape[-1]) if x.dim() != 2 else x, "x"), "x")
     out2 = torch.empty((x2.shape[0], x2.shape[1]), dtype=torch.bfloat16, device=x.device) if out is None else _row2d(out.reshape(-1, shape[-1]) if out.dim() != 2 else out, "out")
     init()
-    _check(_lib.x2v_rmsnorm_bf16(_p(x2), x2.stride(0), _p(_bf16(weight, "weight")), _p(out2), out2.stride(0), x2.shape[0], x2.shape[1], eps, round_mode, _stream()), "rmsnorm")
+    if x2.shape[0] == 0:  # empty shard: torch hands out a null data_ptr, nothing to launch
+        return out2.view(shape) if out is None else out
+    _check(_lib.x2v_rmsnorm_bf16(_p(x2), x2.stride(0), _p(_vec(weight, "rmsnorm weight", x2.shape[1])), _p(out2), out2.stride(0), x2.shape[0], x2.shape[1], eps, round_mode, _stream()), "rmsnorm")
     return out2.view(shape) if out is None else out
 
 
-def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=None):
-    """LN(x)[*w+b] then optional adaLN `* (1 + scale) + shift` (scale/shift: [D] or [1,D] bf16)."""
+def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=None, variant=0):
+    """LN(x)[*w+b] then optional adaLN `* (1 + scale) + shift` (scale/shift: [D] or [1,D] bf16).  variant: x2v_layernorm_bf16_variant."""
     x2 = _row2d(_bf16(x, "x"), "x")
     out2 = torch.empty_like(x2) if out is None else _row2d(out, "out")
-    if scale is not None:
-        scale, shift = scale.reshape(-1), shift.reshape(-1)
-        if not (scale.is_contiguous() and shift.is_contiguous()):
-            scale, shift = scale.contiguous(), shift.contiguous()
+    D = x2.shape[1]
+    if (scale is None) != (shift is None):
+        raise X2VError("layernorm: scale and shift must be given together")
+    weight, bias = _vec(weight, "layernorm weight", D), _vec(bias, "layernorm bias", D)
+    scale, shift = _vec(scale, "layernorm scale", D), _vec(shift, "layernorm shift", D)
     init()
+    if x2.shape[0] == 0:
+        return out2
     _check(
-        _lib.x2v_layernorm_bf16(_p(x2), x2.stride(0), _p(weight), _p(bias), _p(scale), _p(shift), _p(out2), out2.stride(0), x2.shape[0], x2.shape[1], eps, _stream()),
+        _lib.x2v_layernorm_bf16_variant(_p(x2), x2.stride(0), _p(weight), _p(bias), _p(scale), _p(shift), _p(out2), out2.stride(0), x2.shape[0], x2.shape[1], eps, variant,
+                                        _stream()),
         "layernorm",
     )
     return out2
@@ -157,16 +179,19 @@ ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
 
 
-def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0):
+def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0, variant=0):
     """In place: q,k [S, H*128] ← RoPE3D(RMSNorm(q|k)); q additionally * q_out_scale inside its final rounding."""
     q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
     if rope_cs.dtype != torch.float32 or tuple(rope_cs.shape) != (1024, 64, 2) or not rope_cs.is_contiguous():
         raise X2VError("rope_cs must be a contiguous float32 [1024,64,2] (cos,sin) table")
     gf, gh, gw = grid
+    wq, wk = _vec(wq, "norm_q weight", q2.shape[1]), _vec(wk, "norm_k weight", k2.shape[1])
     init()
+    if q2.shape[0] == 0:
+        return q, k
     _check(
-        _lib.x2v_rmsnorm_rope_scaled_bf16(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(wq), _p(wk), _p(rope_cs), q2.shape[0], num_heads, s0, gf, gh, gw, eps, round_mode,
-                                          q_out_scale, _stream()),
+        _lib.x2v_rmsnorm_rope_scaled_bf16_variant(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(wq), _p(wk), _p(rope_cs), q2.shape[0], num_heads, s0, gf, gh, gw, eps,
+                                                  round_mode, q_out_scale, variant, _stream()),
         "rmsnorm_rope",
     )
     return q, k
@@ -174,9 +199,10 @@ def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_
 
 def gate_residual_(x, y, gate=None):
     x2, y2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(y, "y"), "y")
-    if gate is not None:
-        gate = gate.reshape(-1)
+    gate = _vec(gate, "gate", x2.shape[1])
     init()
+    if x2.shape[0] == 0:
+        return x
     _check(_lib.x2v_gate_residual_bf16(_p(x2), x2.stride(0), _p(y2), y2.stride(0), _p(gate), x2.shape[0], x2.shape[1], _stream()), "gate_residual")
     return x
 
@@ -201,12 +227,16 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
             raise X2VError("gemm: residual epilogue needs resid")
         out2 = _row2d(resid if out is None else out, "out")
         r2 = _row2d(_bf16(resid, "resid"), "resid")
-        if gate is not None:
-            gate = gate.reshape(-1)
+        gate = _vec(gate, "gemm gate", N)
     else:
         out2 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if out is None else _row2d(out, "out")
         r2 = None
+    bias = _vec(bias, "gemm bias", N)
+    if _bf16(out2, "out").shape != (M, N):
+        raise X2VError(f"gemm: out is {tuple(out2.shape)}, expected {(M, N)}")
     init()
+    if M == 0:
+        return out2
     _check(
         _lib.x2v_gemm_bf16_variant(_p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), variant, _stream()),
         "gemm_bf16",
@@ -239,8 +269,14 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
 
     q2, k2, v2 = as2d(q, "q"), as2d(k, "k"), as2d(v, "v")
     Sq, Sk = q2.shape[0], k2.shape[0]
-    out2 = torch.empty((Sq, num_heads * head_dim), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(out, "out")
+    out2 = torch.empty((Sq, num_heads * head_dim), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(_bf16(out, "out"), "out")
+    if out2.shape[0] != Sq or v2.shape[0] != Sk or min(q2.shape[1], k2.shape[1], v2.shape[1], out2.shape[1]) < num_heads * head_dim:
+        raise X2VError(f"attention: q {tuple(q2.shape)} k {tuple(k2.shape)} v {tuple(v2.shape)} out {tuple(out2.shape)} do not describe {num_heads} heads of {head_dim}")
+    if Sk == 0:
+        raise X2VError("attention: no keys (softmax over an empty set)")
     init()
+    if Sq == 0:
+        return out2
     if (variant & 0xFF) == ATTN_FAST:
         if vt is None:
             vt = transpose_heads(v2, num_heads)
@@ -265,6 +301,8 @@ def quant_fp8_rowwise(x):
     xq = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
     s = torch.empty((M, 1), dtype=torch.float32, device=x.device)
     init()
+    if M == 0:
+        return xq, s
     _check(_lib.x2v_quant_fp8_rowwise(_p(x2), x2.stride(0), _p(xq), xq.stride(0), _p(s), M, K, _stream()), "quant_fp8_rowwise")
     return xq, s
 
@@ -277,6 +315,8 @@ def quant_mxfp8(x):
     q = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
     sc = torch.empty((max(K // 128, 1), M, 4), dtype=torch.uint8, device=x.device)
     init()
+    if M == 0:
+        return q, sc
     _check(_lib.x2v_quant_mxfp8_bf16(_p(x2), x2.stride(0), _p(q), q.stride(0), _p(sc), M, K, _stream()), "quant_mxfp8")
     return q, sc
 
@@ -314,8 +354,8 @@ def gemm_mxfp8(a, sa, b, sb, alpha=None, bias=None, out=None, variant=0, epilogu
     if epilogue != EPI_NONE:
         if epilogue == EPI_RESIDUAL:
             out2 = _row2d(resid if out is None else out, "out")
-            r2 = _row2d(resid, "resid")
-            gate = None if gate is None else gate.reshape(-1)
+            r2 = _row2d(_bf16(resid, "resid"), "resid")
+            gate = _vec(gate, "gemm_mxfp8 gate", N)
         else:
             out2 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out is None else _row2d(out, "out")
             r2 = None
@@ -342,15 +382,18 @@ def gemm_fp8(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, resid=None, gate=N
         raise X2VError("gemm_fp8: operands must be float8_e4m3fn (OCP; gfx950)")
     if epilogue == EPI_RESIDUAL:
         out2 = _row2d(resid if out is None else out, "out")
-        r2 = _row2d(resid, "resid")
-        if gate is not None:
-            gate = gate.reshape(-1)
+        r2 = _row2d(_bf16(resid, "resid"), "resid")
+        gate = _vec(gate, "gemm_fp8 gate", N)
     else:
         out2 = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device) if out is None else _row2d(out, "out")
         r2 = None
-    sw = sw.reshape(-1)
-    sx = sx.reshape(-1)
+    if wq_nk.shape[1] != K or not xq.is_cuda or not wq_nk.is_cuda or xq.stride(1) != 1 or wq_nk.stride(1) != 1:
+        raise X2VError(f"gemm_fp8: xq {tuple(xq.shape)} / wq {tuple(wq_nk.shape)} must be device matrices with unit inner stride and equal K")
+    sw, sx = _vec(sw, "gemm_fp8 weight scales", N, torch.float32), _vec(sx, "gemm_fp8 activation scales", M, torch.float32)
+    bias = _vec(bias, "gemm_fp8 bias", N)
     init()
+    if M == 0:
+        return out2
     _check(
         _lib.x2v_gemm_fp8_variant(_p(xq), xq.stride(0), _p(sx), _p(wq_nk), wq_nk.stride(0), _p(sw), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), variant, _stream()),
         "gemm_fp8",

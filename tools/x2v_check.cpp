@@ -988,6 +988,90 @@ static void run_bench(bool big) {
   }
 }
 
+// HBM-bound row kernels at the DiT activation shapes: the one-block-per-row and the persistent streaming forms must agree bit for
+// bit (same arithmetic, different schedule), and both are timed against the achievable HBM rate.  `x2v_check hbm`
+static ErrStat compare_bits(const DevBuf<uint16_t>& a, const DevBuf<uint16_t>& b) {
+  const auto ha = a.host(), hb = b.host();
+  ErrStat e;
+  e.n = ha.size();
+  if (memcmp(ha.data(), hb.data(), ha.size() * 2) != 0)
+    for (size_t i = 0; i < ha.size(); ++i) e.bad += ha[i] != hb[i];
+  e.max_abs = (double)e.bad;
+  return e;
+}
+
+static void run_hbm() {
+  Rng rng(41);
+  // all = every operand combination is compared (small shapes); otherwise only the combinations the DiT block uses
+  struct Shape { int64_t M; int D; int gf, gh, gw; bool all; } shapes[] = {{1000, 5120, 3, 17, 20, true},  {3000, 1536, 3, 25, 40, true}, {2100, 3072, 3, 25, 28, true},
+                                                                           {777, 8192, 3, 16, 16, true},   {75600, 5120, 21, 45, 80, false}, {20280, 1536, 13, 30, 52, false}};
+  for (auto sh : shapes) {
+    const int64_t M = sh.M;
+    const int D = sh.D;
+    DevBuf<uint16_t> x((size_t)M * D), y1((size_t)M * D), y2((size_t)M * D), w(D), b(D), sc(D), shf(D), q1((size_t)M * D), k1((size_t)M * D), q2((size_t)M * D), k2((size_t)M * D);
+    fill_random(x, rng, 1.f);
+    fill_random(w, rng, 1.f);
+    fill_random(b, rng, .1f);
+    fill_random(sc, rng, .1f);
+    fill_random(shf, rng, .1f);
+    std::vector<float> cs(1024 * 64 * 2);
+    for (size_t i = 0; i < cs.size(); i += 2) {
+      const double a = 0.37 * (double)(i / 2 % 977);
+      cs[i] = (float)cos(a);
+      cs[i + 1] = (float)sin(a);
+    }
+    DevBuf<float> dcs(cs);
+    const double bytes = 2.0 * M * D * 2;
+    char name[160];
+    struct Ln { const char* what; const uint16_t *w, *b, *sc, *sh; } lns[] = {{"modulate", nullptr, nullptr, sc.p, shf.p}, {"affine", w.p, b.p, nullptr, nullptr},
+                                                                             {"plain", nullptr, nullptr, nullptr, nullptr}, {"affine+modulate", w.p, b.p, sc.p, shf.p}};
+    for (auto ln : lns) {
+      if (!sh.all && ln.what[0] == 'p') continue;
+      if (!sh.all && ln.w && ln.sc) continue;
+      X2V_OKAY(x2v_layernorm_bf16_variant(x.p, D, ln.w, ln.b, ln.sc, ln.sh, y1.p, D, M, D, 1e-6f, 1, nullptr));
+      X2V_OKAY(x2v_layernorm_bf16_variant(x.p, D, ln.w, ln.b, ln.sc, ln.sh, y2.p, D, M, D, 1e-6f, 2, nullptr));
+      HIP_OK(hipDeviceSynchronize());
+      snprintf(name, sizeof name, "layernorm %s M=%lld D=%d: streaming == per-row (bit-exact)", ln.what, (long long)M, D);
+      report(name, compare_bits(y2, y1));
+      if (sh.all) continue;
+      for (int variant : {1, 2}) {
+        double ms = time_ms(10, [&] { X2V_OKAY(x2v_layernorm_bf16_variant(x.p, D, ln.w, ln.b, ln.sc, ln.sh, y1.p, D, M, D, 1e-6f, variant, nullptr)); });
+        printf("BENCH layernorm %-16s v=%d M=%lld D=%d %9.3f ms  %8.1f GB/s (%.1f%% of 6290 achievable)\n", ln.what, variant, (long long)M, D, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 62.9);
+      }
+    }
+    for (int mode = 0; mode < 2; ++mode) {
+      for (int with_w = 1; with_w >= 0; --with_w) {
+        if (!sh.all && (mode == 1 || with_w == 0)) continue;
+        HIP_OK(hipMemcpy(q1.p, x.p, (size_t)M * D * 2, hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemcpy(q2.p, x.p, (size_t)M * D * 2, hipMemcpyDeviceToDevice));
+        HIP_OK(hipMemset(k1.p, 0, (size_t)M * D * 2));
+        HIP_OK(hipMemset(k2.p, 0, (size_t)M * D * 2));
+        HIP_OK(hipMemcpy(k1.p, x.p + 8, ((size_t)M * D - 8) * 2, hipMemcpyDeviceToDevice));  // k = x shifted by one chunk: different data than q
+        HIP_OK(hipMemcpy(k2.p, x.p + 8, ((size_t)M * D - 8) * 2, hipMemcpyDeviceToDevice));
+        const uint16_t* ww = with_w ? w.p : nullptr;
+        const uint16_t* wk = with_w ? b.p : nullptr;
+        // s0 = 7: the last 7 tokens fall beyond the grid (identity rotation)
+        X2V_OKAY(x2v_rmsnorm_rope_scaled_bf16_variant(q1.p, D, k1.p, D, ww, wk, dcs.p, M, D / 128, 7, sh.gf, sh.gh, sh.gw, 1e-6f, mode, 0.1275f, 1, nullptr));
+        X2V_OKAY(x2v_rmsnorm_rope_scaled_bf16_variant(q2.p, D, k2.p, D, ww, wk, dcs.p, M, D / 128, 7, sh.gf, sh.gh, sh.gw, 1e-6f, mode, 0.1275f, 2, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        snprintf(name, sizeof name, "rmsnorm+rope M=%lld D=%d mode=%d norm=%d: streaming == per-row (bit-exact, q)", (long long)M, D, mode, with_w);
+        report(name, compare_bits(q2, q1));
+        snprintf(name, sizeof name, "rmsnorm+rope M=%lld D=%d mode=%d norm=%d: streaming == per-row (bit-exact, k)", (long long)M, D, mode, with_w);
+        report(name, compare_bits(k2, k1));
+      }
+    }
+    if (sh.all) continue;
+    for (int variant : {1, 2}) {
+      double ms = time_ms(10, [&] { X2V_OKAY(x2v_rmsnorm_rope_scaled_bf16_variant(q1.p, D, k1.p, D, w.p, b.p, dcs.p, M, D / 128, 0, sh.gf, sh.gh, sh.gw, 1e-6f, 0, 0.1275f, variant, nullptr)); });
+      printf("BENCH rmsnorm+rope (q,k) v=%d M=%lld D=%d %9.3f ms  %8.1f GB/s (%.1f%%)\n", variant, (long long)M, D, ms, 2 * bytes / ms / 1e6, 2 * bytes / ms / 1e6 / 62.9);
+    }
+    double ms = time_ms(10, [&] { X2V_OKAY(x2v_rmsnorm_bf16(x.p, D, w.p, y1.p, D, M, D, 1e-6f, 0, nullptr)); });
+    printf("BENCH rmsnorm M=%lld D=%d            %9.3f ms  %8.1f GB/s (%.1f%%)\n", (long long)M, D, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 62.9);
+    ms = time_ms(10, [&] { X2V_OKAY(x2v_gate_residual_bf16(y1.p, D, x.p, D, sc.p, M, D, nullptr)); });
+    printf("BENCH gate_residual M=%lld D=%d       %9.3f ms  %8.1f GB/s (%.1f%%; 3 streams)\n", (long long)M, D, ms, 1.5 * bytes / ms / 1e6, 1.5 * bytes / ms / 1e6 / 62.9);
+  }
+}
+
 // single-kernel loops for rocprofv3 --pmc passes: `x2v_check pattn <variant> <S> <H> [iters]`, `x2v_check pgemm <M> <N> <K> [iters]`
 static void run_single(int argc, char** argv) {
   Rng rng(31);
@@ -1039,6 +1123,7 @@ int main(int argc, char** argv) {
   if (mode == "attn" || mode == "all") run_attn();
   if (mode == "fp8" || mode == "all") run_fp8();
   if (mode == "conv" || mode == "all") run_conv();
+  if (mode == "hbm") run_hbm();
   if (mode == "bench") run_bench(false);
   if (mode == "benchbig") run_bench(true);
   printf("x2v_check %s: %s (%d failing checks)\n", mode.c_str(), g_fail ? "FAILED" : "ALL PASS", g_fail);
