@@ -60,6 +60,8 @@ def main():
         if r == 0:
             print("REFERENCE_EXCHANGE_OK")
 
+    hunyuan_checks(r, n, ulysses, O)
+
     # distributed oracle forward == single-process oracle forward (pins compute_freqs_dist + sharding; S % N == 0)
     from lightx2v_amd import synth
 
@@ -84,6 +86,83 @@ def main():
     if r == 0:
         print("DIST_OK")
     dist.destroy_process_group()
+
+
+def hunyuan_checks(r, n, ulysses, O):
+    """HunyuanVideo's joint image+text attention under Ulysses and the latent / RoPE-table sharding around the model:
+    against the single-process result, and — where /root/reference exists — against the reference's own ulysses_attn
+    (attentions/distributed/ulysses/attn.py:7-91) and hunyuan processor (utils/hunyuan/processor.py:5-77) in this same 2-process run."""
+    gen = torch.Generator().manual_seed(11)
+    H, d = 4, 128
+    t_, hh, ww = 2, 4, 6  # token grid (latent 8 x 12): h % n == 0 -> split along h
+    n_img_full, n_txt = t_ * hh * ww, 10
+    qf, kf, vf = (torch.randn(n_img_full + n_txt, H * d, generator=gen).to(torch.bfloat16) for _ in range(3))
+
+    # each rank holds its image rows (contiguous slab of the h axis of every frame) and all text rows
+    idx = torch.arange(n_img_full).view(t_, hh, ww)
+    mine = torch.chunk(idx, n, dim=1)[r].reshape(-1)
+    order = torch.cat([torch.chunk(idx, n, dim=1)[j].reshape(-1) for j in range(n)])  # rank-major image order seen by the attention
+    rows = torch.cat([mine, n_img_full + torch.arange(n_txt)])
+    q, k, v = qf[rows].contiguous(), kf[rows].contiguous(), vf[rows].contiguous()
+    n_img = mine.numel()
+
+    def sdpa2d(a, b, c, h, oo):
+        dd = a.shape[1] // h
+        oo.copy_(O.sdpa(a.reshape(-1, h, dd), b.reshape(-1, h, dd), c.reshape(-1, h, dd)))
+
+    ua = ulysses.UlyssesHunyuanAttention(attn_fn=sdpa2d)
+    out = torch.empty_like(q)
+    ua(q, k, v, n_img, (n_txt, n_txt), H, out)
+    # single process: attention over [all image tokens in the rank-major order ; text] with all heads
+    allrows = torch.cat([order, n_img_full + torch.arange(n_txt)])
+    full = O.sdpa(qf[allrows].view(-1, H, d), kf[allrows].view(-1, H, d), vf[allrows].view(-1, H, d))
+    inv = {int(g): i for i, g in enumerate(allrows.tolist())}
+    want = full[[inv[int(g)] for g in rows.tolist()]]
+    # attention is permutation-equivariant in the keys up to fp summation order: bf16-rounding agreement, not bits
+    assert (out.float() - want.float()).abs().max() <= 2 ** -6, (out.float() - want.float()).abs().max()
+
+    # masked text: rows beyond n_valid attend among themselves only (two segments, as the single-GPU path)
+    out2 = torch.empty_like(q)
+    ua(q, k, v, n_img, (n_txt - 3, n_txt), H, out2)
+    assert torch.isfinite(out2.float()).all()
+    seg1 = torch.cat([order, n_img_full + torch.arange(n_txt - 3)])
+    f1 = O.sdpa(qf[seg1].view(-1, H, d), kf[seg1].view(-1, H, d), vf[seg1].view(-1, H, d))
+    inv1 = {int(g): i for i, g in enumerate(seg1.tolist())}
+    want1 = f1[[inv1[int(g)] for g in rows[: n_img + n_txt - 3].tolist()]]
+    assert (out2[: n_img + n_txt - 3].float() - want1.float()).abs().max() <= 2 ** -6
+    pad = n_img_full + torch.arange(n_txt - 3, n_txt)
+    f2 = O.sdpa(qf[pad].view(-1, H, d), kf[pad].view(-1, H, d), vf[pad].view(-1, H, d))
+    assert (out2[n_img + n_txt - 3 :].float() - f2.float()).abs().max() <= 2 ** -6
+
+    # latent / RoPE-table sharding and the gather of the noise prediction
+    lat = torch.randn(1, 16, t_, 2 * hh, 2 * ww, generator=gen)
+    cos, sin = torch.randn(n_img_full, d, generator=gen), torch.randn(n_img_full, d, generator=gen)
+    l2, c2, s2, split_dim = ulysses.hunyuan_pre_process(lat, cos, sin)
+    assert split_dim == -2 and torch.equal(l2, torch.chunk(lat, n, dim=-2)[r]) and torch.equal(c2, cos[mine]) and torch.equal(s2, sin[mine])
+    assert torch.equal(ulysses.hunyuan_post_process(l2, split_dim), lat)
+    latw = torch.randn(1, 16, t_, 2 * 3, 2 * ww, generator=gen)  # h = 3 does not divide: split along w
+    l3, c3, s3, sd3 = ulysses.hunyuan_pre_process(latw, torch.randn(t_ * 3 * ww, d, generator=gen), torch.randn(t_ * 3 * ww, d, generator=gen))
+    assert sd3 == -1 and torch.equal(ulysses.hunyuan_post_process(l3, sd3), latw)
+
+    from oracle import ref_import
+
+    if ref_import.reference_available():
+        ref_import.patch_and_import()
+        from lightx2v.attentions.distributed.ulysses import attn as ref_attn
+        from lightx2v.attentions.distributed.utils.hunyuan import processor as ref_proc
+
+        # the reference's dispatcher reaches flash-attn (absent here): one unmasked segment [0, s] is plain SDPA, which is what stands in
+        ref_attn.attention = lambda attention_type, q, k, v, **kw: O.sdpa(q, k, v)
+        got_ref = ref_attn.ulysses_attn(q.view(-1, H, d), k.view(-1, H, d), v.view(-1, H, d), img_qkv_len=n_img,
+                                        cu_seqlens_qkv=torch.tensor([0, n_img + n_txt], dtype=torch.int32), attention_type="flash_attn2")
+        assert torch.equal(out, got_ref), "UlyssesHunyuanAttention differs from the reference's ulysses_attn"
+        rl, rc, rs, rsd = ref_proc.pre_process(lat, cos, sin)
+        assert rsd == split_dim and torch.equal(rl, l2) and torch.equal(rc, c2) and torch.equal(rs, s2)
+        assert torch.equal(ref_proc.post_process(rl.contiguous(), rsd), ulysses.hunyuan_post_process(l2, split_dim))
+        rl3, _, _, rsd3 = ref_proc.pre_process(latw, torch.zeros(t_ * 3 * ww, d), torch.zeros(t_ * 3 * ww, d))
+        assert rsd3 == sd3 and torch.equal(rl3, l3)
+        if r == 0:
+            print("REFERENCE_HUNYUAN_EXCHANGE_OK")
 
 
 if __name__ == "__main__":

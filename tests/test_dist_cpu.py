@@ -1,5 +1,7 @@
-"""N>1 path on CPU: world_size-2 `gloo` run of the Ulysses exchange (seq↔head all-to-all, shard/gather) with the
-oracle attention — must reproduce the single-process result exactly."""
+"""N>1 path on CPU: world_size-2 `gloo` run of the Ulysses exchanges with the oracle attention — Wan (seq↔head all-to-all,
+shard/gather: exact permutations, sharded forward == unsharded) and HunyuanVideo (joint image+text attention, latent / RoPE-table
+split and gather).  Where /root/reference exists the same run also requires bit-equality with the reference's own exchange code
+(comm/all2all.py, utils/wan/processor.py, ulysses/attn.py::ulysses_attn, utils/hunyuan/processor.py)."""
 import os
 import subprocess
 import sys
@@ -14,3 +16,8 @@ def test_ulysses_world2_gloo():
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_OK" in p.stdout
+    sys.path.insert(0, ROOT)
+    from oracle import ref_import
+
+    if ref_import.reference_available():
+        assert "REFERENCE_EXCHANGE_OK" in p.stdout and "REFERENCE_HUNYUAN_EXCHANGE_OK" in p.stdout
