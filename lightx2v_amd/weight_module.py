@@ -56,7 +56,10 @@ class WeightModule:
         for name, child in self._walk((_PARAM,)):
             yield prefix + name, child
         for name, child in self._walk((_MODULE,)):
-            yield from child.named_parameters(f"{prefix}{name}.")
+            if hasattr(child, "named_parameters"):
+                yield from child.named_parameters(f"{prefix}{name}.")
+            else:  # a leaf operator object attached with add_module
+                yield prefix + name, child
 
     # ---- lifecycle
     def calculate_size(self):

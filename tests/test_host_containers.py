@@ -1,0 +1,110 @@
+"""Host-side plumbing the reference's model code is written against: the string-keyed operator registries
+(lightx2v/utils/registry_factory.py) and the recursive weight containers (lightx2v/common/modules/weight_module.py).
+Pure Python, no device."""
+import pytest
+
+from lightx2v_amd.registry import DuplicateKey, Registry
+from lightx2v_amd.weight_module import WeightModule, WeightModuleList
+
+
+def test_registry_decorator_alias_and_lookup():
+    reg = Registry("demo")
+
+    @reg("fast")
+    class Fast:
+        pass
+
+    @reg
+    class Plain:
+        pass
+
+    assert reg["fast"] is Fast and reg["Plain"] is Plain
+    assert "fast" in reg and "slow" not in reg and len(reg) == 2
+    assert sorted(reg.keys()) == ["Plain", "fast"] and dict(reg.items())["fast"] is Fast and Fast in reg.values()
+    with pytest.raises(Exception):  # the reference raises a bare Exception for a taken key
+        reg("fast")(Plain)
+    with pytest.raises(DuplicateKey):
+        reg.register(Plain)
+    reg["Default"] = Fast  # item assignment is an explicit alias / override, as the reference's dict-style writes
+    reg["fast"] = Plain
+    assert reg["Default"] is Fast and reg["fast"] is Plain
+    with pytest.raises(KeyError, match="demo registry has no 'nope'"):
+        reg["nope"]
+    with pytest.raises(TypeError):
+        reg["bad"] = 3
+    assert reg.get("nope") is None
+
+
+class _Leaf:
+    def __init__(self, name, log):
+        self.name, self.log, self.cfg = name, log, None
+
+    def set_config(self, cfg):
+        self.cfg = cfg
+
+    def load(self, wd):
+        self.log.append(("load", self.name))
+        self.value = wd[self.name]
+
+    def state_dict(self, dest):
+        dest[self.name] = self.value
+        return dest
+
+    def to_cuda(self, non_blocking=False):
+        self.log.append(("cuda", self.name, non_blocking))
+
+    def to_cpu(self, non_blocking=False):
+        self.log.append(("cpu", self.name, non_blocking))
+
+    def _calculate_size(self):
+        return 10
+
+    def clear(self):
+        self.log.append(("clear", self.name))
+
+
+class _Block(WeightModule):
+    def __init__(self, i, log, config):
+        super().__init__()
+        self.config = config
+        self.register_parameter("modulation", _Leaf(f"blocks.{i}.modulation", log))
+        self.add_module("q", _Leaf(f"blocks.{i}.q.weight", log))
+        self.add_module("absent", None)
+
+
+class _Tree(WeightModule):
+    def __init__(self, log):
+        super().__init__()
+        self.config = {"mm_config": {"mm_type": "Hip-bf16"}}
+        self.register_parameter("head", _Leaf("head.weight", log))
+        self.blocks = WeightModuleList([_Block(i, log, self.config) for i in range(2)])
+        self.add_module("blocks", self.blocks)
+
+
+def test_weight_module_tree_walks():
+    log = []
+    tree = _Tree(log)
+    wd = {"head.weight": 1, "blocks.0.modulation": 2, "blocks.0.q.weight": 3, "blocks.1.modulation": 4, "blocks.1.q.weight": 5}
+    tree.load(wd)
+    # sub-modules load before parameters at every level (the reference's order); every leaf got the mm_config
+    assert [n for op, n in log if op == "load"] == ["blocks.0.q.weight", "blocks.0.modulation", "blocks.1.q.weight", "blocks.1.modulation", "head.weight"]
+    assert tree.head.cfg == {"mm_type": "Hip-bf16"} and tree.blocks[1].q.cfg == {"mm_type": "Hip-bf16"}
+    # state_dict: parameters first, then sub-modules
+    assert list(tree.state_dict()) == ["head.weight", "blocks.0.modulation", "blocks.0.q.weight", "blocks.1.modulation", "blocks.1.q.weight"]
+    assert tree.state_dict() == wd
+    names = [n for n, _ in tree.named_parameters()]
+    assert names == ["head", "blocks.0.modulation", "blocks.0.q", "blocks.1.modulation", "blocks.1.q"]
+    assert tree.calculate_size() == 10  # leaves of this level only (the reference sizes one block at a time for its offload manager)
+    assert tree.blocks[0].calculate_size() == 20 and len(tree.blocks) == 2 and [b for b in tree.blocks] == [tree.blocks[0], tree.blocks[1]]
+    del log[:]
+    tree.blocks[0].to_cuda_async()
+    tree.blocks[0].to_cpu()
+    tree.blocks[0].clear()
+    assert log == [("cuda", "blocks.0.q.weight", True), ("cuda", "blocks.0.modulation", True), ("cpu", "blocks.0.q.weight", False),
+                   ("cpu", "blocks.0.modulation", False), ("clear", "blocks.0.q.weight"), ("clear", "blocks.0.modulation")]
+    # re-attaching a name replaces the child instead of loading / exporting it twice
+    replacement = _Leaf("blocks.0.q.weight", log)
+    tree.blocks[0].add_module("q", replacement)
+    assert tree.blocks[0].q is replacement
+    tree.blocks[0].load(wd)
+    assert list(tree.blocks[0].state_dict()) == ["blocks.0.modulation", "blocks.0.q.weight"]
