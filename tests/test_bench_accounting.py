@@ -1,0 +1,40 @@
+"""The algorithmic work bench.py divides by (roofline.achieved, step_tflops) must be SURVEY.md §8(d)'s per-unit figures:
+per Wan block and forward GEMM = 12 S D^2 + 4 Lc D^2 + 4 S D F, ATTN = 4 S^2 D + 4 S Lc D; step = L x (GEMM + ATTN) x forwards."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_step_flops_match_survey_table(bench):
+    from lightx2v_amd import synth
+
+    # config 2 (1.3B 480p x 49f, S = 20280) and config 3 (14B 720p x 81f, S = 75600), CFG = 2 forwards
+    rows = {"wan1.3b_480px49f": (20280, 1.695e12, 2.591e12, 2.572e14), "wan14b_720px81f": (75600, 4.524e13, 1.178e14, 1.305e16)}
+    for name, (S, gemm_blk, attn_blk, step) in rows.items():
+        wl = synth.WORKLOADS[name]
+        dims = synth.WAN_DIMS[wl["model"]]
+        assert synth.seq_len_of(wl["target_shape"]) == S
+        total, attn = bench.step_flops(dims, S, dims["text_len"], 2)
+        L = dims["num_layers"]
+        assert attn / (2 * L) == pytest.approx(attn_blk, rel=2e-3)
+        assert (total - attn) / (2 * L) == pytest.approx(gemm_blk, rel=2e-3)
+        assert total == pytest.approx(step, rel=2e-3)
+    # the distilled config runs one forward per step: half the CFG step
+    dims = synth.WAN_DIMS["wan2.1-14b"] if "wan2.1-14b" in synth.WAN_DIMS else synth.WAN_DIMS[synth.WORKLOADS["wan14b_720px81f"]["model"]]
+    assert bench.step_flops(dims, 75600, 512, 1)[0] * 2 == bench.step_flops(dims, 75600, 512, 2)[0]
+
+
+def test_roofline_peak_is_the_dense_bf16_figure(bench):
+    # /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters": 2.5 PFLOP/s dense bf16 (the 5 PFLOP/s headline includes 2:1 sparsity)
+    assert bench.BF16_MFMA_PEAK_TFLOPS == 2500.0
