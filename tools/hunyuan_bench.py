@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Times one HunyuanVideo-13B denoise step (HIP path) on a synthetic 720p x 129-frame latent (BASELINE config #5 on
 one GPU: 118 800 image + 256 text tokens, 20 double + 40 single blocks) with seeded random weights.
-    python tools/hunyuan_bench.py [--workload hunyuan13b_720px129f] [--steps 1] [--warmup 1]"""
+    python tools/hunyuan_bench.py [--workload hunyuan13b_720px129f] [--steps 1] [--warmup 1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/hunyuan_bench.py --gpus N
+        (config #5 as specified: Ulysses over RCCL, latent grid split along h or w, 24 heads -> N in {1, 2, 3, 4, 6, 8})"""
 import argparse
 import json
 import os
@@ -26,14 +28,31 @@ def main():
     ap.add_argument("--workload", default="hunyuan13b_720px129f")
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
-    lib.init(0)
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib.init(local_rank)
     wl = synth.HUNYUAN_WORKLOADS[a.workload]
     dims = synth.HUNYUAN_DIMS[wl["model"]]
     cfg = hy.default_config(dims, infer_steps=50)
     wd = synth.synth_hunyuan_weights(dims, seed=0, device="cuda", gen_device="cuda")
     model = hy.HunyuanModel(cfg, wd)
     del wd
+    if world > 1:
+        from lightx2v_amd import ulysses
+
+        if dims["heads"] % world:
+            raise SystemExit(f"Ulysses needs heads % N == 0 ({dims['heads']} heads, N={world})")
+        ulysses.parallelize_hunyuan(model)
     lat, text_states, mask, ts2 = synth.synth_hunyuan_inputs(dims, wl["target_shape"], valid_text=(dims["text_len"] * 3) // 4)
     sch = hy.HunyuanScheduler(cfg)
     sch.prepare(lat)
@@ -45,20 +64,36 @@ def main():
         model.infer(inputs)
         sch.step_post()
 
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for i in range(a.warmup):
         one(i)
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
         one(a.warmup + i)
-    torch.cuda.synchronize()
+    fence()
     dt = (time.perf_counter() - t0) / a.steps
+    if dist is not None:  # slowest rank
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
     assert torch.isfinite(sch.latents).all()
     _, _, t, h, w = wl["target_shape"]
     n_img = t * (h // 2) * (w // 2)
     fl = step_flops(dims, n_img, dims["text_len"])
-    print(json.dumps({"workload": a.workload, "tokens": n_img + dims["text_len"], "ms_per_step": dt * 1e3, "step_tflop": fl / 1e12, "tflops_per_s": fl / dt / 1e12,
-                      "frac_of_bf16_peak": fl / dt / 1e12 / 2500.0, "frames_per_s_50_steps": wl["frames"] / (50 * dt), "hbm_gb": torch.cuda.max_memory_allocated() / 1e9}))
+    if rank == 0:
+        print(json.dumps({"workload": a.workload, "n_gpus": world, "parallelism": f"ulysses-sp{world}" if world > 1 else "single", "tokens": n_img + dims["text_len"],
+                          "ms_per_step": dt * 1e3, "step_tflop": fl / 1e12, "tflops_per_s": fl / dt / 1e12, "tflops_per_s_per_gpu": fl / dt / 1e12 / world,
+                          "frac_of_bf16_peak": fl / dt / 1e12 / world / 2500.0, "frames_per_s_50_steps": wl["frames"] / (50 * dt),
+                          "hbm_gb": torch.cuda.max_memory_allocated() / 1e9}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
