@@ -2,7 +2,9 @@
 """End-to-end wall clock of the hot path on one GPU: the full denoise loop (all infer_steps, CFG) followed by the VAE decode of the
 final latents — the quantity BASELINE.json's north star asks for next to the per-step number ("end-to-end wall-clock and frames/sec").
 Synthetic weights and inputs of the named shape (no text encoder: its output is an input here, as in bench.py).  One JSON line.
-    python tools/e2e.py [--workload wan14b_720px81f] [--steps 50] [--fp8|--mxfp8] [--distill] [--teacache T]"""
+    python tools/e2e.py [--workload wan14b_720px81f] [--steps 50] [--fp8|--mxfp8] [--distill] [--teacache T]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/e2e.py --gpus N ...
+        (N GPUs of one node: Ulysses sequence parallel denoise loop over RCCL + the halo-split `decode_dist` VAE decode)"""
 import argparse
 import json
 import os
@@ -24,8 +26,19 @@ def main():
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule, no CFG (BASELINE config #4)")
     ap.add_argument("--vae16", action="store_true", help="opt-in fast VAE decode: fp16 convolution operands (the reference decodes in fp32)")
     ap.add_argument("--teacache", type=float, default=0.0, help="TeaCache threshold (0 = off); uses the released 14B 720p coefficients")
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
-    lib.init(0)
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib.init(local_rank)
     wl = synth.WORKLOADS[a.workload]
     dims = synth.WAN_DIMS[wl["model"]]
     steps = 4 if a.distill else a.steps
@@ -41,6 +54,10 @@ def main():
         extra.update(feature_caching="Tea", teacache_thresh=a.teacache, use_ret_steps=False,
                      coefficients=[[8.10705460e03, 2.13393892e03, -3.72934672e02, 1.66203073e01, -4.17769401e-02],
                                    [-114.36346466, 65.26524496, -18.82220707, 4.91518089, -0.23412683]])
+    if world > 1:
+        if dims["num_heads"] % world:
+            raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
+        extra["parallel_attn_type"] = "ulysses"
     cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=steps, **extra)
     model = wan.WanModel(cfg, synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda"))
     lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
@@ -48,7 +65,7 @@ def main():
     sch.prepare(latents=lat)
     model.set_scheduler(sch)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
-    decoder = vae.WanVAE(synth.synth_wan_vae_weights(dim=96, seed=0), dim=96, conv16=a.vae16)
+    decoder = vae.WanVAE(synth.synth_wan_vae_weights(dim=96, seed=0), dim=96, conv16=a.vae16, parallel=world > 1)
     # warm-up outside the clock: one step on a scratch scheduler state (allocator pools, lazy tables) and a short decode
     sch.step_pre(0)
     model.infer(inputs)
@@ -57,17 +74,24 @@ def main():
     sch.prepare(latents=lat)
     if a.teacache > 0:
         model.transformer_infer.cnt = 0
-    torch.cuda.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
     t0 = time.perf_counter()
     scheduler.run_denoise_loop(model, sch, inputs)
-    torch.cuda.synchronize()
+    fence()
     t1 = time.perf_counter()
     video = decoder.decode(sch.latents.float())
-    torch.cuda.synchronize()
+    fence()
     t2 = time.perf_counter()
     assert torch.isfinite(video).all() and torch.isfinite(sch.latents).all()
     frames = wl["frames"]
-    rec = {"workload": a.workload, "steps": steps, "cfg": bool(cfg["enable_cfg"]), "gemm_dtype": "mxfp8" if a.mxfp8 else "fp8" if a.fp8 else "bf16",
+    rec = {"workload": a.workload, "n_gpus": world, "parallelism": f"ulysses-sp{world} + decode_dist" if world > 1 else "single", "steps": steps, "cfg": bool(cfg["enable_cfg"]), "gemm_dtype": "mxfp8" if a.mxfp8 else "fp8" if a.fp8 else "bf16",
            "teacache_thresh": a.teacache, "vae_conv_operands": "fp16" if a.vae16 else "fp32", "denoise_s": t1 - t0, "ms_per_step": (t1 - t0) * 1e3 / steps, "vae_decode_s": t2 - t1, "total_s": t2 - t0,
            "frames": frames, "video_shape": list(video.shape), "fps_denoise_only": frames / (t1 - t0), "fps_with_vae": frames / (t2 - t0),
            "hbm_gb_peak": torch.cuda.max_memory_allocated() / 1e9, "data": "synthetic weights / latents / text embeddings"}
@@ -75,7 +99,11 @@ def main():
         rec_c, rec_u = list(getattr(sch, "caching_records", [])), list(getattr(sch, "caching_records_2", []))
         rec["teacache_forwards_computed"] = int(sum(bool(v) for v in rec_c + rec_u))
         rec["teacache_forwards_total"] = len(rec_c) + len(rec_u)
-    print(json.dumps(rec))
+    if rank == 0:
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
