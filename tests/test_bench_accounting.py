@@ -38,3 +38,15 @@ def test_step_flops_match_survey_table(bench):
 def test_roofline_peak_is_the_dense_bf16_figure(bench):
     # /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters": 2.5 PFLOP/s dense bf16 (the 5 PFLOP/s headline includes 2:1 sparsity)
     assert bench.BF16_MFMA_PEAK_TFLOPS == 2500.0
+
+
+@pytest.mark.parametrize("script", ["bench.py", "tools/e2e.py", "tools/hunyuan_bench.py"])
+def test_multi_gpu_launch_contract(script):
+    """`--gpus N` must match the launcher's WORLD_SIZE (one process per GPU under torch.distributed.run); a mismatch stops before
+    any device work with a message that says how to launch."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "torch.distributed.run --nproc-per-node" in (p.stderr + p.stdout)
