@@ -9,9 +9,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_ulysses_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ulysses_gloo(world):
+    """world 3: a non-power-of-two group — 6 heads, S = 96 + 1 padded to 99, and a Hunyuan token grid whose h axis (4) does not
+    divide, so the split falls to the w axis."""
     env = dict(os.environ, OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29531 + world),
            os.path.join(ROOT, "tests", "_dist_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
