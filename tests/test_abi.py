@@ -29,6 +29,30 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in lib.version()
 
 
+def test_ctypes_table_matches_header_signatures():
+    """Every PROTOTYPES entry has the header's parameter count and kinds (pointer / 64-bit int / int / float): a drift between
+    include/x2v.h and the ctypes binding would pass garbage to a kernel instead of raising."""
+    from lightx2v_amd import lib
+
+    src = open(os.path.join(ROOT, "include", "x2v.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = dict(re.findall(r"\b(x2v_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src))
+    assert sorted(decls) == sorted(lib.PROTOTYPES)
+
+    def kind(param):
+        param = param.strip()
+        if "*" in param:
+            return "ptr"
+        base = param.rsplit(" ", 1)[0].replace("const", "").strip()
+        return {"int64_t": "i64", "int": "i32", "float": "f32"}[base]
+
+    ctypes_kind = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int: "i32", ctypes.c_float: "f32"}
+    for name, params in decls.items():
+        want = [] if params.strip() in ("", "void") else [kind(p) for p in params.split(",")]
+        got = [ctypes_kind.get(t, "ptr") for t in lib.PROTOTYPES[name]]  # POINTER(c_int) etc. are pointers
+        assert got == want, f"{name}: header {want} vs ctypes {got}"
+
+
 def test_argument_validation_needs_no_gpu():
     """Shape/alignment/null checks run before any HIP call, so the error convention is testable on CPU."""
     from lightx2v_amd import lib
