@@ -257,3 +257,27 @@ def test_wan_oracle_bit_exact_against_live_reference_on_other_shapes(case):
         mine = O.wan_model_infer(wd, dims, sch.latents, sch.timesteps[i], ctx, ctx_null, 6.0)
         assert torch.equal(mine, sch.noise_pred), f"step {i}"
         sch.step_post()
+
+
+@pytest.mark.parametrize("dim,seed,zshape", [(16, 3, (16, 1, 6, 10)), (32, 5, (16, 4, 4, 4)), (48, 6, (16, 2, 10, 6))])
+def test_wan_vae_oracle_bit_exact_against_live_reference_on_other_shapes(dim, seed, zshape):
+    """Where /root/reference exists: the reference's WanVAE_.decode side by side with the oracle at other channel widths and latent
+    shapes (a single latent frame — no temporal cache reuse —, four frames, non-square grids)."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    ref_import.patch_and_import()
+    from lightx2v.models.video_encoders.hf.wan.vae import WanVAE_
+
+    from oracle import wan_vae_oracle as V
+
+    sd = synth.synth_wan_vae_weights(dim=dim, seed=seed)
+    m = WanVAE_(dim=dim, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[], temperal_downsample=[False, True, True], dropout=0.0).eval()
+    m.load_state_dict(sd, strict=False)
+    z = torch.randn(*zshape, generator=torch.Generator().manual_seed(seed))
+    mean, inv_std = torch.tensor(synth.WAN_VAE_MEAN), 1.0 / torch.tensor(synth.WAN_VAE_STD)
+    with torch.no_grad():
+        raw = m.decode(z.unsqueeze(0), [mean, inv_std])[0]
+        mine = V.wan_vae_decode(sd, z, mean, inv_std, dim=dim, clamp=False)
+    assert torch.equal(raw.reshape(mine.shape), mine)
