@@ -325,6 +325,14 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
     """HunyuanVideo DiT fixtures from the reference's own infer objects at a reduced width (hidden 256, 2 heads of
     128, 2 double + 3 single blocks): scheduler tables, pre-infer outputs, one double block, one single block, the
     full forward.  Text mask all ones (then the `torch_sdpa` op's dense attention equals the flash varlen call)."""
+    out = run_reference_hunyuan(synth.HUNYUAN_DIMS[name], synth.HUNYUAN_WORKLOADS[name]["target_shape"], seed)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "hunyuan_tiny.safetensors"))
+    print("hunyuan_tiny.safetensors:", len(out), "tensors; noise_pred", tuple(out["noise_pred"].shape), out["noise_pred"].dtype)
+
+
+def run_reference_hunyuan(dims, ts, seed):
+    """The reference run behind gen_hunyuan for any (dims, latent target_shape, seed): returns the tensor dict (also used live by
+    tests/test_oracle_golden.py on shapes the committed fixture does not hold)."""
     ref_import.patch_and_import()
     from easydict import EasyDict
     from lightx2v.common.modules.weight_module import WeightModule, WeightModuleList
@@ -336,8 +344,6 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
     from lightx2v.models.networks.hunyuan.weights.transformer_weights import HunyuanTransformerDoubleBlock, HunyuanTransformerSingleBlock, HunyuanTransformerWeights
     from lightx2v.models.schedulers.hunyuan import scheduler as ref_sched
 
-    dims = synth.HUNYUAN_DIMS[name]
-    ts = synth.HUNYUAN_WORKLOADS[name]["target_shape"]
     wd = synth.synth_hunyuan_weights(dims, seed=seed)
     lat, text_states, text_mask, text_states_2 = synth.synth_hunyuan_inputs(dims, ts)
     cfg = EasyDict(task="t2v", do_mm_calib=False, mm_config={}, attention_type="torch_sdpa", cpu_offload=False, feature_caching="NoCaching")
@@ -395,8 +401,7 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
         out.update(noise_pred=post.infer(post_w, img_o, vec_o).clone())
     out["weights_checksum"] = weights_checksum(wd)
     out["seed"] = torch.tensor([seed])
-    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "hunyuan_tiny.safetensors"))
-    print("hunyuan_tiny.safetensors:", len(out), "tensors; noise_pred", tuple(out["noise_pred"].shape), out["noise_pred"].dtype)
+    return out
 
 
 def gen_hunyuan_vae(seed=1):

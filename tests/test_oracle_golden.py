@@ -281,3 +281,28 @@ def test_wan_vae_oracle_bit_exact_against_live_reference_on_other_shapes(dim, se
         raw = m.decode(z.unsqueeze(0), [mean, inv_std])[0]
         mine = V.wan_vae_decode(sd, z, mean, inv_std, dim=dim, clamp=False)
     assert torch.equal(raw.reshape(mine.shape), mine)
+
+
+@pytest.mark.parametrize("ts,seed,over", [((1, 16, 1, 12, 8), 9, dict(text_len=8)), ((1, 16, 5, 4, 20), 10, dict(double_blocks=1, single_blocks=2, mlp=768))])
+def test_hunyuan_oracle_bit_exact_against_live_reference_on_other_shapes(ts, seed, over):
+    """Where /root/reference exists: the reference's Hunyuan pre / double / single / post infer objects run live
+    (gen_golden.run_reference_hunyuan) on another latent grid, text length and block plan than the committed fixture's."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    from oracle import gen_golden as G
+    from oracle import hunyuan_oracle as H
+
+    dims = dict(synth.HUNYUAN_DIMS["hunyuan-tiny"], **over)
+    g = G.run_reference_hunyuan(dims, ts, seed)
+    wd = synth.synth_hunyuan_weights(dims, seed=seed)
+    fc, fs = H.rope_tables([ts[2], ts[3] // 2, ts[4] // 2])
+    assert torch.equal(fc, g["freqs_cos"]) and torch.equal(fs, g["freqs_sin"])
+    with torch.no_grad():
+        img, txt, vec, cu, ml = H.pre_infer(wd, dims, g["latents"].to(torch.bfloat16), g["t"][0], g["guidance"], g["text_states"], g["text_mask"], g["text_states_2"])
+        assert torch.equal(img, g["pre_img"]) and torch.equal(txt, g["pre_txt"]) and torch.equal(vec, g["pre_vec"])
+        i1, t1 = H.double_block(wd, 0, img, txt, vec, (fc, fs), dims["heads"], cu)
+        assert torch.equal(i1, g["d0_img"]) and torch.equal(t1, g["d0_txt"])
+        noise = H.forward(wd, dims, g["latents"].to(torch.bfloat16), g["t"][0], g["guidance"], g["text_states"], g["text_mask"], g["text_states_2"], (fc, fs))
+        assert torch.equal(noise, g["noise_pred"])
