@@ -306,3 +306,35 @@ def test_hunyuan_oracle_bit_exact_against_live_reference_on_other_shapes(ts, see
         assert torch.equal(i1, g["d0_img"]) and torch.equal(t1, g["d0_txt"])
         noise = H.forward(wd, dims, g["latents"].to(torch.bfloat16), g["t"][0], g["guidance"], g["text_states"], g["text_mask"], g["text_states_2"], (fc, fs))
         assert torch.equal(noise, g["noise_pred"])
+
+
+@pytest.mark.parametrize("seed,shape", [(2, (1, 16, 2, 11, 9)), (3, (1, 16, 5, 7, 13)), (4, (1, 16, 9, 8, 8))])
+def test_hunyuan_vae_oracle_bit_exact_against_live_reference_on_other_shapes(seed, shape):
+    """Where /root/reference exists: the reference's AutoencoderKLCausal3D (tiling enabled, as VideoEncoderKLCausal3DModel.decode runs
+    it) side by side with the oracle on latent shapes with ragged spatial tiles, spatial-only tiling and temporal tiling of a grid
+    that fits one spatial tile."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    ref_import.patch_and_import()
+    from lightx2v.models.video_encoders.hf.autoencoder_kl_causal_3d.autoencoder_kl_causal_3d import AutoencoderKLCausal3D
+
+    from oracle import hunyuan_vae_oracle as V
+
+    cfg = synth.HUNYUAN_VAE_TINY_CFG
+    vae = AutoencoderKLCausal3D(
+        in_channels=3, out_channels=3, down_block_types=("DownEncoderBlockCausal3D",) * 4, up_block_types=("UpDecoderBlockCausal3D",) * 4,
+        block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"], latent_channels=cfg["latent_channels"],
+        norm_num_groups=cfg["norm_num_groups"], sample_size=cfg["sample_size"], sample_tsize=cfg["sample_tsize"], scaling_factor=cfg["scaling_factor"],
+        time_compression_ratio=cfg["time_compression_ratio"], spatial_compression_ratio=cfg["spatial_compression_ratio"], mid_block_add_attention=True,
+    )
+    sd = synth.synth_hunyuan_vae_weights(cfg, seed=seed)
+    vae.load_state_dict(sd, strict=False)
+    vae.requires_grad_(False)
+    vae.eval()
+    vae.enable_tiling()
+    z = torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * 0.5
+    with torch.no_grad():
+        ref = (vae.decode(z / vae.config.scaling_factor, return_dict=False, generator=None)[0] / 2 + 0.5).clamp(0, 1).float()
+        assert torch.equal(V.vae_decode(sd, z, cfg), ref)
