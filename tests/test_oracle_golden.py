@@ -338,3 +338,36 @@ def test_hunyuan_vae_oracle_bit_exact_against_live_reference_on_other_shapes(see
     with torch.no_grad():
         ref = (vae.decode(z / vae.config.scaling_factor, return_dict=False, generator=None)[0] / 2 + 0.5).clamp(0, 1).float()
         assert torch.equal(V.vae_decode(sd, z, cfg), ref)
+
+
+def test_fp8_oracle_bit_exact_against_live_reference_class_on_random_shapes():
+    """Where /root/reference exists: the reference's MMWeightWfp8channelAfp8channeldynamicVllm (auto-quantised load + apply, over the
+    restated vLLM stubs) side by side with the oracle's w8a8 functions on random shapes and magnitudes, with and without bias, with
+    all-zero tokens and out channels."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    ref_import.patch_and_import()
+    from lightx2v.utils.registry_factory import MM_WEIGHT_REGISTER
+
+    cls = MM_WEIGHT_REGISTER["W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Vllm"]
+    g = torch.Generator().manual_seed(1)
+    for trial in range(12):
+        M, K, N = (int(torch.randint(1, 9, (1,), generator=g)) * m for m in (7, 32, 16))
+        mag = 10.0 ** float(torch.randint(-3, 3, (1,), generator=g))
+        x = (torch.randn(M, K, generator=g) * mag).to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) / K**0.5).to(torch.bfloat16)
+        b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+        if trial % 3 == 0:
+            x[0] = 0
+            w[-1] = 0
+        use_bias = trial % 4 != 1
+        op = cls("w.weight", "w.bias" if use_bias else None)
+        op.set_config({"weight_auto_quant": True})
+        op.load({"w.weight": w.clone(), "w.bias": b.clone()})
+        wq, sw = O.quant_fp8_weight_per_channel(w)
+        assert torch.equal(op.apply(x.clone()), O.mm_fp8(x, wq, sw, b if use_bias else None)), (trial, M, K, N)
+        xq, sx = op.act_quant_func(x.clone())
+        mq, ms = O.quant_fp8_per_token(x)
+        assert torch.equal(xq.view(torch.uint8), mq.view(torch.uint8)) and torch.equal(sx.reshape(-1), ms.reshape(-1))
