@@ -371,3 +371,47 @@ def test_fp8_oracle_bit_exact_against_live_reference_class_on_random_shapes():
         xq, sx = op.act_quant_func(x.clone())
         mq, ms = O.quant_fp8_per_token(x)
         assert torch.equal(xq.view(torch.uint8), mq.view(torch.uint8)) and torch.equal(sx.reshape(-1), ms.reshape(-1))
+
+
+@pytest.mark.parametrize("steps,thresh,use_ret", [(12, 4.0, True), (12, 8.0, False)])
+def test_teacache_oracle_bit_exact_against_live_reference(steps, thresh, use_ret):
+    """Where /root/reference exists: the reference's WanTransformerInferTeaCaching driving a CFG loop on another latent grid, weight
+    seed, step count and threshold than the committed fixture — same calc/skip decisions for both branches, same latents each step."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    ref_import.patch_and_import()
+    from lightx2v.models.networks.wan.infer.feature_caching.transformer_infer import WanTransformerInferTeaCaching
+    from lightx2v.models.schedulers.wan.scheduler import WanScheduler as RefScheduler
+
+    from oracle import gen_golden as G
+
+    dims, ts = synth.WAN_DIMS["wan-tiny"], (16, 2, 8, 12)
+    wd = synth.synth_wan_weights(dims, seed=5)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    cfg = ref_import.make_config(dims, target_shape=ts, target_video_length=5, infer_steps=steps, feature_caching="Tea", coefficients=G.TEA_TEST_COEFFS,
+                                 use_ret_steps=use_ret, teacache_thresh=thresh)
+    R = ref_import.build_reference_wan(cfg, wd)
+    R["tr"] = WanTransformerInferTeaCaching(cfg)
+    sch = RefScheduler(cfg)
+    sch.device = torch.device("cpu")
+    sch.prepare()
+    sch.latents = lat.clone()
+    sch.caching_records = [True] * steps
+    for m in ("pre", "post", "tr"):
+        R[m].set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": ctx, "context_null": ctx_null}}
+    ref_lat = []
+    for i in range(steps):
+        sch.step_pre(i)
+        G._ref_model_infer(R, sch, cfg, inputs)
+        sch.step_post()
+        ref_lat.append(sch.latents.clone())
+    tea = O.TeaCacheOracle(steps, thresh, G.TEA_TEST_COEFFS, use_ret)
+    mine = []
+    O.denoise_loop(wd, dims, lat, ctx, ctx_null, steps, 8.0, 6.0, True, tea, step_callback=lambda i, latents: mine.append(latents.clone()))
+    assert [bool(c) for c in tea.records[True]] == [bool(c) for c in sch.caching_records]
+    assert [bool(c) for c in tea.records[False]] == [bool(c) for c in sch.caching_records_2]
+    assert 0 < sum(bool(c) for c in sch.caching_records) < steps  # both the compute and the skip path ran
+    assert len(mine) == steps and all(torch.equal(a, b) for a, b in zip(mine, ref_lat))
