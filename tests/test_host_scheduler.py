@@ -125,3 +125,41 @@ def test_unipc_bit_exact_against_live_reference_at_edge_step_counts(steps, shift
             s.noise_pred = torch.sin(s.latents.float() * 1.3 + 0.1 * i) + 0.05 * i
             s.step_post()
         assert torch.equal(ours.latents, ref.latents), f"step {i}"
+
+
+@pytest.mark.parametrize("steps,grid", [(4, (3, 8, 12)), (50, (33, 90, 160)), (7, (1, 6, 10))])
+def test_hunyuan_scheduler_against_live_reference_functions(steps, grid):
+    """Where /root/reference exists: the flow-match tables (set_timesteps_sigmas, shift 7), the (T, H/2, W/2) RoPE tables
+    (get_nd_rotary_pos_embed, dims [16, 56, 56], theta 256, bf16) and the t2v Euler update of the reference's HunyuanScheduler.step_post
+    (schedulers/hunyuan/scheduler.py:237-260), called unbound on a stand-in object since its constructor needs a CUDA generator."""
+    from types import SimpleNamespace
+
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    ref_import.patch_and_import()
+    from lightx2v.models.schedulers.hunyuan import scheduler as ref_sched
+
+    from lightx2v_amd import hunyuan as hy
+
+    t, h, w = grid
+    ours = hy.HunyuanScheduler({"infer_steps": steps}, device="cpu")
+    tt, ss = ref_sched.set_timesteps_sigmas(steps, 7.0, device=torch.device("cpu"))
+    assert torch.equal(ours.timesteps, tt) and torch.equal(ours.sigmas, ss)
+    small = min(t, 3), min(h, 12), min(w, 16)  # the table is a pure function of the grid: full size for the rope check only
+    lat = torch.randn(1, 16, small[0], small[1], small[2], generator=torch.Generator().manual_seed(steps))
+    ours.prepare(lat)
+    fc, fs = ref_sched.get_nd_rotary_pos_embed([16, 56, 56], [t, h // 2, w // 2], theta=256, use_real=True, theta_rescale_factor=1)
+    c2, s2 = hy.rope_tables([t, h // 2, w // 2])
+    assert torch.equal(c2, fc.to(torch.bfloat16)) and torch.equal(s2, fs.to(torch.bfloat16))
+    assert torch.equal(ours.guidance, torch.tensor([6.0], dtype=torch.bfloat16) * 1000.0)
+    ref = SimpleNamespace(config=SimpleNamespace(task="t2v"), latents=lat.clone(), sigmas=ss, step_index=0, noise_pred=None)
+    for i in range(min(steps, 5)):
+        pred = torch.cos(ours.latents.float() * 0.9 + i).to(torch.bfloat16)
+        ours.step_pre(i)
+        ref.step_index = i
+        ours.noise_pred = ref.noise_pred = pred
+        ours.step_post()
+        ref_sched.HunyuanScheduler.step_post(ref)
+        assert torch.equal(ours.latents, ref.latents) and ours.latents.dtype == ref.latents.dtype, f"step {i}"
