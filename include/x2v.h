@@ -122,6 +122,11 @@ int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
 int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                           int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream);
 
+/* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape: 1 = the
+ * 128x128 kernel, 2 = the 256x256 ping-pong kernel (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it
+ * compared with the oracle is the one the dispatcher takes for a model's shapes. */
+int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8);
+
 /* Dense non-causal attention, head_dim 128: o[Sq, H*128] = softmax(q k^T * scale) v per head —
  * replaces FlashAttn2Weight/FlashAttn3Weight/TorchSDPAWeight.apply (common/ops/attn/attn_weight.py:71-126,
  * 209-239) for one sequence (cu_seqlens = [0, S]).  q/k/v: token stride in elements (ldq/ldk/ldv), head h

@@ -276,6 +276,14 @@ static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t 
   return X2V_OK;
 }
 
+// The shape rule of variant 0 (one place: the dispatcher and x2v_gemm_kernel_choice both ask it): the 256^2 kernel wants at least
+// ~one full round of tiles (256 CUs), a K loop longer than its pipeline, and 32-bit buffer offsets over a 256-row tile.
+static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb) {
+  const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
+  const int64_t tiles256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
+  return (fits256 && tiles256 >= 192 && nk >= 8) ? 2 : 1;
+}
+
 // variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel; bits 8..15 = m-tiles per scheduling
 // group of the 256x256 kernel (0 = default), bits 16.. = its schedule selector (tuning hook)
 template <bool FP8>
@@ -284,14 +292,11 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
   const int kind = variant & 0xff;
   int gm_tiles = variant >> 8;
   const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
-  // the 256^2 kernel wants at least ~one full round of tiles (256 CUs) and a K loop longer than its pipeline
-  const int64_t tiles256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
-  const bool big = tiles256 >= 192 && nk >= 8;
   if (kind == 2 && !fits256) {
     set_error("gemm: leading dimension too large for the 256x256 kernel");
     return X2V_E_SHAPE;
   }
-  if (kind == 2 || (kind == 0 && fits256 && big)) {
+  if (kind == 2 || (kind == 0 && choose_kernel(M, N, nk, ldxb, ldwb) == 2)) {
     return gemm256_dispatch<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
   }
   switch (epilogue) {
@@ -349,4 +354,9 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8_variant(const
 extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                             int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
   return x2v_gemm_fp8_variant(xq, ldx, sx, wq, ldw, sw, bias, y, ldy, M, N, K, epilogue, resid, ldr, gate, 0, stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8) {
+  if (M <= 0 || N <= 0 || K <= 0) return X2V_E_SHAPE;
+  return fp8 ? choose_kernel(M, N, K / 128, ldx, ldw) : choose_kernel(M, N, K / GB_K, ldx * 2, ldw * 2);
 }

@@ -247,9 +247,12 @@ class HunyuanTransformerInfer:
         shift, scale, gate = weights.modulation.apply(vec_silu).chunk(3, dim=-1)
         mod, qkv, cat = ws["mod"], ws["qkv"], ws["cat"]
         lib.layernorm(x, scale=scale, shift=shift, eps=1e-6, out=mod)
-        w1, b1 = weights.linear1.weight, weights.linear1.bias
-        lib.gemm(mod, w1[: 3 * D], b1[: 3 * D], out=qkv)                                        # qkv rows of linear1
-        lib.gemm(mod, w1[3 * D :], b1[3 * D :], epilogue=lib.EPI_GELU_TANH, out=cat[:, D:])      # mlp rows, GELU, into linear2's input
+        # linear1 = [qkv | mlp] rows of one checkpoint tensor, two epilogues: through the operator (bf16 / fp8 / mxfp8 alike), the
+        # activation quantised once when the operator is a quantised one
+        l1 = weights.linear1
+        pre = {"quantized": l1.quantize_input(mod)} if hasattr(l1, "quantize_input") else {}
+        l1.apply(mod, out=qkv, row_slice=slice(0, 3 * D), **pre)                                          # qkv rows of linear1
+        l1.apply(mod, epilogue=lib.EPI_GELU_TANH, out=cat[:, D:], row_slice=slice(3 * D, None), **pre)    # mlp rows, GELU, into linear2's input
         q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
         cos, sin = freqs_cis
         lib.headnorm_rope_(q, k, weights.q_norm.weight, weights.k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
@@ -286,7 +289,7 @@ class HunyuanPreInfer:
         text_states, text_mask, text_states_2 = te["text_encoder_1_text_states"], te["text_encoder_1_attention_mask"], te["text_encoder_2_text_states"]
         dev = x.device
         time_out = self._mlp(weights.time_in_mlp_0, weights.time_in_mlp_2, _t_embed(t, dev))
-        img_out = weights.img_in_proj.apply(x.to(BF16))  # [S, D]
+        img_out = weights.img_in_proj.apply(x.to(BF16)).flatten(2).transpose(1, 2).squeeze(0)  # pre_infer.py:72-75 → [S, D] (views of the GEMM output)
         txt_out = self.infer_text_in(weights, text_states, text_mask, t)
         vec = time_out + self._mlp(weights.vector_in_in_layer, weights.vector_in_out_layer, text_states_2)
         vec = vec + self._mlp(weights.guidance_in_mlp_0, weights.guidance_in_mlp_2, _t_embed(sch.guidance, dev))

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
+    "x2v_gemm_kernel_choice": [_i64, _i32, _i32, _i64, _i64, _i32],
     "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
     "x2v_transpose_heads_bf16": [_c_void_p, _i64, _c_void_p, _i64, _i64, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
@@ -242,6 +243,14 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
         "gemm_bf16",
     )
     return out2
+
+
+def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False):
+    """1 = 128x128 kernel, 2 = 256x256 ping-pong kernel: what variant 0 launches for this shape (x2v_gemm_kernel_choice)."""
+    rc = _lib.x2v_gemm_kernel_choice(M, N, K, K if ldx is None else ldx, K if ldw is None else ldw, int(fp8))
+    if rc < 0:
+        raise X2VError(f"gemm_kernel_choice: bad shape M={M} N={N} K={K}")
+    return rc
 
 
 def transpose_heads(v, num_heads):

@@ -72,8 +72,14 @@ class MMWeightHip(_Movable):
         self.weight = self.lazy_load_file.get_tensor(self.weight_name).to(torch.bfloat16)
         self.bias = self.lazy_load_file.get_tensor(self.bias_name).to(torch.bfloat16) if self.bias_name is not None else None
 
-    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None):
-        return lib.gemm(input_tensor, self.weight, self.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None, row_slice=None):
+        """`row_slice` (a slice over the N output channels) runs the layer on that block of weight rows only — weight, bias (and, in the
+        quantised classes, the per-channel scales) sliced together; used where one checkpoint tensor feeds two consumers with different
+        epilogues (HunyuanVideo's linear1 = [qkv | mlp], hunyuan/infer/transformer_infer.py:329-334)."""
+        w, b = self.weight, self.bias
+        if row_slice is not None:
+            w, b = w[row_slice], (None if b is None else b[row_slice])
+        return lib.gemm(input_tensor, w, b, epilogue=epilogue, resid=resid, gate=gate, out=out)
 
     def state_dict(self, destination=None):
         destination = {} if destination is None else destination
@@ -112,9 +118,23 @@ class MMWeightFp8Hip(_Movable):
             self.weight_scale = weight_dict[self.weight_scale_name].float()
         self.bias = weight_dict[self.bias_name] if self.bias_name is not None else None
 
-    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None):
-        xq, sx = lib.quant_fp8_rowwise(input_tensor)
-        return lib.gemm_fp8(xq, sx, self.weight, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+    def load_from_disk(self):
+        """mm_weight.py:146-165 (lazy-load path of the quantised template): e4m3 weight + fp32 `<name>.weight_scale` from the open file."""
+        self.weight = self.lazy_load_file.get_tensor(self.weight_name).contiguous()
+        self.weight_scale = self.lazy_load_file.get_tensor(self.weight_scale_name).float()
+        self.bias = self.lazy_load_file.get_tensor(self.bias_name).to(torch.bfloat16) if self.bias_name is not None else None
+
+    def quantize_input(self, input_tensor):
+        """Per-token dynamic e4m3 quantisation of an activation (mm_weight.py:236-245): (codes, fp32 scales).  The fused block driver calls
+        it once per LayerNorm output and hands the pair to every projection that consumes that tensor (`apply(..., quantized=)`)."""
+        return lib.quant_fp8_rowwise(input_tensor)
+
+    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None, row_slice=None, quantized=None):
+        xq, sx = self.quantize_input(input_tensor) if quantized is None else quantized
+        w, sw, b = self.weight, self.weight_scale, self.bias
+        if row_slice is not None:
+            w, sw, b = w[row_slice], sw[row_slice], (None if b is None else b[row_slice])
+        return lib.gemm_fp8(xq, sx, w, sw, b, epilogue=epilogue, resid=resid, gate=gate, out=out)
 
     def state_dict(self, destination=None):
         destination = {} if destination is None else destination
@@ -150,9 +170,15 @@ class MMWeightMxfp8Hip(_Movable):
         self.weight, self.weight_scale = lib.quant_mxfp8(w.to(torch.bfloat16).contiguous())
         self.bias = weight_dict[self.bias_name] if self.bias_name is not None else None
 
-    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None):
-        xq, sx = lib.quant_mxfp8(input_tensor)
-        return lib.gemm_mxfp8(xq, sx, self.weight, self.weight_scale, bias=self.bias, epilogue=epilogue, resid=resid, gate=gate, out=out)
+    def quantize_input(self, input_tensor):
+        return lib.quant_mxfp8(input_tensor)
+
+    def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None, row_slice=None, quantized=None):
+        xq, sx = self.quantize_input(input_tensor) if quantized is None else quantized
+        w, sw, b = self.weight, self.weight_scale, self.bias
+        if row_slice is not None:  # scale table [K/128, N, 4]: slice its row axis; the kernel wants it contiguous
+            w, sw, b = w[row_slice], sw[:, row_slice].contiguous(), (None if b is None else b[row_slice])
+        return lib.gemm_mxfp8(xq, sx, w, sw, bias=b, epilogue=epilogue, resid=resid, gate=gate, out=out)
 
     def state_dict(self, destination=None):
         destination = {} if destination is None else destination
@@ -224,10 +250,66 @@ class LNWeightHip(_Movable):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+_CU_CACHE = {}
+
+
+def _segments(cu):
+    """cu_seqlens (int tensor on any device, list, or None) → python list of boundaries.  A device tensor costs one host read; the
+    boundaries are cached per (data_ptr, version, length) because the block loop passes the same tensor to every layer."""
+    if cu is None:
+        return None
+    if not torch.is_tensor(cu):
+        return [int(c) for c in cu]
+    if not cu.is_cuda:
+        return cu.tolist()
+    key = (cu.data_ptr(), cu._version, cu.numel())
+    hit = _CU_CACHE.get(key)
+    if hit is None:
+        if len(_CU_CACHE) > 64:
+            _CU_CACHE.clear()
+        hit = _CU_CACHE[key] = cu.tolist()
+    return hit
+
+
+def hip_flash(q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, model_cls=None, variant=0):
+    """Functional form (reference: lightx2v/attentions/common/flash_attn2.py:8, dispatcher attentions/__init__.py:8-20) with
+    flash_attn_varlen_func's contract (attn_weight.py:76-97): q [total_q, H, d], k/v [total_k, H, d]; segment i attends
+    q[cu_q[i]:cu_q[i+1]] over k/v[cu_kv[i]:cu_kv[i+1]] — one launch per non-empty segment (Wan: one segment; HunyuanVideo builds
+    [0, img + valid text, img + all text], hunyuan/infer/pre_infer.py:50-56).  Returns [max_seqlen_q, H*d] (`.reshape(max_seqlen_q, -1)`
+    of the reference, :95; max_seqlen_q defaults to total_q); query rows that belong to no segment are zero.  Keys past the last
+    boundary (a padded token buffer) are not attended, as with flash-attn."""
+    H, d = q.shape[1], q.shape[2]
+    total_q = q.shape[0]
+    cq, ck = _segments(cu_seqlens_q), _segments(cu_seqlens_kv)
+    if cq is None:
+        cq = [0, total_q]
+    if ck is None:
+        ck = cq if k.shape[0] == total_q else [0, k.shape[0]]
+    if len(cq) != len(ck) or len(cq) < 2:
+        raise lib.X2VError(f"hip_flash: cu_seqlens_q ({len(cq)} entries) and cu_seqlens_kv ({len(ck)}) must describe the same number of sequences")
+    if cq[-1] > total_q or ck[-1] > k.shape[0] or any(b < a for a, b in zip(cq[:-1], cq[1:])) or any(b < a for a, b in zip(ck[:-1], ck[1:])):
+        raise lib.X2VError(f"hip_flash: cu_seqlens {cq} / {ck} do not fit q [{total_q}] / k [{k.shape[0]}] rows")
+    rows = total_q if max_seqlen_q is None else int(max_seqlen_q)
+    if rows * H * d != total_q * H * d:
+        raise lib.X2VError(f"hip_flash: max_seqlen_q={rows} does not reshape a [{total_q}, {H}, {d}] result (the reference's .reshape(max_seqlen_q, -1))")
+    out = torch.empty((total_q, H * d), dtype=q.dtype, device=q.device)
+    if cq[0] > 0:
+        out[: cq[0]].zero_()
+    if cq[-1] < total_q:
+        out[cq[-1] :].zero_()
+    for (qa, qb), (ka, kb) in zip(zip(cq[:-1], cq[1:]), zip(ck[:-1], ck[1:])):
+        if qb == qa:
+            continue
+        if kb == ka:
+            raise lib.X2VError("hip_flash: a sequence with queries but no keys")
+        lib.attention(q[qa:qb], k[ka:kb], v[ka:kb], num_heads=H, head_dim=d, out=out[qa:qb], variant=variant)
+    return out
+
+
 @ATTN_WEIGHT_REGISTER("hip_flash")
 class HipFlashAttnWeight:
-    """reference: common/ops/attn/attn_weight.py:71-126 (flash_attn2/3 keys), :209-239 (torch_sdpa): q,k,v
-    [tokens,H,d] → [max_seqlen_q, H*d].  One sequence (cu_seqlens = [0,S]) as in every Wan call site."""
+    """reference: common/ops/attn/attn_weight.py:71-126 (flash_attn2/3 keys), :209-239 (torch_sdpa): q,k,v [tokens,H,d] →
+    [max_seqlen_q, H*d]; any number of sequences through cu_seqlens (see hip_flash)."""
 
     def __init__(self):
         self.config = {}
@@ -240,9 +322,7 @@ class HipFlashAttnWeight:
             self.config = config
 
     def apply(self, q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, model_cls=None, mask_map=None):
-        if cu_seqlens_q is not None and len(cu_seqlens_q) != 2:
-            raise lib.X2VError("hip_flash: only a single sequence (cu_seqlens of length 2) is supported")
-        return lib.attention(q, k, v, num_heads=q.shape[1], head_dim=q.shape[2])
+        return hip_flash(q, k, v, cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv, model_cls)
 
     def to_cpu(self, non_blocking=False):
         pass
@@ -252,11 +332,6 @@ class HipFlashAttnWeight:
 
     def state_dict(self, destination=None):
         return {} if destination is None else destination
-
-
-def hip_flash(q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, model_cls=None):
-    """Functional twin (reference: lightx2v/attentions/common/flash_attn2.py:8, dispatcher attentions/__init__.py:8-20)."""
-    return lib.attention(q, k, v, num_heads=q.shape[1], head_dim=q.shape[2])
 
 
 # ------------------------------------------------------------------------------------------------ tensors / conv
@@ -286,20 +361,37 @@ class DefaultTensor(_Movable):
 
 @CONV3D_WEIGHT_REGISTER("hip_patch")
 class PatchEmbedConv3dHip(MMWeightHip):
-    """reference: common/ops/conv/conv3d.py:29-75 as used by pre_infer.py:57 — a Conv3d whose kernel equals
-    its stride (1,2,2) is a GEMM over non-overlapping patches: x[S, C*1*2*2] . W[D, C*4]^T + b."""
+    """reference: common/ops/conv/conv3d.py:29-75 as used by pre_infer.py:57 — a Conv3d whose kernel equals its stride (1,2,2) with no
+    padding is a GEMM over non-overlapping patches: x[S, C*1*2*2] . W[D, C*4]^T + b.  `apply` returns the reference's layout
+    [1, D, T, H/2, W/2] as a VIEW of the GEMM's token-major [S, D] result, so the caller's `flatten(2).transpose(1, 2)`
+    (pre_infer.py:59) lands back on the contiguous [1, S, D] tensor without a copy."""
 
     def __init__(self, weight_name, bias_name, stride=(1, 2, 2), padding=0, dilation=1, groups=1):
         super().__init__(weight_name, bias_name)
-        self.stride = tuple(stride)
+        self.stride = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        if padding not in (0, (0, 0, 0)) or dilation not in (1, (1, 1, 1)) or groups != 1:
+            raise lib.X2VError("hip_patch: only the patch-embedding form (no padding, no dilation, groups = 1) is a GEMM")
 
-    def apply(self, input_tensor):
-        # input [1, C, T, H, W] → patches [T*(H/2)*(W/2), C*4] in (c, pt, ph, pw) order = the conv kernel's layout
+    def load(self, weight_dict):
+        w = weight_dict[self.weight_name]
+        if w.dim() == 5 and tuple(w.shape[2:]) != self.stride:
+            raise lib.X2VError(f"hip_patch: kernel {tuple(w.shape[2:])} != stride {self.stride}: not a patch embedding")
+        super().load(weight_dict)
+
+    def apply_tokens(self, input_tensor):
+        """[1, C, T, H, W] → token-major [S, D] (what the fused driver consumes)."""
+        # patches [T*(H/2)*(W/2), C*4] in (c, pt, ph, pw) order = the conv kernel's layout
         _, c, t, h, w = input_tensor.shape
         pt, ph, pw = self.stride
         x = input_tensor.reshape(c, t // pt, pt, h // ph, ph, w // pw, pw).permute(1, 3, 5, 0, 2, 4, 6)
         x = x.reshape((t // pt) * (h // ph) * (w // pw), c * pt * ph * pw).contiguous()
-        return lib.gemm(x, self.weight, self.bias)  # [S, D] token-major (what pre_infer flattens to)
+        return lib.gemm(x, self.weight, self.bias)
+
+    def apply(self, input_tensor):
+        _, _, t, h, w = input_tensor.shape
+        pt, ph, pw = self.stride
+        y = self.apply_tokens(input_tensor)  # [S, D]
+        return y.t().reshape(1, y.shape[1], t // pt, h // ph, w // pw)
 
 
 # the reference's weight classes look norms up under these keys; inside this package they resolve to HIP

@@ -24,6 +24,7 @@ def register_into_reference():
         (rf.ATTN_WEIGHT_REGISTER, "hip_flash", ops.HipFlashAttnWeight),
         (rf.RMS_WEIGHT_REGISTER, "hip", ops.RMSWeightHip),
         (rf.LN_WEIGHT_REGISTER, "hip", ops.LNWeightHip),
+        (rf.CONV3D_WEIGHT_REGISTER, "hip_patch", ops.PatchEmbedConv3dHip),
     ):
         if key not in reg:
             reg.register(cls, key=key)

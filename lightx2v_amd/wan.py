@@ -21,6 +21,18 @@ from . import ops  # noqa: F401  (registers the HIP operator classes)
 from .weight_module import WeightModule, WeightModuleList
 
 
+def _weight_signature(*ops_):
+    """(data_ptr, version) of every tensor the given operator objects hold: changes when a checkpoint is re-loaded into the same
+    objects or a tensor is updated in place."""
+    sig = []
+    for op in ops_:
+        for name in ("weight", "weight_scale", "bias"):
+            t = getattr(op, name, None)
+            if torch.is_tensor(t):
+                sig.append((t.data_ptr(), t._version))
+    return tuple(sig)
+
+
 def _cfg(config, key, default=None):
     try:
         return config[key]
@@ -171,9 +183,9 @@ class WanPreInfer:
         context = inputs["text_encoder_output"]["context" if positive else "context_null"]
         seq_len = sch.seq_len
 
-        x = weights.patch_embedding.apply(latents.unsqueeze(0))  # [S, D]
-        _, _, T, H, W = (1, *latents.shape)
-        grid_sizes = torch.tensor([[T, H // 2, W // 2]], dtype=torch.long)
+        x = weights.patch_embedding.apply(latents.unsqueeze(0))  # [1, D, T, H/2, W/2] (pre_infer.py:57)
+        grid_sizes = torch.tensor([list(x.shape[2:])], dtype=torch.long)
+        x = x.flatten(2).transpose(1, 2).squeeze(0)  # :59 — a view chain back onto the GEMM's contiguous [S, D]
         s = x.shape[0]
         assert s <= seq_len
         if s < seq_len:
@@ -193,12 +205,15 @@ class WanPreInfer:
         """pre_infer.py:86-96: pad the T5 rows to text_len, Linear + GELU-tanh + Linear.  The prompt embeddings do not change during a
         denoise loop, so with `cache_cross_kv` the result is computed once per input tensor list and the SAME output tensor object is
         handed to the block stack on every step — which is what lets the transformer reuse each block's cross-attention K/V.  Cache
-        entries pin their input tensors (so an id cannot be recycled) and check the version counters; at most 4 contexts are kept."""
+        entries pin their input tensors AND the weights object (so an id cannot be recycled) and check the version counters of the
+        inputs and the (data_ptr, version) of the two weight tensors, so a re-loaded or in-place updated checkpoint (the reference's
+        LoRA-switch path re-runs `_init_weights`) is never served stale; at most 4 contexts are kept."""
         key = None
         if self.cache_text_context:
             key = (id(weights),) + tuple(id(u) for u in context)
+            sig = _weight_signature(weights.text_embedding_0, weights.text_embedding_2)
             hit = self._text_cache.get(key)
-            if hit is not None and all(u._version == ver for u, ver in zip(hit[0], hit[1])):
+            if hit is not None and hit[3] is weights and hit[4] == sig and all(u._version == ver for u, ver in zip(hit[0], hit[1])):
                 return hit[2]
         stacked = torch.stack([torch.cat([u, u.new_zeros(self.text_len - u.size(0), u.size(1))]) for u in context]).squeeze(0)
         out = weights.text_embedding_0.apply(stacked, epilogue=lib.EPI_GELU_TANH)
@@ -206,8 +221,11 @@ class WanPreInfer:
         if key is not None:
             if len(self._text_cache) >= 4:
                 self._text_cache.pop(next(iter(self._text_cache)))
-            self._text_cache[key] = (list(context), [u._version for u in context], out)
+            self._text_cache[key] = (list(context), [u._version for u in context], out, weights, sig)
         return out
+
+    def clear_text_cache(self):
+        self._text_cache.clear()
 
 
 class WanTransformerInfer:
@@ -301,9 +319,10 @@ class WanTransformerInfer:
         """k = RMSNorm(W_k context), v = W_v context (transformer_infer.py:419-424).  The text context and the weights do not change
         between denoise steps, so with config `cache_cross_kv` (default on) each block's pair is computed once per context
         tensor OBJECT (WanPreInfer hands the same object over on every step) and reused — the same values the reference recomputes
-        every step (0.8 GB for Wan-14B with CFG).  An entry pins its context tensor (its id cannot be recycled) and checks the version
-        counter; contexts other than the two most recent ones (cond / uncond) are evicted, so a caller that passes fresh tensors
-        every step gets the reference behaviour without growth."""
+        every step (0.8 GB for Wan-14B with CFG).  An entry pins its context tensor and its weights object (their ids cannot be recycled)
+        and checks the context's version counter and the (data_ptr, version) of the k / v / norm_k weight tensors; contexts other than
+        the two most recent ones (cond / uncond) are evicted, so a caller that passes fresh tensors every step gets the reference
+        behaviour without growth.  `WanModel._init_weights` clears the cache as well."""
         if not self.cache_cross_kv:
             k = weights.cross_attn_k.apply(context)
             lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
@@ -313,12 +332,13 @@ class WanTransformerInfer:
             while len(self._cross_kv_cache) >= 2:
                 self._cross_kv_cache.pop(next(iter(self._cross_kv_cache)))
             per_ctx = self._cross_kv_cache[id(context)] = {"ctx": context, "version": context._version, "kv": {}}
+        sig = _weight_signature(weights.cross_attn_k, weights.cross_attn_v, weights.cross_attn_norm_k)
         hit = per_ctx["kv"].get(id(weights))
-        if hit is None:
+        if hit is None or hit[2] is not weights or hit[3] != sig:  # the entry pins its weights object; tensors re-loaded / edited in place: recompute
             k = weights.cross_attn_k.apply(context)
             lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
-            hit = per_ctx["kv"][id(weights)] = (k, weights.cross_attn_v.apply(context))
-        return hit
+            hit = per_ctx["kv"][id(weights)] = (k, weights.cross_attn_v.apply(context), weights, sig)
+        return hit[0], hit[1]
 
     def clear_cross_kv(self):
         self._cross_kv_cache.clear()
@@ -466,6 +486,11 @@ class WanModel:
         self.pre_weight.load(weight_dict)
         self.post_weight.load(weight_dict)
         self.transformer_weights.load(weight_dict)
+        # step-invariant caches are keyed by weight objects: a re-load (the reference's LoRA switch re-runs this method) drops them
+        if getattr(self, "transformer_infer", None) is not None:
+            self.transformer_infer.clear_cross_kv()
+        if getattr(self, "pre_infer", None) is not None:
+            self.pre_infer.clear_text_cache()
 
     def _init_infer(self):
         self.pre_infer = self.pre_infer_class(self.config)

@@ -46,6 +46,11 @@ class WeightModule:
             if hasattr(child, "load"):
                 child.load(weight_dict)
 
+    def load_from_disk(self):
+        """reference: weight_module.py:37-45 — the lazy-load path: every child that can re-read its tensors from its open checkpoint
+        file does so (sub-modules first, then parameters)."""
+        self._forward("load_from_disk")
+
     def state_dict(self, destination=None):
         destination = {} if destination is None else destination
         for _, child in self._walk((_PARAM, _MODULE)):

@@ -1,0 +1,257 @@
+"""Parity of the kernels and dimensions that bench.py / the BASELINE configs really execute, against the CPU oracle.
+
+The op-level tests in test_gpu_ops.py use small shapes, which the GEMM dispatcher sends to the 128x128 kernel and where attention
+runs a handful of key tiles.  Here the shapes are chosen so that
+  * `lib.gemm` / `lib.gemm_fp8` take the 256x256 ping-pong kernel BY THEIR OWN DISPATCH (asserted through x2v_gemm_kernel_choice, and by
+    bit-equality with the forced variant 2) — the Wan-14B projections 5120→5120, 5120→13824, 13824→5120, ragged M included,
+    all four epilogues;
+  * the ping-pong attention kernel on pre-transposed V with a pre-scaled q (what the fused block drivers launch) sees >= 8192 keys
+    through strided fused-QKV views, against torch SDPA and exact fp32 attention;
+  * one Wan block runs at 14B dimensions (D 5120, 40 heads, F 13824; configs #3/#4) and one at config #2's sequence length
+    (1.3B, S = 20 280), one HunyuanVideo double + single block at D 3072 / 24 heads (config #5) — each vs the oracle.
+Reference call sites: common/ops/mm/mm_weight.py:81-88, common/ops/attn/attn_weight.py:229-239,
+models/networks/wan/infer/transformer_infer.py:289-508, models/networks/hunyuan/infer/transformer_infer.py:81-384.
+
+Tolerances are those of test_gpu_ops.py / test_gpu_model.py (bf16: 1 ulp = 2^-7 relative):
+GEMM <= 1 ulp + atol on all but <= 2e-3 of the elements; attention at >= 8192 keys: the reference's own acceptance
+allclose(rtol=1e-3, atol=1e-3) (attentions/distributed/ring/tests/test.py:97) for every kernel variant, plus the triangle bound against
+fp32 attention (our error <= 1.5x the reference CPU kernel's own); block outputs relative L2 <= 1e-2.
+"""
+import math
+
+import pytest
+import torch
+
+from tests.util import assert_bf16_close, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lightx2v_amd import lib as L
+
+    L.init()
+    return L
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM, 256x256 kernel
+WAN14B_GEMMS = [(4096, 5120, 5120), (4096, 5120, 13824), (4100, 13824, 5120), (4100, 5120, 5120)]  # (M, K, N); 4100 = ragged M
+
+
+@pytest.mark.parametrize("M,K,N", WAN14B_GEMMS)
+def test_gemm256_bf16_natural_dispatch_vs_oracle(lib, M, K, N):
+    from oracle import wan_oracle as O
+
+    assert lib.gemm_kernel_choice(M, N, K) == 2, "shape must take the 256x256 kernel by the dispatcher's own rule"
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16)
+    b = (torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16)
+    xd, wd_, bd = dev(x), dev(w), dev(b)
+    ref = O.mm(x, w, b)
+    got = lib.gemm(xd, wd_, bd)
+    assert_bf16_close(got, ref, ulps=1, atol=2e-3, bad_frac=1e-3, name="gemm256")
+    assert torch.equal(got, lib.gemm(xd, wd_, bd, variant=2)), "variant 0 did not run the 256x256 kernel"
+    assert_bf16_close(lib.gemm(xd, wd_), O.mm(x, w), ulps=1, atol=2e-3, bad_frac=1e-3, name="gemm256 no bias")
+    # fused epilogues against the reference's separate ops (transformer_infer.py:402,468,488-503; pre_infer.py:74-76)
+    ref_g = torch.nn.functional.gelu(ref, approximate="tanh")
+    assert_bf16_close(lib.gemm(xd, wd_, bd, epilogue=lib.EPI_GELU_TANH), ref_g, ulps=1, atol=2e-3, bad_frac=2e-3, name="gemm256+gelu")
+    assert_bf16_close(lib.gemm(xd, wd_, bd, epilogue=lib.EPI_SILU), torch.nn.functional.silu(ref), ulps=1, atol=2e-3, bad_frac=2e-3, name="gemm256+silu")
+    res = torch.randn(M, N, generator=gen).to(torch.bfloat16)
+    gate = (torch.randn(1, N, generator=gen) * 0.5).to(torch.bfloat16)
+    for g in (gate, None):
+        ref_r = res.clone()
+        ref_r.add_(ref * g.squeeze(0) if g is not None else ref)
+        r = dev(res).clone()
+        out = lib.gemm(xd, wd_, bd, epilogue=lib.EPI_RESIDUAL, resid=r, gate=None if g is None else dev(g))
+        assert out.data_ptr() == r.data_ptr()
+        assert_bf16_close(r, ref_r, ulps=1, atol=6e-3, bad_frac=2e-3, name=f"gemm256+residual(gate={g is not None})")
+    # the two tilings agree to summation-order effects (both compared with the oracle above; this catches a tile-local defect)
+    assert_bf16_close(lib.gemm(xd, wd_, bd, variant=1), got.cpu(), ulps=1, atol=2e-3, bad_frac=1e-3, name="128^2 vs 256^2")
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 5120, 5120), (4100, 5120, 13824), (4096, 13824, 5120)])
+def test_gemm256_fp8_natural_dispatch_vs_oracle(lib, M, K, N):
+    """Per-token x per-channel w8a8 (mm_weight.py:236-245,310-318) on the 256x256 kernel's fp8 mode — the kernel config #4 runs."""
+    from oracle import wan_oracle as O
+
+    assert lib.gemm_kernel_choice(M, N, K, fp8=True) == 2
+    gen = torch.Generator().manual_seed(M + K + N + 8)
+    x = torch.randn(M, K, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16)
+    b = (torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16)
+    wq, sw = O.quant_fp8_weight_per_channel(w)
+    xq_ref, sx_ref = O.quant_fp8_per_token(x)
+    xq, sx = lib.quant_fp8_rowwise(dev(x))
+    assert torch.allclose(sx.cpu(), sx_ref, rtol=1e-6, atol=0)
+    # the GEMM is compared on the ORACLE's codes so that a quantiser tie cannot hide in (or leak into) the GEMM tolerance
+    xq_o, sx_o = dev(xq_ref), dev(sx_ref)
+    ref = O.mm_fp8(x, wq, sw, b)
+    got = lib.gemm_fp8(xq_o, sx_o, dev(wq), dev(sw), dev(b))
+    assert_bf16_close(got, ref, ulps=1, atol=4e-3, bad_frac=2e-3, name="fp8 gemm256")
+    assert torch.equal(got, lib.gemm_fp8(xq_o, sx_o, dev(wq), dev(sw), dev(b), variant=2))
+    ref_g = torch.nn.functional.gelu(ref, approximate="tanh")
+    assert_bf16_close(lib.gemm_fp8(xq_o, sx_o, dev(wq), dev(sw), dev(b), epilogue=lib.EPI_GELU_TANH), ref_g, ulps=1, atol=4e-3, bad_frac=2e-3, name="fp8 gemm256+gelu")
+    res = torch.randn(M, N, generator=gen).to(torch.bfloat16)
+    gate = (torch.randn(1, N, generator=gen) * 0.5).to(torch.bfloat16)
+    ref_r = res.clone()
+    ref_r.add_(ref * gate.squeeze(0))
+    r = dev(res).clone()
+    lib.gemm_fp8(xq_o, sx_o, dev(wq), dev(sw), dev(b), epilogue=lib.EPI_RESIDUAL, resid=r, gate=dev(gate))
+    assert_bf16_close(r, ref_r, ulps=1, atol=8e-3, bad_frac=2e-3, name="fp8 gemm256+gate-residual")
+    mism = (xq.cpu().view(torch.uint8) != xq_ref.view(torch.uint8)).float().mean().item()
+    assert mism <= 1e-3, f"{mism} of e4m3 codes differ"
+
+
+# ------------------------------------------------------------------------------------------------ attention, bench variant
+@pytest.mark.parametrize("Sq,Sk,H", [(1024, 8192, 2), (777, 9001, 3), (2048, 12352, 1)])
+def test_bench_attention_variant_vs_oracle_long_keys(lib, Sq, Sk, H):
+    """ATTN_FAST | ATTN_Q_PRESCALED (ping-pong kernel, V^T operand, q carrying scale*log2e) with >= 128 key tiles, q/k/v as strided views
+    of one fused-QKV buffer — vs torch SDPA (attn_weight.py:229-239) and fp32 attention."""
+    from oracle import wan_oracle as O
+
+    gen = torch.Generator().manual_seed(Sq + Sk + H)
+    S = max(Sq, Sk)
+    qkv = torch.randn(S, 3 * H * 128, generator=gen).to(torch.bfloat16)
+    D = H * 128
+    q, k, v = qkv[:Sq, :D], qkv[:Sk, D : 2 * D], qkv[:Sk, 2 * D :]
+    ref = O.sdpa(q.reshape(Sq, H, 128), k.reshape(Sk, H, 128), v.reshape(Sk, H, 128))
+    f32 = O.attention_fp32(q.reshape(Sq, H, 128), k.reshape(Sk, H, 128), v.reshape(Sk, H, 128))
+    e_ref = (ref.float() - f32).abs().max().item()
+    d = dev(qkv)
+    qd, kd, vd = d[:Sq, :D], d[:Sk, D : 2 * D], d[:Sk, 2 * D :]
+    # what the block driver does: the producer folds scale*log2(e) into q inside q's one rounding (x2v_rmsnorm_rope_scaled_bf16)
+    q_pre = (qd.float() * lib.ATTN_PRESCALE).to(torch.bfloat16)
+    # With >= 8192 keys |o| <~ 0.1, so the bf16 rounding of the output no longer needs its own allowance: the tolerance here is the
+    # reference's own acceptance, allclose(rtol=1e-3, atol=1e-3) (attentions/distributed/ring/tests/test.py:97), for every kernel
+    rtol_ulps, atol = 1e-3 / 0.0078125, 1e-3
+    got = lib.attention(q_pre, kd, vd, H, variant=lib.ATTN_FAST | lib.ATTN_Q_PRESCALED)
+    assert_bf16_close(got, ref, ulps=rtol_ulps, atol=atol, name="ping-pong prescaled vs torch_sdpa")
+    e_ours = (got.float().cpu() - f32).abs().max().item()
+    assert e_ours <= 1.5 * e_ref + 2e-4, (e_ours, e_ref)
+    # the kernel folding the scale itself (one more rounding of q) and the default entry, same inputs
+    got2 = lib.attention(qd, kd, vd, H, variant=lib.ATTN_FAST)
+    assert_bf16_close(got2, ref, ulps=rtol_ulps, atol=atol, name="ping-pong vs torch_sdpa")
+    got0 = lib.attention(qd, kd, vd, H)
+    assert_bf16_close(got0, ref, ulps=rtol_ulps, atol=atol, name="default kernel vs torch_sdpa")
+    assert (got0.float().cpu() - f32).abs().max().item() <= 1.5 * e_ref + 2e-4
+
+
+def test_bench_attention_variant_properties_full_size(lib):
+    """Config #2's sequence length (S = 20 280) on the kernel the model launches: rows of P sum to 1, identical keys give mean(V), a dominant
+    key (the lazy-rescale branch, taken late in the key loop) returns its V row, and a spike in the FIRST tile followed by ordinary keys
+    keeps the result finite and correct (first-tile adoption of the running max)."""
+    S, H = 20280, 2
+    var = lib.ATTN_FAST | lib.ATTN_Q_PRESCALED
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.randn(S, H * 128, generator=gen, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    k = torch.randn(S, H * 128, generator=gen, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    qp = (q.float() * lib.ATTN_PRESCALE).to(torch.bfloat16)
+    ones = torch.ones(S, H * 128, device="cuda", dtype=torch.bfloat16)
+    o = lib.attention(qp, k, ones, H, variant=var)
+    assert (o.float() - 1).abs().max().item() <= 2 ** -7
+    v = torch.randn(S, H * 128, generator=gen, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    o = lib.attention(qp, torch.zeros_like(k), v, H, variant=var)
+    assert (o.float() - v.float().mean(0, keepdim=True)).abs().max().item() <= 2e-3
+    for spike_at in (12345, 3):
+        k2 = k.clone()
+        k2[spike_at] = (q[7].float() * 3).to(torch.bfloat16)
+        o = lib.attention(qp[:64].contiguous(), k2, v, H, variant=var)
+        assert torch.isfinite(o.float()).all()
+        assert (o[7].float() - v[spike_at].float()).abs().max().item() <= 2 ** -6, spike_at
+        other = lib.attention(q[:64].contiguous(), k2, v, H)
+        assert_bf16_close(o, other.cpu(), ulps=0.256, atol=8e-3, name=f"spike at key {spike_at}: ping-pong vs default kernel")
+
+
+# ------------------------------------------------------------------------------------------------ blocks at real widths
+def _one_wan_block(dims, target_shape, frames, wd, lat, ctx, ref_rounding):
+    from lightx2v_amd import scheduler, wan
+
+    cfg = wan.default_config(dims, target_shape=target_shape, target_video_length=frames, infer_steps=4, hip_ref_rounding=ref_rounding)
+    model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    sch.timesteps[1] = 777
+    model.set_scheduler(sch)
+    sch.step_pre(1)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx]}}
+    embed, grid_sizes, (x, embed0, seq_lens, freqs, context) = model.pre_infer.infer(model.pre_weight, inputs, positive=True)
+    return model, grid_sizes, embed, x, embed0, seq_lens, freqs, context
+
+
+@pytest.mark.parametrize("ref_rounding", [False, True])
+def test_wan14b_block_vs_oracle(ref_rounding):
+    """One Wan2.1-14B block (D 5120, 40 heads, F 13824; configs #3/#4) from the ORACLE's pre-infer tensors, so that only the block's own
+    error is measured; both rounding modes.  2560 tokens (token grid 5 x 16 x 32): the dispatcher sends a projection to the 256x256
+    GEMM kernel from ~2400 rows on, so q / k / v / o / ffn_0 / ffn_2 all run on the kernel the bench runs."""
+    from lightx2v_amd import lib, synth
+    from oracle import wan_oracle as O
+
+    dims = dict(synth.WAN_DIMS["wan2.1-14b"], num_layers=1)
+    ts = (16, 5, 32, 64)  # (C, T, H, W) latent → 5 x 16 x 32 = 2560 tokens
+    S = synth.seq_len_of(ts)
+    assert lib.gemm_kernel_choice(S, dims["dim"], dims["dim"]) == 2 and lib.gemm_kernel_choice(S, dims["ffn_dim"], dims["dim"]) == 2
+    wd = synth.synth_wan_weights(dims, seed=11)
+    lat, ctx, _ = synth.synth_inputs(dims, ts)
+    t = torch.tensor(777)
+    embed_o, grid, x_o, embed0_o, _, context_o = O.wan_pre_infer(wd, dims, lat.to(torch.bfloat16), t, ctx)
+    ref = O.wan_block(wd, 0, dims, grid, x_o.clone(), embed0_o, O.rope_freqs_table(128), context_o)
+    model, grid_sizes, embed, x, embed0, seq_lens, freqs, context = _one_wan_block(dims, ts, 17, wd, lat, ctx, ref_rounding)
+    assert_rel(x, x_o, 1e-2, "14B patch embedding")
+    tr = model.transformer_infer
+    out = tr.infer_block(model.transformer_weights.blocks[0], grid_sizes, embed, x_o.cuda().clone(), embed0_o.cuda(), seq_lens, freqs, context_o.cuda())
+    assert_rel(out, ref, 1e-2, f"Wan-14B block (ref_rounding={ref_rounding})")
+
+
+def test_wan13b_block_config2_sequence_vs_oracle():
+    """One Wan2.1-1.3B block at BASELINE config #2's shape: 480p x 49 frames → S = 20 280 tokens (the CPU oracle's attention over
+    20 280^2 x 12 heads takes ~10-30 s on the box's host cores)."""
+    from lightx2v_amd import synth
+    from oracle import wan_oracle as O
+
+    dims = dict(synth.WAN_DIMS["wan2.1-1.3b"], num_layers=1)
+    wl = synth.WORKLOADS["wan1.3b_480px49f"]
+    ts = wl["target_shape"]
+    assert synth.seq_len_of(ts) == 20280
+    wd = synth.synth_wan_weights(dims, seed=12)
+    lat, ctx, _ = synth.synth_inputs(dims, ts)
+    t = torch.tensor(777)
+    embed_o, grid, x_o, embed0_o, _, context_o = O.wan_pre_infer(wd, dims, lat.to(torch.bfloat16), t, ctx)
+    ref = O.wan_block(wd, 0, dims, grid, x_o.clone(), embed0_o, O.rope_freqs_table(128), context_o)
+    model, grid_sizes, embed, x, embed0, seq_lens, freqs, context = _one_wan_block(dims, ts, wl["frames"], wd, lat, ctx, False)
+    tr = model.transformer_infer
+    out = tr.infer_block(model.transformer_weights.blocks[0], grid_sizes, embed, x_o.cuda().clone(), embed0_o.cuda(), seq_lens, freqs, context_o.cuda())
+    assert_rel(out, ref, 1e-2, "Wan-1.3B block at S = 20280")
+
+
+@pytest.mark.parametrize("ref_rounding", [False, True])
+def test_hunyuan13b_width_blocks_vs_oracle(ref_rounding):
+    """HunyuanVideo-13B width (hidden 3072, 24 heads, mlp 12288): one double block + one single block on 2304 image tokens + 256 text
+    tokens (56 of them padding → two attention segments), vs oracle/hunyuan_oracle.py; inputs are seeded tensors at the block
+    boundary (the pre-infer is covered at tiny width by test_gpu_hunyuan.py)."""
+    from lightx2v_amd import hunyuan as hy, synth
+    from oracle import hunyuan_oracle as H
+
+    dims = dict(synth.HUNYUAN_DIMS["hunyuan-13b"], double_blocks=1, single_blocks=1)
+    wd = {k: v for k, v in synth.synth_hunyuan_weights(dims, seed=21).items() if k.startswith(("double_blocks.", "single_blocks."))}
+    grid = (4, 24, 24)  # (T, H/2, W/2) tokens = 2304
+    n_img, n_txt, n_valid = grid[0] * grid[1] * grid[2], dims["text_len"], 200
+    gen = torch.Generator().manual_seed(5)
+    img = torch.randn(n_img, dims["hidden"], generator=gen).to(torch.bfloat16)
+    txt = torch.randn(n_txt, dims["hidden"], generator=gen).to(torch.bfloat16)
+    vec = torch.randn(1, dims["hidden"], generator=gen).to(torch.bfloat16)
+    cos, sin = H.rope_tables(list(grid))
+    cu = torch.tensor([0, n_img + n_valid, n_img + n_txt], dtype=torch.int32)
+    with torch.no_grad():
+        ref, _ = H.transformer_infer(wd, dims, img, txt, vec, cu, (cos, sin))
+    cfg = hy.default_config(dims, infer_steps=4, hip_ref_rounding=ref_rounding)
+    tw = hy.HunyuanTransformerWeights(cfg)
+    tw.load({k: v.cuda() for k, v in wd.items()})
+    tr = hy.HunyuanTransformerInfer(cfg)
+    out, _ = tr.infer(tw, img.cuda(), txt.cuda(), vec.cuda(), cu, n_img + n_txt, (cos.cuda(), sin.cuda()))
+    assert_rel(out, ref, 1e-2, f"Hunyuan-13B-width double+single block (ref_rounding={ref_rounding})")

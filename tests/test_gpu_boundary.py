@@ -1,0 +1,118 @@
+"""The operator objects behave like the reference classes they stand in for, at the points VERDICT r1 found loose:
+multi-sequence attention behind `hip_flash` (attn_weight.py:76-97 with HunyuanVideo's three-entry cu_seqlens,
+hunyuan/infer/pre_infer.py:50-56), the Conv3d layout of the patch embedding (common/ops/conv/conv3d.py:40-50),
+`row_slice` on the MM operators (all three weight formats) and cache invalidation when weights change."""
+import math
+
+import pytest
+import torch
+
+from tests.util import assert_bf16_close, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_flash_multi_segment_matches_varlen_oracle():
+    from lightx2v_amd import ops, registry
+    from oracle import hunyuan_oracle as H
+
+    gen = torch.Generator().manual_seed(1)
+    n_img, n_valid, n_txt, heads = 700, 37, 64, 3
+    total = n_img + n_txt
+    q, k, v = (torch.randn(total, heads, 128, generator=gen).to(torch.bfloat16) for _ in range(3))
+    cu = torch.tensor([0, n_img + n_valid, total], dtype=torch.int32)
+    ref = H.varlen_attention(q, k, v, cu)
+    attn = registry.ATTN_WEIGHT_REGISTER["hip_flash"]()
+    for cu_in in (cu, cu.cuda(), cu.tolist()):
+        got = attn.apply(q.cuda(), k.cuda(), v.cuda(), cu_seqlens_q=cu_in, cu_seqlens_kv=cu_in, max_seqlen_q=total, max_seqlen_kv=total)
+        assert got.shape == (total, heads * 128)
+        assert_bf16_close(got, ref.reshape(total, -1), ulps=0.128, atol=4e-3, name="hip_flash, two segments")
+    # different q / kv boundaries (cross-attention style) and a padded tail of query rows that belong to no sequence
+    cq, ck = [0, 300, 600], [0, 50, 64]
+    kk, vv = k[:64], v[:64]
+    got = ops.hip_flash(q.cuda(), kk.cuda(), vv.cuda(), cq, ck, max_seqlen_q=total)
+    from oracle import wan_oracle as O
+
+    for (qa, qb), (ka, kb) in (((0, 300), (0, 50)), ((300, 600), (50, 64))):
+        assert_bf16_close(got[qa:qb], O.sdpa(q[qa:qb], kk[ka:kb], vv[ka:kb]), ulps=0.128, atol=4e-3, name=f"segment {qa}:{qb}")
+    assert not got[600:].any(), "rows outside every sequence must be zero"
+    from lightx2v_amd.lib import X2VError
+
+    with pytest.raises(X2VError):
+        ops.hip_flash(q.cuda(), k.cuda(), v.cuda(), [0, total + 1], [0, total])
+    with pytest.raises(X2VError):
+        ops.hip_flash(q.cuda(), k.cuda(), v.cuda(), [0, 10, total], [0, total])
+
+
+def test_patch_embedding_returns_the_conv3d_layout():
+    from lightx2v_amd import registry
+
+    gen = torch.Generator().manual_seed(2)
+    D, C, T, Hh, Ww = 256, 16, 3, 8, 12
+    w = (torch.randn(D, C, 1, 2, 2, generator=gen) * 0.1).to(torch.bfloat16)
+    b = torch.randn(D, generator=gen).to(torch.bfloat16)
+    x = torch.randn(1, C, T, Hh, Ww, generator=gen).to(torch.bfloat16)
+    ref = torch.nn.functional.conv3d(x, w, b, stride=(1, 2, 2))
+    op = registry.CONV3D_WEIGHT_REGISTER["hip_patch"]("w", "b", stride=(1, 2, 2))
+    op.load({"w": w.cuda(), "b": b.cuda()})
+    y = op.apply(x.cuda())
+    assert y.shape == ref.shape == (1, D, T, Hh // 2, Ww // 2)
+    assert_bf16_close(y, ref, ulps=1, atol=2e-3, bad_frac=2e-3, name="patch embedding (Conv3d layout)")
+    tok = y.flatten(2).transpose(1, 2)  # the caller's next two ops (pre_infer.py:59)
+    assert tok.is_contiguous() and tok.data_ptr() == y.data_ptr(), "flatten(2).transpose(1,2) must land on the GEMM output without a copy"
+
+
+@pytest.mark.parametrize("mm_type", ["Hip-bf16", "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "W-mxfp8-A-mxfp8-dynamic-Hip"])
+def test_mm_row_slice_equals_sliced_full_apply(mm_type):
+    from lightx2v_amd import lib, registry
+
+    gen = torch.Generator().manual_seed(3)
+    M, K, N = 300, 512, 1024
+    wd = {"w.weight": (torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16).cuda(), "w.bias": torch.randn(N, generator=gen).to(torch.bfloat16).cuda()}
+    x = torch.randn(M, K, generator=gen).to(torch.bfloat16).cuda()
+    op = registry.MM_WEIGHT_REGISTER[mm_type]("w.weight", "w.bias")
+    op.set_config({"weight_auto_quant": True})
+    op.load(wd)
+    full = op.apply(x)
+    for sl in (slice(0, 384), slice(384, None)):
+        part = op.apply(x, row_slice=sl)
+        assert torch.equal(part, full[:, sl]), (mm_type, sl)
+        if hasattr(op, "quantize_input"):
+            assert torch.equal(op.apply(x, row_slice=sl, quantized=op.quantize_input(x)), part)
+    g = op.apply(x, epilogue=lib.EPI_GELU_TANH, row_slice=slice(384, None))
+    assert torch.equal(g, op.apply(x, epilogue=lib.EPI_GELU_TANH)[:, 384:])
+
+
+def test_caches_follow_weight_updates():
+    """the step-invariant caches are keyed by weight objects; an in-place weight edit and a re-load must both be noticed."""
+    from lightx2v_amd import scheduler, synth, wan
+
+    dims, wl = synth.WAN_DIMS["wan-tiny"], synth.WORKLOADS["wan-tiny"]
+    wd = {k: v.cuda() for k, v in synth.synth_wan_weights(dims, seed=0).items()}
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=3)
+    model = wan.WanModel(cfg, wd)
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    model.set_scheduler(sch)
+    sch.step_pre(0)
+    model.infer(inputs)
+    first = sch.noise_pred.clone()
+    model.infer(inputs)
+    assert torch.equal(sch.noise_pred, first)
+    wd["blocks.0.cross_attn.k.weight"].mul_(0.5)  # in place: same object ids, same data_ptr, new version
+    model.infer(inputs)
+    second = sch.noise_pred.clone()
+    assert not torch.equal(second, first), "stale cross-attention K served after an in-place weight update"
+    wd2 = dict(wd)
+    wd2["text_embedding.2.weight"] = wd["text_embedding.2.weight"] * 0.5
+    model._init_weights(wd2)  # the reference's LoRA-switch path
+    assert not model.transformer_infer._cross_kv_cache and not model.pre_infer._text_cache
+    model.infer(inputs)
+    assert not torch.equal(sch.noise_pred, second)
+    fresh = wan.WanModel(cfg, wd2)
+    fresh.set_scheduler(sch)
+    third = sch.noise_pred.clone()
+    fresh.infer(inputs)
+    assert torch.equal(sch.noise_pred, third), "re-loaded model must equal a freshly built one"

@@ -108,3 +108,22 @@ def test_weight_module_tree_walks():
     assert tree.blocks[0].q is replacement
     tree.blocks[0].load(wd)
     assert list(tree.blocks[0].state_dict()) == ["blocks.0.modulation", "blocks.0.q.weight"]
+
+
+def test_load_from_disk_reaches_every_child_that_can():
+    """reference weight_module.py:37-45: the lazy-load path forwards to sub-modules and parameters that implement it."""
+    log = []
+
+    class _Lazy(_Leaf):
+        def load_from_disk(self):
+            self.log.append(("disk", self.name))
+
+    root, inner = WeightModule(), WeightModule()
+    root.config = inner.config = {"mm_config": {}}
+    inner.add_module("a", _Lazy("a", log))
+    inner.register_parameter("p", _Lazy("p", log))
+    inner.add_module("plain", _Leaf("plain", log))  # no load_from_disk: skipped
+    root.add_module("inner", inner)
+    root.add_module("blocks", WeightModuleList([inner]))
+    root.load_from_disk()
+    assert log == [("disk", "a"), ("disk", "p"), ("disk", "a"), ("disk", "p")]
