@@ -203,6 +203,28 @@ int x2v_gemm_mxfp8_variant(const void* a, int64_t lda, const void* sa, const voi
  * float64 then rounded — replaces sinusoidal_embedding_1d (wan/infer/utils.py:161-172).  t: int64 [n]. */
 int x2v_sinusoid_embed_bf16(const int64_t* t, void* y, int n, int dim, void* stream);
 
+/* One denoise step's sampler update on the fp32 latent tensor as a single elementwise kernel — replaces the CFG combine
+ * `noise_pred = uncond + guide * (cond - uncond)` (models/networks/wan/model.py:218) followed by WanScheduler.step_post
+ * (models/schedulers/wan/scheduler.py:322-360: x0 = sample - sigma_i * noise_pred; UniPC-bh2 corrector :224-320 when order_c > 0;
+ * predictor :130-222), solver order <= 2.  Every product / sum / quotient is rounded separately, in the reference's order (the result is
+ * bit-identical to the reference's op sequence on CPU tensors).
+ *   cond, uncond (NULL = no CFG): fp32 [n];  latents: the sample (bf16 if latents_bf16 — the reference's DTYPE=BF16 step_pre — else fp32);
+ *   last_sample, m0, m1: the previous step's corrected sample and the x0 predictions of steps i-1, i-2 (fp32 [n]; NULL where unused);
+ *   outputs (fp32 [n], must not alias the inputs): noise_pred (NULL = not wanted), x0_out (this step's x0 prediction), sample_out (the
+ *   corrected sample = next step's last_sample), latents_out (the predictor's output = next latents);
+ *   coef: HOST array of 12 floats {guide, sigma_i, c_a = sigma_t/sigma_s0, c_b = alpha_t*h_phi_1, c_c = alpha_t*B_h, c_rk = r_1,
+ *   c_rho0 = rhos_c[0], c_rhol = rhos_c[-1], p_a, p_b, p_c, p_rk} (corrector c_*, predictor p_*), each computed as the reference
+ *   computes it; order_c in {0 (no corrector), 1, 2}, order_p in {1, 2}. */
+int x2v_unipc_step_f32(const float* cond, const float* uncond, const void* latents, int latents_bf16, const float* last_sample, const float* m0,
+                       const float* m1, float* noise_pred, float* x0_out, float* sample_out, float* latents_out, const float* coef, int order_c, int order_p,
+                       int64_t n, void* stream);
+
+/* The 4-step-distilled scheduler's update (schedulers/wan/step_distill/scheduler.py:40-56) with the optional CFG combine in front:
+ * x0 = latents - sigma * noise_pred;  noise != NULL (not the last step): x0 = one_minus_next * x0 + sigma_next * noise;
+ * latents_out = x0 in the dtype of `latents` (bf16 if latents_bf16).  latents_out may alias latents. */
+int x2v_distill_step_f32(const float* cond, const float* uncond, float guide, const void* latents, int latents_bf16, const float* noise, float sigma,
+                         float one_minus_next, float sigma_next, float* noise_pred, void* latents_out, int64_t n, void* stream);
+
 /* Causal Conv3d on channels-last fp32 activations — replaces CausalConv3d.forward
  * (models/video_encoders/hf/wan/vae.py:19-44; with kt = 1 also the decoder's Conv2d, vae.py:70-118).
  * Time axis input = [zeros(kt-1-cache_frames) | cache (cache_frames frames) | x (T frames)], output T frames;

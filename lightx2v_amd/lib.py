@@ -49,6 +49,9 @@ PROTOTYPES = {
     "x2v_gemm_mxfp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p],
     "x2v_gemm_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_fp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
+    "x2v_unipc_step_f32": [_c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, ctypes.POINTER(_f32), _i32, _i32, _i64,
+                           _c_void_p],
+    "x2v_distill_step_f32": [_c_void_p, _c_void_p, _f32, _c_void_p, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p, _c_void_p, _i64, _c_void_p],
     "x2v_sinusoid_embed_bf16": [_c_void_p, _c_void_p, _i32, _i32, _c_void_p],
     "x2v_causal_conv3d_f32": [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "x2v_vae_conv_f32": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
@@ -551,3 +554,53 @@ def blend_axis_(a, b, axis, extent):
     init()
     _check(_lib.x2v_blend_axis_f32(_p(a), _p(b), outer, na, nb, inner, na * inner, nb * inner, min(extent, na, nb), _stream()), "blend_axis")
     return b
+
+
+def _f32flat(t, name, n):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+        raise X2VError(f"{name}: expected a contiguous float32 device tensor of {n} elements, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t
+
+
+def _latents(t, name, n):
+    if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+        raise X2VError(f"{name}: expected a contiguous float32 / bfloat16 device tensor of {n} elements")
+    return t
+
+
+def unipc_step(cond, uncond, latents, last_sample, m0, m1, coef, order_c, order_p, want_noise_pred=False):
+    """x2v_unipc_step_f32: (noise_pred | None, x0, corrected sample, next latents) — CFG combine + WanScheduler.step_post in one launch.
+    `coef`: the 12 fp32 coefficients of include/x2v.h as Python floats."""
+    n = cond.numel()
+    _f32flat(cond, "cond", n), _f32flat(uncond, "uncond", n), _latents(latents, "latents", n)
+    _f32flat(last_sample, "last_sample", n), _f32flat(m0, "m0", n), _f32flat(m1, "m1", n)
+    if len(coef) != 12:
+        raise X2VError("unipc_step: coef must hold 12 values")
+    new = lambda: torch.empty(cond.shape, dtype=torch.float32, device=cond.device)  # noqa: E731
+    noise_pred = new() if want_noise_pred else None
+    x0, sample, lat = new(), new(), new()
+    init()
+    carr = (_f32 * 12)(*[float(c) for c in coef])
+    _check(
+        _lib.x2v_unipc_step_f32(_p(cond), _p(uncond), _p(latents), int(latents.dtype == torch.bfloat16), _p(last_sample), _p(m0), _p(m1), _p(noise_pred), _p(x0), _p(sample),
+                                _p(lat), carr, order_c, order_p, n, _stream()),
+        "unipc_step",
+    )
+    return noise_pred, x0, sample, lat
+
+
+def distill_step(cond, uncond, guide, latents, noise, sigma, one_minus_next, sigma_next, want_noise_pred=False):
+    """x2v_distill_step_f32: (noise_pred | None, next latents in the dtype of `latents`)."""
+    n = cond.numel()
+    _f32flat(cond, "cond", n), _f32flat(uncond, "uncond", n), _latents(latents, "latents", n), _f32flat(noise, "noise", n)
+    noise_pred = torch.empty(cond.shape, dtype=torch.float32, device=cond.device) if want_noise_pred else None
+    out = torch.empty(cond.shape, dtype=latents.dtype, device=cond.device)
+    init()
+    _check(
+        _lib.x2v_distill_step_f32(_p(cond), _p(uncond), float(guide), _p(latents), int(latents.dtype == torch.bfloat16), _p(noise), float(sigma), float(one_minus_next),
+                                  float(sigma_next), _p(noise_pred), _p(out), n, _stream()),
+        "distill_step",
+    )
+    return noise_pred, out

@@ -3,10 +3,12 @@ wan/scheduler.py:9-360, wan/step_distill/scheduler.py:8-56).  Same public surfac
 `step_pre(i)`, `step_post()`, `.latents`, `.timesteps`, `.sigmas`, `.noise_pred`, `clear()` — so the
 reference's runner loop (default_runner.py:97-114) drives them unchanged.
 
-The step is a handful of fp32 elementwise updates on the latent tensor (19 MB at 720p): microseconds
-next to the DiT forward, so it stays torch on the device (SURVEY.md §2.1 #5 marks it "not a kernel target";
-a fused step_post kernel is listed under §8f "next").  Scalar coefficients are fp32 0-dim tensors and are
-combined in the same order as the reference so the CPU run is bit-identical to it.
+Two forms of `step_post`, bit-identical to each other and to the reference's CPU result:
+  * latents on a HIP device: ONE launch of x2v_unipc_step_f32 / x2v_distill_step_f32 (csrc/sched.hip) that also does the
+    CFG combine when the model handed over the two branches (`set_cfg_parts`) — ~25 torch launches and their temporaries become one
+    pass over the 19 MB latent tensor, which matters for the 4-step distilled and the 256x256 configs;
+  * anywhere else (CPU tests, the reference-parity fixtures): the torch op sequence below.
+Scalar coefficients are fp32 0-dim tensors combined in the reference's order in both forms.
 """
 import math
 
@@ -20,8 +22,33 @@ class BaseScheduler:
         self.step_index = 0
         self.latents = None
         self.infer_steps = config["infer_steps"]
-        self.noise_pred = None
+        self._noise_pred = None
+        self._cfg_parts = None  # (cond, uncond, guide): the CFG combine deferred into the fused step_post
         self.bf16_latents = True  # DTYPE=BF16 mode of the reference (utils/envs.py; all shipped scripts)
+        self.fused_step_post = bool(config.get("fused_step_post", True)) if hasattr(config, "get") else True
+
+    # `noise_pred` is what the model writes and step_post reads (scheduler.py:5-21).  A model may instead hand over the two CFG
+    # branches; the combined tensor then only materialises if somebody reads the attribute (same three fp32 ops as wan/model.py:218).
+    @property
+    def noise_pred(self):
+        if self._noise_pred is None and self._cfg_parts is not None:
+            cond, uncond, guide = self._cfg_parts
+            self._noise_pred = uncond + guide * (cond - uncond)
+        return self._noise_pred
+
+    @noise_pred.setter
+    def noise_pred(self, value):
+        self._noise_pred, self._cfg_parts = value, None
+
+    def set_cfg_parts(self, cond, uncond, guide):
+        self._noise_pred, self._cfg_parts = None, (cond, uncond, float(guide))
+
+    def _branches(self):
+        """(cond, uncond | None, guide) as contiguous fp32 tensors for the fused kernels."""
+        if self._cfg_parts is not None and self._noise_pred is None:
+            cond, uncond, guide = self._cfg_parts
+            return cond.to(torch.float32).contiguous(), uncond.to(torch.float32).contiguous(), guide
+        return self.noise_pred.to(torch.float32).contiguous(), None, 0.0
 
     def step_pre(self, step_index):
         self.step_index = step_index
@@ -123,7 +150,60 @@ class WanScheduler(BaseScheduler):
         corr_res = torch.einsum("k,bkc...->bc...", rhos_c[:-1].to(last_sample.device), D1s) if D1s is not None else 0
         return (x_t_ - alpha_t * B_h * (corr_res + rhos_c[-1] * (this_model_output - m0))).to(last_sample.dtype)
 
+    def _scalars(self, idx_t, idx_s0, order, d1_base):
+        """The scalar half of `_coeffs` as Python floats (each an exactly represented fp32): (a, b, c, r_1, R, b_vec)."""
+        sigma_t, sigma_s0 = self.sigmas[idx_t], self.sigmas[idx_s0]
+        lam_s0 = self._lambda(sigma_s0)
+        h = self._lambda(sigma_t) - lam_s0
+        rks = [(self._lambda(self.sigmas[d1_base - i]) - lam_s0) / h for i in range(1, order)]
+        rk1 = rks[0].item() if rks else 1.0
+        rks = torch.tensor(rks + [1.0])
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        alpha_t = 1 - sigma_t
+        return (sigma_t / sigma_s0).item(), (alpha_t * h_phi_1).item(), (alpha_t * B_h).item(), rk1, torch.stack(R), torch.tensor(b)
+
+    def _step_post_fused(self):
+        """CFG combine + x0 prediction + corrector + predictor in one launch (csrc/sched.hip)."""
+        from . import lib
+
+        i = self.step_index
+        cond, uncond, guide = self._branches()
+        use_corrector = i > 0 and (i - 1) not in self.disable_corrector and self.last_sample is not None
+        order_c = self.this_order if use_corrector else 0
+        coef = [guide, self.sigmas[i].item()] + [0.0] * 10
+        if use_corrector:
+            a, b, c, rk, R, bvec = self._scalars(i, i - 1, order_c, i - 1)
+            rhos_c = torch.tensor([0.5], dtype=torch.float32) if order_c == 1 else torch.linalg.solve(R, bvec).to(torch.float32)
+            coef[2:8] = [a, b, c, rk, rhos_c[0].item() if order_c == 2 else 0.0, rhos_c[-1].item()]
+        this_order = min(self.solver_order, len(self.timesteps) - i)
+        order_p = min(this_order, self.lower_order_nums + 1)  # multistep warm-up
+        if order_p > 2 or order_c > 2:
+            raise NotImplementedError("fused step_post: solver order <= 2 (the reference's setting)")
+        a, b, c, rk, _, _ = self._scalars(i + 1, i, order_p, i)
+        coef[8:12] = [a, b, c, rk]
+        m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+        lat = self.latents if self.latents.dtype in (torch.bfloat16, torch.float32) else self.latents.to(torch.float32)
+        _, x0, sample, new_lat = lib.unipc_step(cond, uncond, lat.contiguous(), self.last_sample if use_corrector else None, m0, m1 if (order_c == 2) else None, coef,
+                                                order_c, order_p)
+        self.model_outputs = self.model_outputs[1:] + [x0]
+        self.this_order = order_p
+        self.last_sample = sample
+        self.latents = new_lat
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+
     def step_post(self):
+        if self.fused_step_post and self.latents.is_cuda:
+            return self._step_post_fused()
         model_output = self.noise_pred.to(torch.float32)
         sample = self.latents.to(torch.float32)
         use_corrector = self.step_index > 0 and (self.step_index - 1) not in self.disable_corrector and self.last_sample is not None
@@ -143,7 +223,7 @@ class WanScheduler(BaseScheduler):
         self.lower_order_nums = 0
         self.last_sample = None
         self.this_order = None
-        self.noise_pred = None
+        self.noise_pred = None  # (the setter drops pending CFG branches as well)
 
 
 class WanStepDistillScheduler(WanScheduler):
@@ -166,6 +246,17 @@ class WanStepDistillScheduler(WanScheduler):
         self.sigmas = sig[idx].to("cpu")
 
     def step_post(self):
+        if self.fused_step_post and self.latents.is_cuda and self.latents.dtype in (torch.bfloat16, torch.float32):
+            from . import lib
+
+            cond, uncond, guide = self._branches()
+            sigma = self.sigmas[self.step_index].item()
+            noise, nxt = None, 0.0
+            if self.step_index < self.infer_steps - 1:
+                nxt = self.sigmas[self.step_index + 1].item()
+                noise = self.noise_fn(cond).to(torch.float32).contiguous()
+            _, self.latents = lib.distill_step(cond, uncond, guide, self.latents.contiguous(), noise, sigma, 1 - nxt, nxt)
+            return
         flow_pred = self.noise_pred.to(torch.float32)
         sigma = self.sigmas[self.step_index].item()
         x0 = self.latents.to(torch.float32) - sigma * flow_pred

@@ -519,10 +519,17 @@ class WanModel:
     @torch.no_grad()
     def infer(self, inputs):
         """cond forward, uncond forward, fp32 CFG combine (model.py:197-226)."""
-        self.scheduler.noise_pred = self._forward(inputs, True)
-        if self.config["enable_cfg"]:
-            uncond = self._forward(inputs, False)
-            self.scheduler.noise_pred = uncond + self.config["sample_guide_scale"] * (self.scheduler.noise_pred - uncond)
+        cond = self._forward(inputs, True)
+        if not self.config["enable_cfg"]:
+            self.scheduler.noise_pred = cond
+            return
+        uncond = self._forward(inputs, False)
+        if hasattr(self.scheduler, "set_cfg_parts"):
+            # our schedulers fold `uncond + guide * (cond - uncond)` (:218) into the fused step_post launch; reading
+            # scheduler.noise_pred still yields the combined tensor
+            self.scheduler.set_cfg_parts(cond, uncond, self.config["sample_guide_scale"])
+        else:
+            self.scheduler.noise_pred = uncond + self.config["sample_guide_scale"] * (cond - uncond)
 
 
 def default_config(dims, **overrides):
