@@ -135,14 +135,9 @@ int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, in
 int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                       int64_t Sk, int H, int head_dim, float scale, void* stream);
 
-/* Same, selecting a kernel variant (tuning / validation hook; 0 = the default x2v_attn_fwd_bf16 uses = 6):
- * v1: 1 = 4 waves x 32 queries, 2 = 8 waves x 32 queries, 3 = 4 waves with scalar LDS reads of V instead of the
- * hardware transpose read (cross-checks ds_read_b64_tr_b16 addressing);
- * v2 (software-pipelined, LDS-DMA K, buffer loads): 4 = eager rescale, 5/6 = lazy rescale (threshold 4 / 8 in
- * base-2 units), 7 = 4-wave workgroups;
- * v3 (softmax scale folded into Q, running max as the MFMA C operand): 8 = single tile body, 9 = x2-unrolled loop;
- * v4: 10 (v3 numerics, copy-free single body).  OR-ing X2V_ATTN_Q_PRESCALED into a v3/v4 variant says q already carries
- * scale * log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16), so the kernel skips its own bf16 prescale. */
+/* Same, selecting the lazy-rescale threshold of the online softmax (validation hook for the rare, data-dependent rescale branch: the three
+ * must agree to rounding): 0 = default (= 6), 4 = rescale O on every tile, 5 = when a row max grew by more than 4 (base-2 units), 6 = by
+ * more than 8.  X2V_ATTN_Q_PRESCALED is the flag of x2v_attn_fwd_bf16_vt's `q_prescaled` argument. */
 #define X2V_ATTN_Q_PRESCALED 0x100
 #define X2V_ATTN_LOG2E_SCALE(head_dim_rsqrt) ((head_dim_rsqrt) * 1.4426950408889634f)
 int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
@@ -152,9 +147,10 @@ int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t
  * keys >= Sk zero-filled (ldvt % 64 == 0, ldvt >= Sk): the operand layout of x2v_attn_fwd_bf16_vt. */
 int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt, int64_t Sk, int H, void* stream);
 
-/* x2v_attn_fwd_bf16 on a pre-transposed V (x2v_transpose_heads_bf16): V^T is staged by LDS-DMA and read as plain
- * 16-byte fragments (no transpose reads, a third fewer LDS instructions per MFMA).  v3/v4 numerics (scale folded into q;
- * q_prescaled != 0: q already carries scale*log2(e), see X2V_ATTN_Q_PRESCALED). */
+/* x2v_attn_fwd_bf16 on a pre-transposed V (x2v_transpose_heads_bf16) — the "ping-pong" kernel the fused block drivers launch for
+ * self-attention (transformer_infer.py:369-379): V^T is staged by LDS-DMA and read as plain 16-byte fragments, the softmax scale * log2(e)
+ * lives in q.  q_prescaled bit 0: q already carries scale*log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16 folded it into
+ * q's one rounding), else the kernel multiplies and re-rounds q itself; bits 1..: kernel-body selector for A/B measurements (0 = default). */
 int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                          int H, int head_dim, float scale, int q_prescaled, void* stream);
 

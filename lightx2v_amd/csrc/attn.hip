@@ -1,23 +1,25 @@
 // Dense non-causal attention forward, head_dim 128, bf16 in/out, fp32 online softmax.
 //
-// Bound: MFMA.  Algorithmic work per launch = 4 * Sq * Sk * H * 128 FLOP (QK^T + PV).
+// Bound: MFMA.  Algorithmic work per launch = 4 * Sq * Sk * H * 128 FLOP (QK^T + PV); algorithmic bytes = q, k, v, o once.
 //
-// Structure (v1):
-//   * one workgroup = NW waves x 32 query rows of ONE head; K/V tiles of 64 keys are staged once per
-//     workgroup in LDS (register-staged, issue-early / write-late so HBM latency hides under the MFMAs of
-//     the current tile) and shared by all waves; double buffered, one barrier per tile.
+// Two kernels (earlier generations — the register-staged v1, the x2-unrolled v3, v4, the in-phase v6 and their timing probes — live in
+// git history; DESIGN.md §4.1 keeps their measurements):
+//   * attn_fwd_pipe_kernel ("v2"): the general entry on row-major q/k/v (x2v_attn_fwd_bf16): what cross-attention, the text refiner and
+//     the reference-rounding mode launch.  Per-wave software pipeline, K by LDS-DMA, V^T fragments by ds_read_b64_tr_b16.
+//   * attn_fwd_v8_kernel ("ping-pong"): what the fused block drivers launch for self-attention (x2v_attn_fwd_bf16_vt) on a
+//     pre-transposed V and a q that already carries scale*log2(e).
+// Common structure:
+//   * one workgroup = 8 waves x 32 query rows of ONE head; K/V tiles of 64 keys are staged once per workgroup in LDS and shared
+//     by all waves; double buffered.
 //   * "swapped" QK^T: S^T = K . Q^T with v_mfma_f32_32x32x16_bf16, K fragment as the A operand.  Each lane
 //     then owns ONE query column (lane&31) and 32 of the tile's 64 keys, so the whole online softmax
-//     (max, exp2, row sum, rescale of O) is lane-local; the two half-waves exchange one max per tile.
+//     (max, exp2, row sum, rescale of O) is lane-local; the two half-waves exchange one max per tile (v_permlane32_swap).
 //   * P never leaves registers: the accumulator layout of S^T (per lane: keys {0-3,8-11,..}+4*half) IS a valid
 //     B-operand layout for the PV MFMA as long as the V^T fragment enumerates keys in the same order — the
-//     reduction index of an MFMA may be permuted freely if both operands agree.  V^T fragments come from
-//     row-major V tiles through the gfx950 transpose read ds_read_b64_tr_b16 (two per fragment).
+//     reduction index of an MFMA may be permuted freely if both operands agree.
 //   * O^T accumulates as 4 MFMA tiles of [32 dv][32 queries] per wave (64 accumulator registers).
-//   * LDS images: K [64 keys][256 B] with the 16-byte chunk index XORed by (key & 15) (conflict-free
-//     ds_read_b128 over its 16-lane service groups); V as 8 sub-tiles [64 keys][16 cols] (32-byte rows, so a
-//     16-lane transpose read touches 128 contiguous bytes) with a 2080-byte sub-tile pitch chosen so both
-//     the 16-byte staging writes and the paired (sub-tile T, T+4) transpose reads are conflict-free.
+//   * LDS image of K: [64 keys][256 B] with the 16-byte chunk index XORed by (key & 15) (conflict-free
+//     ds_read_b128 over its 16-lane service groups); the swizzle is applied on the per-lane DMA SOURCE address.
 //   * q-block-fastest grid: co-resident workgroups walk the same head's K/V stream in near lock-step, so
 //     each XCD's L2 serves a K/V tile to its 32 CUs from one fill.
 #include "x2v_common.h"
@@ -27,10 +29,12 @@ namespace x2v {
 constexpr int AT_D = 128;
 constexpr int AT_KV = 64;
 constexpr int AT_K_BYTES = AT_KV * 256;     // 16 KiB
-constexpr int AT_VSUB = 2080;               // bytes per V sub-tile ([64][16] bf16 = 2048 + 32 pad)
+constexpr int AT_VSUB = 2080;               // v2: bytes per V sub-tile ([64][16] bf16 = 2048 + 32 pad: conflict-free 16-byte staging writes
+                                            // AND paired (sub-tile T, T+4) transpose reads)
 constexpr int AT_V_BYTES = 8 * AT_VSUB;     // 16640
 constexpr int AT_BUF_BYTES = AT_K_BYTES + AT_V_BYTES;
 constexpr int AT_LDS_BYTES = 2 * AT_BUF_BYTES;  // 66,048 B
+
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
@@ -56,207 +60,6 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 
 // key index (within a 32-key MFMA tile) held in accumulator register r of half-wave `hi`
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-
-template <int NW, bool SAFE_V>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const unsigned short* __restrict__ Q, int64_t ldq, const unsigned short* __restrict__ Kp,
-                                                              int64_t ldk, const unsigned short* __restrict__ Vp, int64_t ldv,
-                                                              unsigned short* __restrict__ O, int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;           // queries per workgroup
-  constexpr int CPT = (AT_KV * 16) / NT;  // 16-byte chunks per thread per operand tile (4 for NW=4, 2 for NW=8)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int fl = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
-
-  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
-  const unsigned short* Vh = Vp + (int64_t)head * AT_D;
-
-  // ---- Q fragments (B operand): lane (query fl, half hi) holds d = ks*16 + hi*8 .. +8
-  bf16x8_t qf[8];
-  {
-    int64_t qr = q0 + fl;
-    qr = qr < Sq ? qr : Sq - 1;
-    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    // Make the Q loads land HERE: otherwise hipcc keeps their vmcnt waits inside the tile loop, where the
-    // in-order counter also drains the K/V prefetch issued at the top of every iteration (vmcnt(0) mid-QK^T).
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
-  // ---- staging assignment: chunk id = i*NT + tid -> key = id/16, c = id%16.  Staging registers are
-  //      plain named vectors (no arrays captured by reference: hipcc would demote those to scratch).
-  i32x4_t kst[CPT], vst[CPT];
-  int k_wr[CPT], v_wr[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int id = i * NT + tid;
-    const int key = id >> 4, c = id & 15;
-    k_wr[i] = key * 256 + ((c ^ (key & 15)) << 4);
-    v_wr[i] = AT_K_BYTES + (c >> 1) * AT_VSUB + key * 32 + (c & 1) * 16;
-  }
-#define AT_ISSUE_LOADS(T_)                                                         \
-  _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                \
-    const int id = i * NT + tid;                                                   \
-    int64_t key = (int64_t)(T_) * AT_KV + (id >> 4);                               \
-    key = key < Sk ? key : Sk - 1;                                                 \
-    const int c = id & 15;                                                         \
-    kst[i] = *reinterpret_cast<const i32x4_t*>(Kh + key * ldk + c * 8);            \
-    vst[i] = *reinterpret_cast<const i32x4_t*>(Vh + key * ldv + c * 8);            \
-  }
-#define AT_WRITE_STAGE(BUF_)                                                       \
-  {                                                                                \
-    char* b_ = smem + (BUF_) * AT_BUF_BYTES;                                       \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                              \
-      *reinterpret_cast<i32x4_t*>(b_ + k_wr[i]) = kst[i];                          \
-      *reinterpret_cast<i32x4_t*>(b_ + v_wr[i]) = vst[i];                          \
-    }                                                                              \
-  }
-
-  // ---- fragment read offsets
-  int k_rd[2][8];  // K A-operand: key = t*32 + fl, chunk = ks*2 + hi
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int key = t * 32 + fl;
-      k_rd[t][ks] = key * 256 + (((ks * 2 + hi) ^ (key & 15)) << 4);
-    }
-  // V^T A-operand for dv tile T: lanes fl<16 read sub-tile T, fl>=16 read sub-tile T+4; within the 16-lane
-  // group lane L supplies row (L>>2) / column group (L&3) of the [4 keys][16 cols] block.
-  const int L = lane & 15;
-  const int v_rd_base = AT_K_BYTES + ((fl >> 4) * 4) * AT_VSUB + (4 * hi + (L >> 2)) * 32 + (L & 3) * 8;
-
-  f32x16_t oacc[4];
-#pragma unroll
-  for (int T = 0; T < 4; ++T)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
-  AT_ISSUE_LOADS(0)
-  AT_WRITE_STAGE(0)
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const char* kb = smem + (t & 1) * AT_BUF_BYTES;
-    if (t + 1 < nt) {
-      AT_ISSUE_LOADS(t + 1)
-    }
-
-    // ---- S^T = K Q^T : two [32 keys][32 queries] tiles
-    f32x16_t st[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[u][e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + k_rd[u][ks]);
-        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[u], 0, 0, 0);
-      }
-    }
-    // ---- mask keys beyond Sk (last tile only; wave-uniform branch)
-    if ((int64_t)(t + 1) * AT_KV > Sk) {
-      const int left = (int)(Sk - (int64_t)t * AT_KV);  // valid keys in this tile, 1..63
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (u * 32 + acc_row(r, hi) >= left) st[u][r] = -1e30f;
-    }
-    // ---- online softmax (base-2 domain): lane-local over its 32 keys, one exchange across half-waves
-    float mx = st[0][0];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8_t pb[2][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(st[u][r] * scale_log2e - m_new);
-        psum += p[r];
-      }
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pb[u][h2][e] = (__bf16)p[h2 * 8 + e];
-    }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[T][e] *= alpha;
-
-    // ---- O^T += V^T P^T
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        // keys of this k16 step: u*32 + h2*16 + {0-3, 8-11} + 4*hi
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-          bf16x8_t vf;
-          if (!SAFE_V) {
-            const char* p0 = kb + v_rd_base + T * AT_VSUB + (u * 32 + h2 * 16) * 32;
-            vf = tr_frag(p0, p0 + 8 * 32);
-          } else {
-            const int sub = T + (fl >> 4) * 4, col = fl & 15;
-            const unsigned short* vs = reinterpret_cast<const unsigned short*>(kb + AT_K_BYTES + sub * AT_VSUB);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int key = u * 32 + h2 * 16 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-              unsigned short raw = vs[key * 16 + col];
-              vf[e] = __builtin_bit_cast(__bf16, raw);
-            }
-          }
-          oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u][h2], oacc[T], 0, 0, 0);
-        }
-      }
-
-    if (t + 1 < nt) AT_WRITE_STAGE((t + 1) & 1)
-    __syncthreads();
-  }
-
-  // ---- epilogue: O[q][dv] = O^T / l
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int64_t qrow = q0 + fl;
-  if (qrow < Sq) {
-    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i0 = 8 * g + 4 * hi;  // row index within the [32 dv] tile (4 consecutive rows i0..i0+3)
-        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
-        uint2 pk;
-        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
-        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dv) = pk;
-      }
-  }
-}
-
-#undef AT_ISSUE_LOADS
-#undef AT_WRITE_STAGE
-
 // ------------------------------------------------------------------------------------------------
 // v2: software-pipelined variant.  PMC on v1 showed per-wave VALU-active ~= MFMA-busy (1142 vs 1024 cycles per
 // tile) and a per-SIMD tile time equal to their SUM over the two co-resident waves: the waves run the same
@@ -465,822 +268,59 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
     __syncthreads();
   }
   AT_TILE(true, sc, sd, (t + 1) & 1, t & 1)
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + fl;
+  if (qrow < Sq) {
+    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 8 * g + 4 * hi;
+        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
+        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + dv) = pk;
+      }
+  }
+#endif
+}
+
+#undef AT_DMA_K
+#undef AT_LOAD_V
+#undef AT_WRITE_V
+#undef AT_QK
+#undef AT_SB
 #undef AT_TILE
-#undef AT_SB
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int64_t qrow = q0 + fl;
-  if (qrow < Sq) {
-    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i0 = 8 * g + 4 * hi;
-        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
-        uint2 pk;
-        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
-        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dv) = pk;
-      }
-  }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------
-// v3 = v2 with (1) the softmax scale folded into Q and the running max entering each score chain as the MFMA's C
-// operand, so P = exp2(S') with no per-score FMA; (2) the tile loop unrolled x2 with the two score buffers swapping
-// roles, so there is no score copy and every LDS address is base + immediate.  Per score the VALU work drops from
-// {max, fma, exp2, add, 1/2 cvt, 1/2 mov} to {max, exp2, add, 1/2 cvt}.
-template <int NW, int RESCALE_THR, bool UNROLL2, bool PRESCALED>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v3_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
-                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
-                                                                   const unsigned short* __restrict__ Vp, int64_t ldv, unsigned short* __restrict__ O,
-                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
-                                                                   unsigned v_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int CPT = (AT_KV * 16) / NT;   // V chunks per thread per tile
-  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
-  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fl = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
-  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
-  const unsigned short* Vh = Vp + (int64_t)head * AT_D;
-
-  bf16x8_t qf[8];
-  {
-    int64_t qr = q0 + fl;
-    qr = qr < Sq ? qr : Sq - 1;
-    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    // fold softmax scale * log2(e) into Q (one extra bf16 rounding of Q, relative 2^-9): the scores leave the MFMA in
-    // the exp2 domain, and with the running max entering as the accumulator's initial value the per-score FMA is gone
-    // (PRESCALED: the producer kernel already did this inside q's own rounding)
-    if constexpr (!PRESCALED) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8_t v = qf[ks];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
-        qf[ks] = v;
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
-  // K by LDS-DMA, V to registers, both through raw buffer loads: per-lane byte offsets are loop-invariant, the
-  // tile offset travels in an SGPR (soffset), and rows past Sk read as zero (hardware bounds check) — no
-  // per-tile 64-bit address VALU, no clamping.  Descriptors are wave-uniform (kernel arguments + blockIdx).
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
-  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), v_tile_bytes = (unsigned)(AT_KV * ldv * 2);
-  unsigned k_voff[KDMA];
-#pragma unroll
-  for (int j = 0; j < KDMA; ++j) {
-    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
-    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
-  }
-#define AT_DMA_K(T_, BUF_)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
-  i32x4_t vst[CPT];
-  int v_wr[CPT];
-  unsigned v_voff[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int id = i * NT + tid;
-    const int key = id >> 4, c = id & 15;
-    v_wr[i] = V_OFF + (c >> 1) * AT_VSUB + key * 32 + (c & 1) * 16;
-    v_voff[i] = (unsigned)(key * ldv * 2) + (unsigned)(c << 4);
-  }
-#define AT_LOAD_V(T_) \
-  _Pragma("unroll") for (int i = 0; i < CPT; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[i], (unsigned)(T_) * v_tile_bytes, 0);
-#define AT_WRITE_V(BUF_)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < CPT; ++i) *reinterpret_cast<i32x4_t*>(smem + (BUF_) * AT_V_BYTES + v_wr[i]) = vst[i];
-
-  // K fragment offsets: row (u*32+fl)*256 + ((ks*2+hi) ^ (fl&15))*16 = kaddr[ks] + u*8192 (+ buffer offset, immediate)
-  int kaddr[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = fl * 256 + (((hi ^ (fl & 15)) << 4) ^ (ks << 5));
-  const int L = lane & 15;
-  const int v_rd_base = ((fl >> 4) * 4) * AT_VSUB + (4 * hi + (L >> 2)) * 32 + (L & 3) * 8;
-
-  f32x16_t oacc[4];
-#pragma unroll
-  for (int T = 0; T < 4; ++T)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
-  // m_run: running row max (exp2 domain), entered into every score chain as C = negm = -m_run.  A chain is started two
-  // decisions before its scores are exponentiated (software pipeline), so scores carry m_run(t-2); d_prev = the growth
-  // decided at tile t-1.  Growth is rare (lazy rescale), so the fix-up  S' -= d_prev + d_cur  lives in a cold branch.
-  float m_run = 0.f, l_run = 0.f, d_prev = 0.f;
-  bool force = true;  // first tile: adopt its row max in either direction (no underflow for very negative rows)
-  f32x16_t negm;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
-  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
-
-#define AT_QK(DST_, BUF_)                                                                                     \
-  {                                                                                                            \
-    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
-    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
-      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
-    }                                                                                                          \
-  }
-
-  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
-  AT_DMA_K(0, 0)
-  if (nt > 1) {
-    AT_DMA_K(1, 1)
-  }
-  AT_LOAD_V(0)
-  AT_WRITE_V(0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x16_t sc[2];
-  AT_QK(sc, 0)
-  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
-  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
-  __syncthreads();
-
-  // One tile, written as an explicit 32-slot software pipeline (the compiler's own interleave of two
-  // independent streams proved unreliable): every slot = {fragment read for the NEXT slot, one MFMA, a fixed
-  // chunk of VALU work}, pinned by sched_barrier(0).
-  //   slots  0..15 (phase 1): MFMA = S(t+1) += K(t+1) Q^T;  VALU = softmax of S(t): 4 slots of row-max, 1 slot of
-  //                           max exchange + the lazy-rescale decision, 11 slots of exp2 + bf16 pack
-  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T;     VALU = row-sum adds
-  // SC_/SN_ are the two score buffers (they ping-pong: the loop is unrolled x2, nothing is copied), KN_/VB_ the
-  // compile-time LDS buffer indices of K(t+1) / V(t) (every LDS address = loop-invariant VGPR + immediate).
-  // LAST_ = true (peeled final tile): key masking, no next-tile MFMAs, no prefetch.
-#define AT_SB() __builtin_amdgcn_sched_barrier(0)
-#define AT_TILE(LAST_, SC_, SN_, KN_, VB_)                                                                     \
-  {                                                                                                            \
-    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  \
-    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
-      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
-        if (u * 32 + acc_row(r, hi) >= left) SC_[u][r] = -1e30f;                                               \
-    }                                                                                                          \
-    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
-    bf16x8_t kf_n = *reinterpret_cast<const bf16x8_t*>(kb_ + kaddr[0]);                                        \
-    float pm[4];                                                                                               \
-    unsigned pw[16];                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
-      const int ks = i >> 1, u = i & 1;                                                                        \
-      if (!(LAST_)) {                                                                                          \
-        const bf16x8_t kf_c = kf_n;                                                                            \
-        if (i < 15) kf_n = *reinterpret_cast<const bf16x8_t*>(kb_ + ((i + 1) & 1) * 8192 + kaddr[(i + 1) >> 1]); \
-        SN_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_c, qf[ks], ks == 0 ? negm : SN_[u], 0, 0, 0);    \
-      }                                                                                                        \
-      if (i < 4) { /* row max of 8 scores: 3 v_max3 + 1 v_max */                                               \
-        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
-        float m_ = vmax3(SC_[uu][r0], SC_[uu][r0 + 1], SC_[uu][r0 + 2]);                                       \
-        m_ = vmax3(m_, SC_[uu][r0 + 3], SC_[uu][r0 + 4]);                                                      \
-        m_ = vmax3(m_, SC_[uu][r0 + 5], SC_[uu][r0 + 6]);                                                      \
-        pm[i] = vmax2(m_, SC_[uu][r0 + 7]);                                                                    \
-      } else if (i == 4) {                                                                                     \
-        float mx = vmax2(vmax3(pm[0], pm[1], pm[2]), pm[3]);                                                   \
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
-        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
-        const float ex = mx - d_prev; /* this tile's row max relative to m_run(t-1) */                             \
-        if (force || __any(ex > (float)RESCALE_THR || d_prev != 0.f)) {                                        \
-          /* cold path: some row's max grew by more than THR (or did so one tile ago, or first tile) */        \
-          const bool grow = force || __any(ex > (float)RESCALE_THR);                                           \
-          const float d_cur = grow ? (force ? ex : fmaxf(ex, 0.f)) : 0.f;                                      \
-          if (grow) {                                                                                          \
-            m_run += d_cur;                                                                                    \
-            if (!force) {                                                                                      \
-              const float al = __builtin_amdgcn_exp2f(-d_cur);                                                 \
-              l_run *= al;                                                                                     \
-              _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
-            }                                                                                                  \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                   \
-          }                                                                                                    \
-          const float corr = d_prev + d_cur;                                                                   \
-          _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) SC_[u][e] -= corr; \
-          d_prev = d_cur;                                                                                      \
-          force = false;                                                                                       \
-        }                                                                                                      \
-      } else { /* slots 5..15: 3 (last: 2) elements of exp2, packed to bf16 pairs as they complete */          \
-        const int e0 = (i - 5) * 3, e1 = (e0 + 3 < 32) ? e0 + 3 : 32;                                          \
-        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
-          SC_[e >> 4][e & 15] = __builtin_amdgcn_exp2f(SC_[e >> 4][e & 15]);             \
-          if (e & 1) pw[e >> 1] = pack_bf2(SC_[e >> 4][(e & 15) - 1], SC_[e >> 4][e & 15]);                    \
-        }                                                                                                      \
-      }                                                                                                        \
-      AT_SB();                                                                                                 \
-    }                                                                                                          \
-    const char* vb = smem + V_OFF + (VB_) * AT_V_BYTES + v_rd_base;                                            \
-    bf16x8_t vf_n = tr_frag(vb, vb + 8 * 32);                                                                  \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
-      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
-      const bf16x8_t vf_c = vf_n;                                                                              \
-      if (j < 15) {                                                                                            \
-        const char* p0 = vb + ((j + 1) >> 2) * AT_VSUB + (((j + 1) & 3) * 16) * 32;                            \
-        vf_n = tr_frag(p0, p0 + 8 * 32);                                                                       \
-      }                                                                                                        \
-      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
-      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_c, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
-      l_run += SC_[j >> 3][(j & 7) * 2] + SC_[j >> 3][(j & 7) * 2 + 1];                                        \
-      AT_SB();                                                                                                 \
-    }                                                                                                          \
-  }
-  // Two tiles per iteration with the score buffers swapping roles (compile-time names and LDS buffer indices): no
-  // score copy, no per-tile LDS address arithmetic.
-#define AT_ITER(T_, SC_, SN_, KN_, VB_)                                                                         \
-  {                                                                                                            \
-    if ((T_) + 2 < nt) {                                                                                       \
-      AT_DMA_K((T_) + 2, VB_)                                                                                  \
-    }                                                                                                          \
-    AT_LOAD_V((T_) + 1)                                                                                        \
-    AT_SB();                                                                                                   \
-    AT_TILE(false, SC_, SN_, KN_, VB_)                                                                         \
-    AT_WRITE_V(KN_)                                                                                            \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
-    __syncthreads();                                                                                           \
-  }
-  f32x16_t sd[2];
-  int t = 0;
-  if constexpr (UNROLL2) {
-    for (; t + 2 < nt; t += 2) {
-      AT_ITER(t, sc, sd, 1, 0)
-      ++t;
-      AT_ITER(t, sd, sc, 0, 1)
-      --t;
-    }
-    if (t + 1 < nt) {
-      AT_ITER(t, sc, sd, 1, 0)
-      ++t;
-      AT_TILE(true, sd, sc, 0, 1)
-    } else {
-      AT_TILE(true, sc, sd, 1, 0)
-    }
-  } else {
-    for (; t < nt - 1; ++t) {
-      AT_ITER(t, sc, sd, (t + 1) & 1, t & 1)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) sc[u] = sd[u];
-    }
-    AT_TILE(true, sc, sd, (t + 1) & 1, t & 1)
-  }
-#undef AT_ITER
-#undef AT_TILE
-#undef AT_SB
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int64_t qrow = q0 + fl;
-  if (qrow < Sq) {
-    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i0 = 8 * g + 4 * hi;
-        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
-        uint2 pk;
-        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
-        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dv) = pk;
-      }
-  }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// v4 = v3's numerics (scale folded into Q, running max as the chain's C operand) with a tile body in which the last
-// link of each S(t+1) chain writes into the buffer S(t) has just vacated (no score copy, no unroll), all softmax VALU
-// in phase 1 with row sums in four partial chains, tree-shaped row maxima, and fragment reads two slots ahead.
-template <int NW, int RESCALE_THR, bool PRESCALED, int EXPERIMENT = 0>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v4_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
-                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
-                                                                   const unsigned short* __restrict__ Vp, int64_t ldv, unsigned short* __restrict__ O,
-                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
-                                                                   unsigned v_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int CPT = (AT_KV * 16) / NT;   // V chunks per thread per tile
-  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
-  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fl = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
-  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
-  const unsigned short* Vh = Vp + (int64_t)head * AT_D;
-
-  bf16x8_t qf[8];
-  {
-    int64_t qr = q0 + fl;
-    qr = qr < Sq ? qr : Sq - 1;
-    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    // fold softmax scale * log2(e) into Q (one extra bf16 rounding of Q, relative 2^-9): the scores leave the MFMA in
-    // the exp2 domain, and with the running max entering as the accumulator's initial value the per-score FMA is gone
-    // (PRESCALED: the producer kernel already did this inside q's own rounding)
-    if constexpr (!PRESCALED) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8_t v = qf[ks];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
-        qf[ks] = v;
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
-  // K by LDS-DMA, V to registers, both through raw buffer loads: per-lane byte offsets are loop-invariant, the
-  // tile offset travels in an SGPR (soffset), and rows past Sk read as zero (hardware bounds check) — no
-  // per-tile 64-bit address VALU, no clamping.  Descriptors are wave-uniform (kernel arguments + blockIdx).
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
-  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), v_tile_bytes = (unsigned)(AT_KV * ldv * 2);
-  unsigned k_voff[KDMA];
-#pragma unroll
-  for (int j = 0; j < KDMA; ++j) {
-    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
-    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
-  }
-#define AT_DMA_K(T_, BUF_)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
-  i32x4_t vst[CPT];
-  int v_wr[CPT];
-  unsigned v_voff[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int id = i * NT + tid;
-    const int key = id >> 4, c = id & 15;
-    v_wr[i] = V_OFF + (c >> 1) * AT_VSUB + key * 32 + (c & 1) * 16;
-    v_voff[i] = (unsigned)(key * ldv * 2) + (unsigned)(c << 4);
-  }
-#define AT_LOAD_V(T_) \
-  _Pragma("unroll") for (int i = 0; i < CPT; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[i], (unsigned)(T_) * v_tile_bytes, 0);
-#define AT_WRITE_V(BUF_)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < CPT; ++i) *reinterpret_cast<i32x4_t*>(smem + (BUF_) * AT_V_BYTES + v_wr[i]) = vst[i];
-
-  // K fragment offsets: row (u*32+fl)*256 + ((ks*2+hi) ^ (fl&15))*16 = kaddr[ks] + u*8192 (+ buffer offset, immediate)
-  int kaddr[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = fl * 256 + (((hi ^ (fl & 15)) << 4) ^ (ks << 5));
-  const int L = lane & 15;
-  const int v_rd_base = ((fl >> 4) * 4) * AT_VSUB + (4 * hi + (L >> 2)) * 32 + (L & 3) * 8;
-
-  f32x16_t oacc[4];
-#pragma unroll
-  for (int T = 0; T < 4; ++T)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
-  // m_run: running row max (exp2 domain), entered into every score chain as C = negm = -m_run.  A chain is started two
-  // decisions before its scores are exponentiated (software pipeline), so scores carry m_run(t-2); d_prev = the growth
-  // decided at tile t-1.  Growth is rare (lazy rescale), so the fix-up  S' -= d_prev + d_cur  lives in a cold branch.
-  float m_run = 0.f, d_prev = 0.f;
-  float lsum[4] = {0.f, 0.f, 0.f, 0.f};  // row sum in four partial chains (a single accumulator would serialise 32 dependent adds)
-  bool force = true;  // first tile: adopt its row max in either direction (no underflow for very negative rows)
-  f32x16_t negm;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
-  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
-
-#define AT_QK(DST_, BUF_)                                                                                     \
-  {                                                                                                            \
-    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
-    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
-      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
-    }                                                                                                          \
-  }
-
-  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
-  AT_DMA_K(0, 0)
-  if (nt > 1) {
-    AT_DMA_K(1, 1)
-  }
-  AT_LOAD_V(0)
-  AT_WRITE_V(0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x16_t sc[2];
-  AT_QK(sc, 0)
-  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
-  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
-  __syncthreads();
-
-  // One tile = 32 slots, each {fragment read two slots ahead, one MFMA, a fixed chunk of VALU work}, pinned by
-  // sched_barrier(0).
-  //   slots  0..15 (phase 1): MFMA = S(t+1) chain (K(t+1) Q'^T, C = negm at its head), accumulated in `sn`; the LAST link
-  //                           of each chain (slots 14, 15) writes its result into `sc`, which the VALU side has finished
-  //                           with by then — the score buffers swap roles without a copy and without unrolling.
-  //                           VALU = softmax of S(t) in sc: slots 0-3 row max (trees), slot 4 half-wave exchange + the
-  //                           lazy-rescale decision (cold branch), slots 5-9 exp2 / row-sum / bf16 pack of sc[0],
-  //                           slots 10-14 of sc[1].
-  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T from the packed P; no VALU (sn is dead: registers are free for
-  //                           the deeper fragment prefetch).
-#define AT_SB() __builtin_amdgcn_sched_barrier(0)
-#define A4_KFRAG(I_) (EXPERIMENT == 6 ? qf[(I_) & 7] : *reinterpret_cast<const bf16x8_t*>(kb_ + ((I_) & 1) * 8192 + kaddr[(I_) >> 1]))
-#define A4_VFRAG(J_) (EXPERIMENT == 6) ? qf[(J_) & 7] : tr_frag(vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32, vb + ((J_) >> 2) * AT_VSUB + (((J_) & 3) * 16) * 32 + 8 * 32)
-#define A4_TILE(LAST_, KN_, VB_)                                                                               \
-  {                                                                                                            \
-    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
-      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
-        if (u * 32 + acc_row(r, hi) >= left) sc[u][r] = -1e30f;                                                \
-    }                                                                                                          \
-    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
-    bf16x8_t kfa, kfb;                                                                                         \
-    if (!(LAST_)) {                                                                                            \
-      kfa = A4_KFRAG(0);                                                                                       \
-      kfb = A4_KFRAG(1);                                                                                       \
-    }                                                                                                          \
-    float pm[4];                                                                                               \
-    unsigned pw[16];                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
-      const int ks = i >> 1, u = i & 1;                                                                        \
-      if (!(LAST_)) {                                                                                          \
-        if (EXPERIMENT == 4) { asm volatile("" :: "v"(kfa), "v"(kfb)); }                                       \
-        else if (i < 14) sn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], ks == 0 ? negm : sn[u], 0, 0, 0); \
-        else sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], sn[u], 0, 0, 0);           \
-        if (i + 2 < 16) {                                                                                      \
-          if (u) kfb = A4_KFRAG(i + 2); else kfa = A4_KFRAG(i + 2);                                            \
-        }                                                                                                      \
-      }                                                                                                        \
-      if (EXPERIMENT == 5) { if (i == 5) { _Pragma("unroll") for (int e = 0; e < 16; ++e) pw[e] = __float_as_uint(sc[e >> 3][e & 7]); } } \
-      else if (i < 4) { /* row max of 8 scores as a depth-2 tree */                                            \
-        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
-        const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                    \
-        const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                \
-        const float c_ = vmax2(sc[uu][r0 + 6], sc[uu][r0 + 7]);                                                \
-        pm[i] = vmax3(a_, b_, c_);                                                                             \
-      } else if (i == 4) {                                                                                     \
-        float mx = vmax2(vmax2(pm[0], pm[1]), vmax2(pm[2], pm[3]));                                            \
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
-        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
-        const float ex = mx - d_prev; /* this tile's row max relative to m_run(t-1) */                         \
-        if (force || __any(ex > (float)RESCALE_THR || d_prev != 0.f)) {                                        \
-          /* cold path: some row's max grew by more than THR (or did so one tile ago, or first tile) */        \
-          const bool grow = force || __any(ex > (float)RESCALE_THR);                                           \
-          const float d_cur = grow ? (force ? ex : fmaxf(ex, 0.f)) : 0.f;                                      \
-          if (grow) {                                                                                          \
-            m_run += d_cur;                                                                                    \
-            if (!force) {                                                                                      \
-              const float al = __builtin_amdgcn_exp2f(-d_cur);                                                 \
-              _Pragma("unroll") for (int e = 0; e < 4; ++e) lsum[e] *= al;                                     \
-              _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
-            }                                                                                                  \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                   \
-          }                                                                                                    \
-          const float corr = d_prev + d_cur;                                                                   \
-          _Pragma("unroll") for (int u2 = 0; u2 < 2; ++u2) _Pragma("unroll") for (int e = 0; e < 16; ++e) sc[u2][e] -= corr; \
-          d_prev = d_cur;                                                                                      \
-          force = false;                                                                                       \
-        }                                                                                                      \
-      } else if (i < 15) { /* slots 5..9: sc[0], slots 10..14: sc[1]; 4,3,3,3,3 elements */                    \
-        const int uu = (i - 5) / 5, q_ = (i - 5) % 5;                                                          \
-        const int e0 = q_ == 0 ? 0 : 1 + 3 * q_, e1 = 4 + 3 * q_;                                              \
-        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
-          const float p_ = EXPERIMENT == 2 ? sc[uu][e] : __builtin_amdgcn_exp2f(sc[uu][e]); /* 2: timing probe */  \
-          sc[uu][e] = p_;                                                                                      \
-          lsum[e & 3] += p_;                                                                                   \
-          if (e & 1) pw[uu * 8 + (e >> 1)] = pack_bf2(sc[uu][e - 1], p_);                                      \
-        }                                                                                                      \
-      }                                                                                                        \
-      AT_SB();                                                                                                 \
-    }                                                                                                          \
-    const char* vb = smem + V_OFF + (VB_) * AT_V_BYTES + v_rd_base;                                            \
-    bf16x8_t vfa = A4_VFRAG(0), vfb = A4_VFRAG(1);                                                             \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
-      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
-      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
-      if (EXPERIMENT != 3) oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((j & 1) ? vfb : vfa, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
-      else { asm volatile("" :: "v"(vfa), "v"(vfb), "v"(pq)); }                                               \
-      if (j + 2 < 16) {                                                                                        \
-        if (j & 1) vfb = A4_VFRAG(j + 2); else vfa = A4_VFRAG(j + 2);                                          \
-      }                                                                                                        \
-      AT_SB();                                                                                                 \
-    }                                                                                                          \
-  }
-  f32x16_t sn[2];
-  int t = 0;
-  for (; t < nt - 1; ++t) {
-    if (t + 2 < nt) {
-      AT_DMA_K(t + 2, t & 1)
-    }
-    AT_LOAD_V(t + 1)
-    AT_SB();
-    A4_TILE(false, (t + 1) & 1, t & 1)
-    AT_WRITE_V((t + 1) & 1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (EXPERIMENT != 1) __syncthreads();  // EXPERIMENT 1: timing-only probe of the barrier cost (results invalid)
-  }
-  A4_TILE(true, (t + 1) & 1, t & 1)
-#undef A4_TILE
-#undef A4_VFRAG
-#undef A4_KFRAG
-#undef AT_SB
-
-  const float l_run = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int64_t qrow = q0 + fl;
-  if (qrow < Sq) {
-    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i0 = 8 * g + 4 * hi;
-        const int dv = (i0 < 16) ? (16 * T + i0) : (64 + 16 * T + (i0 - 16));
-        uint2 pk;
-        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
-        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dv) = pk;
-      }
-  }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// v6 = v4's pipeline on a pre-transposed V: V^T [H][128][Sk padded] (x2v_transpose_heads_bf16) is staged by LDS-DMA like K
-// and read with ds_read_b128; K rows are permuted in the fragment read so that P's register order matches 8 consecutive
-// keys.  Per tile and wave: 32 LDS fragment reads instead of 48, no ds_read_tr, no V register staging / ds_write.
-template <int NW, int RESCALE_THR, bool PRESCALED>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v6_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
-                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
-                                                                   const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
-                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
-                                                                   unsigned v_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (buffer resources): the host pass only needs the launch stub
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int KDMA = 16 / NW;            // K LDS-DMA wave-instructions per wave per tile (1 KiB each)
-  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fl = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
-  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
-  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;  // this head's V^T block: [ldvt/64 tiles][128 dv rows][64 keys]
-
-  bf16x8_t qf[8];
-  {
-    int64_t qr = q0 + fl;
-    qr = qr < Sq ? qr : Sq - 1;
-    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    // fold softmax scale * log2(e) into Q (one extra bf16 rounding of Q, relative 2^-9): the scores leave the MFMA in
-    // the exp2 domain, and with the running max entering as the accumulator's initial value the per-score FMA is gone
-    // (PRESCALED: the producer kernel already did this inside q's own rounding)
-    if constexpr (!PRESCALED) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8_t v = qf[ks];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
-        qf[ks] = v;
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
-  // K and V^T both by LDS-DMA through raw buffer loads: per-lane byte offsets are loop-invariant, the tile offset travels
-  // in an SGPR (soffset); K rows past Sk read as zero (hardware bounds check), V^T is zero-padded to a tile multiple by the
-  // transpose kernel.  V^T tiles [128 dv][64 keys] (16 KiB contiguous each) make the PV A-operand a plain ds_read_b128 of 8 consecutive keys — no
-  // transpose reads, no register staging, the same [rows][128 B] swizzled image as the GEMM tiles.
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
-  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2);
-  unsigned k_voff[KDMA], v_voff[KDMA];
-#pragma unroll
-  for (int j = 0; j < KDMA; ++j) {
-    const int krow = (wid * KDMA + j) * 4 + (lane >> 4);
-    k_voff[j] = (unsigned)(krow * ldk * 2) + (unsigned)(((lane & 15) ^ (krow & 15)) << 4);
-    const int vrow = (wid * KDMA + j) * 8 + (lane >> 3);  // dv row of the [128][128 B] tile; 8 rows per 1 KiB piece
-    v_voff[j] = (unsigned)(vrow * 128) + (unsigned)(((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
-  }
-#define AT_DMA_K(T_, BUF_)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, k_voff[j], (unsigned)(T_) * k_tile_bytes, 0, 0);
-#define AT_DMA_V(T_, BUF_)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < KDMA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wid * KDMA + j) * 1024), 16, v_voff[j], (unsigned)(T_) * AT_K_BYTES, 0, 0);
-
-  // K fragment offsets.  MFMA row i = fl reads key row perm(fl) = fl with bits 2 and 3 swapped, so that a half-wave's
-  // accumulator registers hold 8 CONSECUTIVE keys per 16-key group (keys 16g + 8*hi + 0..7) — the k-order of a plain
-  // 16-byte V^T fragment.  (Any key permutation is legal for QK^T; it only has to agree with the PV operands.)
-  int kaddr[8];
-  const int krow_rd = (fl & 0x13) | ((fl & 4) << 1) | ((fl & 8) >> 1);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = krow_rd * 256 + (((hi ^ (krow_rd & 15)) << 4) ^ (ks << 5));
-  // V^T fragment offsets: dv row (T*32 + fl), 16-byte chunk (g*2 + hi) of 16-key group g, GEMM-style swizzle
-  int vaddr[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) vaddr[g] = fl * 128 + ((((g << 1) | hi) ^ ((fl >> 1) & 7)) << 4);
-
-  f32x16_t oacc[4];
-#pragma unroll
-  for (int T = 0; T < 4; ++T)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[T][e] = 0.f;
-  // m_run: running row max (exp2 domain), entered into every score chain as C = negm = -m_run.  A chain is started two
-  // decisions before its scores are exponentiated (software pipeline), so scores carry m_run(t-2); d_prev = the growth
-  // decided at tile t-1.  Growth is rare (lazy rescale), so the fix-up  S' -= d_prev + d_cur  lives in a cold branch.
-  float m_run = 0.f, d_prev = 0.f;
-  float lsum[4] = {0.f, 0.f, 0.f, 0.f};  // row sum in four partial chains (a single accumulator would serialise 32 dependent adds)
-  bool force = true;  // first tile: adopt its row max in either direction (no underflow for very negative rows)
-  f32x16_t negm;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
-  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
-
-#define AT_QK(DST_, BUF_)                                                                                     \
-  {                                                                                                            \
-    const char* kb_ = smem + K_OFF + (BUF_) * AT_K_BYTES;                                                      \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int e = 0; e < 16; ++e) DST_[u][e] = 0.f; \
-    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) _Pragma("unroll") for (int u = 0; u < 2; ++u) {           \
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb_ + u * 8192 + kaddr[ks]);                      \
-      DST_[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], DST_[u], 0, 0, 0);                         \
-    }                                                                                                          \
-  }
-
-  // ---- prologue: K(0), K(1) by DMA; V(0) by registers; S(0)
-  AT_DMA_K(0, 0)
-  if (nt > 1) {
-    AT_DMA_K(1, 1)
-  }
-  AT_DMA_V(0, 0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x16_t sc[2];
-  AT_QK(sc, 0)
-  // every wave must be done reading K(0) before iteration 0 re-targets K buffer 0 with the DMA of K(2)
-  // (without this barrier a fast wave's DMA could land under a slow wave's prologue QK^T: rare, small errors)
-  __syncthreads();
-
-  // One tile = 32 slots, each {fragment read two slots ahead, one MFMA, a fixed chunk of VALU work}, pinned by
-  // sched_barrier(0).
-  //   slots  0..15 (phase 1): MFMA = S(t+1) chain (K(t+1) Q'^T, C = negm at its head), accumulated in `sn`; the LAST link
-  //                           of each chain (slots 14, 15) writes its result into `sc`, which the VALU side has finished
-  //                           with by then — the score buffers swap roles without a copy and without unrolling.
-  //                           VALU = softmax of S(t) in sc: slots 0-3 row max (trees), slot 4 half-wave exchange + the
-  //                           lazy-rescale decision (cold branch), slots 5-9 exp2 / row-sum / bf16 pack of sc[0],
-  //                           slots 10-14 of sc[1].
-  //   slots 16..31 (phase 2): MFMA = O[T] += V(t)^T P^T from the packed P; no VALU (sn is dead: registers are free for
-  //                           the deeper fragment prefetch).
-#define AT_SB() __builtin_amdgcn_sched_barrier(0)
-#define A4_KFRAG(I_) (*reinterpret_cast<const bf16x8_t*>(kb_ + ((I_) & 1) * 8192 + kaddr[(I_) >> 1]))
-#define A4_VFRAG(J_) (*reinterpret_cast<const bf16x8_t*>(vb + ((J_) >> 2) * 4096 + vaddr[(J_) & 3]))
-#define A4_TILE(LAST_, KN_, VB_)                                                                               \
-  {                                                                                                            \
-    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
-      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
-        if (u * 32 + (r & 7) + 8 * hi + 16 * (r >> 3) >= left) sc[u][r] = -1e30f;                              \
-    }                                                                                                          \
-    const char* kb_ = smem + K_OFF + (KN_) * AT_K_BYTES;                                                       \
-    bf16x8_t kfa, kfb;                                                                                         \
-    if (!(LAST_)) {                                                                                            \
-      kfa = A4_KFRAG(0);                                                                                       \
-      kfb = A4_KFRAG(1);                                                                                       \
-    }                                                                                                          \
-    float pm[4];                                                                                               \
-    unsigned pw[16];                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                           \
-      const int ks = i >> 1, u = i & 1;                                                                        \
-      if (!(LAST_)) {                                                                                          \
-        if (i < 14) sn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], ks == 0 ? negm : sn[u], 0, 0, 0); \
-        else sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u ? kfb : kfa, qf[ks], sn[u], 0, 0, 0);           \
-        if (i + 2 < 16) {                                                                                      \
-          if (u) kfb = A4_KFRAG(i + 2); else kfa = A4_KFRAG(i + 2);                                            \
-        }                                                                                                      \
-      }                                                                                                        \
-      if (i < 4) { /* row max of 8 scores as a depth-2 tree */                                                 \
-        const int uu = i >> 1, r0 = (i & 1) * 8;                                                               \
-        const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                    \
-        const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                \
-        const float c_ = vmax2(sc[uu][r0 + 6], sc[uu][r0 + 7]);                                                \
-        pm[i] = vmax3(a_, b_, c_);                                                                             \
-      } else if (i == 4) {                                                                                     \
-        float mx = vmax2(vmax2(pm[0], pm[1]), vmax2(pm[2], pm[3]));                                            \
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);    \
-        mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                                            \
-        const float ex = mx - d_prev; /* this tile's row max relative to m_run(t-1) */                         \
-        if (force || __any(ex > (float)RESCALE_THR || d_prev != 0.f)) {                                        \
-          /* cold path: some row's max grew by more than THR (or did so one tile ago, or first tile) */        \
-          const bool grow = force || __any(ex > (float)RESCALE_THR);                                           \
-          const float d_cur = grow ? (force ? ex : fmaxf(ex, 0.f)) : 0.f;                                      \
-          if (grow) {                                                                                          \
-            m_run += d_cur;                                                                                    \
-            if (!force) {                                                                                      \
-              const float al = __builtin_amdgcn_exp2f(-d_cur);                                                 \
-              _Pragma("unroll") for (int e = 0; e < 4; ++e) lsum[e] *= al;                                     \
-              _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
-            }                                                                                                  \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                   \
-          }                                                                                                    \
-          const float corr = d_prev + d_cur;                                                                   \
-          _Pragma("unroll") for (int u2 = 0; u2 < 2; ++u2) _Pragma("unroll") for (int e = 0; e < 16; ++e) sc[u2][e] -= corr; \
-          d_prev = d_cur;                                                                                      \
-          force = false;                                                                                       \
-        }                                                                                                      \
-      } else if (i < 15) { /* slots 5..9: sc[0], slots 10..14: sc[1]; 4,3,3,3,3 elements */                    \
-        const int uu = (i - 5) / 5, q_ = (i - 5) % 5;                                                          \
-        const int e0 = q_ == 0 ? 0 : 1 + 3 * q_, e1 = 4 + 3 * q_;                                              \
-        _Pragma("unroll") for (int e = e0; e < e1; ++e) {                                                      \
-          const float p_ = __builtin_amdgcn_exp2f(sc[uu][e]);                                                  \
-          sc[uu][e] = p_;                                                                                      \
-          lsum[e & 3] += p_;                                                                                   \
-          if (e & 1) pw[uu * 8 + (e >> 1)] = pack_bf2(sc[uu][e - 1], p_);                                      \
-        }                                                                                                      \
-      }                                                                                                        \
-      AT_SB();                                                                                                 \
-    }                                                                                                          \
-    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                        \
-    bf16x8_t vfa = A4_VFRAG(0), vfb = A4_VFRAG(1);                                                             \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                           \
-      const int T = j >> 2, uh = j & 3; /* uh = u*2 + h2: keys (uh*16) .. +16 of the tile */                   \
-      i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};       \
-      oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((j & 1) ? vfb : vfa, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
-      if (j + 2 < 16) {                                                                                        \
-        if (j & 1) vfb = A4_VFRAG(j + 2); else vfa = A4_VFRAG(j + 2);                                          \
-      }                                                                                                        \
-      AT_SB();                                                                                                 \
-    }                                                                                                          \
-  }
-  f32x16_t sn[2];
-  int t = 0;
-  for (; t < nt - 1; ++t) {
-    if (t + 2 < nt) {
-      AT_DMA_K(t + 2, t & 1)
-    }
-    AT_DMA_V(t + 1, (t + 1) & 1)
-    AT_SB();
-    A4_TILE(false, (t + 1) & 1, t & 1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  A4_TILE(true, (t + 1) & 1, t & 1)
-#undef A4_TILE
-#undef A4_VFRAG
-#undef A4_KFRAG
-#undef AT_SB
-
-  const float l_run = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int64_t qrow = q0 + fl;
-  if (qrow < Sq) {
-    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = 32 * T + 8 * g + 4 * hi;  // accumulator row of the 32x32 tile = dv row of the V^T fragment
-        uint2 pk;
-        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
-        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dv) = pk;
-      }
-  }
-#endif
-}
-#undef AT_DMA_V
-// ------------------------------------------------------------------------------------------------
-// v8 = "ping-pong" on the v6 operand layouts: every wave alternates a pure matrix half-step {PV(t-1) then QK^T(t): 32 MFMAs +
-// their LDS fragment reads} with a pure vector half-step {softmax(t): row max, exp2, row sum, bf16 pack}, and the two waves of
-// a SIMD (wid and wid + NW/2) run half a step apart — while one occupies the matrix pipe the other occupies the VALU port.
-// In phase (v2..v6) both waves want the VALU during the softmax (exp2 is quarter rate) and both want the matrix pipe during
-// PV; the measured decomposition of v4 showed the parts adding up rather than overlapping.
+// "ping-pong" (v8): every wave alternates a pure matrix half-step {QK^T(t) then PV(t-1): 32 MFMAs + their LDS fragment reads} with a
+// pure vector half-step {softmax(t): row max, exp2, row sum, bf16 pack}, and the two waves of a SIMD (wid and wid + NW/2) run half a
+// step apart — while one occupies the matrix pipe the other occupies the VALU port.  In phase (v2) both waves want the VALU during
+// the softmax (exp2 is quarter rate) and both want the matrix pipe during PV; the measured decomposition showed the parts
+// adding up rather than overlapping.
+//   * V is consumed pre-transposed (x2v_transpose_heads_bf16: V^T [H][S/64][128 dv][64 keys]), so both operand tiles arrive by LDS-DMA
+//     into [rows][128 B]-swizzled images and both fragments are plain ds_read_b128 (K rows are read through a bit-2/bit-3 swap so
+//     that a half-wave's P registers are 8 consecutive keys = the k-order of a 16-byte V^T fragment);
 //   * one barrier per half-step; data movement is by global half-step g, identical for all waves: even g = 2t issues
-//     K(t+1) and V^T(t) (both double buffered), the odd half-step that follows ends with s_waitcnt vmcnt(0);
+//     K(t+1) and V^T(t) (both double buffered), the odd half-step that follows ends with s_waitcnt vmcnt(0).  Only the waves in
+//     their vector half-step issue the DMA (an LDS-DMA issue costs ~60 cycles between bare MFMAs, about half in VALU-only gaps);
 //   * scores leave the MFMA already relative to the running max (C = -m_run, known before QK^T(t) starts because softmax(t-1)
-//     is the same wave's previous half-step — no one-tile lag as in v3/v4), rescale stays lazy (cold branch);
-//   * no second score buffer: 32 accumulator registers fewer than v4/v6, nothing spills at 2 waves per SIMD.
-template <int NW, int RESCALE_THR, bool PRESCALED, int PRIO, int DEPTH, int PROBE, bool DMA_LATE>
+//     is the same wave's previous half-step), q carries scale*log2(e) (PRESCALED: folded in by the producer), so P = exp2(S') with
+//     no per-score FMA; rescale stays lazy (cold branch, threshold RESCALE_THR in base-2 units);
+//   * one score buffer: nothing spills at 2 waves per SIMD.
+// TUNE = 1 (round 2; what the .s of TUNE = 0 showed in the matrix half-step, which sets the kernel's pace):
+//   (a) hipcc computed the second score chain IN the registers of the -m tuple and copied it out afterwards (s_nop 8 + 8 v_mov_b64
+//       between QK^T and PV, and 8 more v_mov_b64 per tile to restore -m): the first MFMA of each chain now goes through an asm
+//       statement whose output is early-clobber, so -m stays a pure input and nothing is copied;
+//   (b) the 19 row-sum adds had been sunk behind the last PV MFMA (inside the matrix half-step, at raised priority): they are pinned
+//       into the vector half-step;
+//   (c) the tile loop is unrolled x2 so that both LDS buffer indices are compile-time: every fragment address is
+//       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
+template <int NW, int RESCALE_THR, bool PRESCALED, int TUNE>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
                                                                    const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
@@ -1289,6 +329,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  constexpr int DEPTH = 4;  // fragment prefetch depth (slots ahead of the consuming MFMA)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1318,16 +359,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
     for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
 
-  // LDS-DMA of K [64 keys][256 B] and V^T [128 dv][128 B] tiles, 1 KiB pieces (4 K rows / 8 V^T rows).  A wave moves pieces
-  // wid + NW*j: the rows of its pieces differ by a multiple of 16, so the swizzled source chunk is the same and ONE per-lane
-  // offset register per operand serves all pieces (the piece stride travels in the scalar offset with the tile offset).
+  // LDS-DMA of K [64 keys][256 B] and V^T [128 dv][128 B] tiles, 1 KiB pieces (4 K rows / 8 V^T rows).  Only the upper half of the
+  // waves moves data (all 16 pieces per operand, during their vector half-step); their pieces are wl + (NW/2) j: the rows of a wave's
+  // pieces differ by a multiple of 16, so the swizzled source chunk is the same and ONE per-lane offset register per operand serves
+  // all pieces (the piece stride travels in the scalar offset with the tile offset).
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
-  // DMA_LATE: only the upper half of the waves moves data (all 16 pieces per operand, during their vector half-step: an LDS-DMA
-  // issue costs ~60 cycles between bare MFMAs and about half of that in VALU-only gaps); their pieces are wl + (NW/2) j.
-  constexpr int NDW = DMA_LATE ? NW / 2 : NW;      // waves that issue
-  constexpr int NPC = 16 / NDW;                    // pieces per issuing wave and operand
-  const int wl = DMA_LATE ? (wid & (NW / 2 - 1)) : wid;
+  constexpr int NDW = NW / 2;     // waves that issue
+  constexpr int NPC = 16 / NDW;   // pieces per issuing wave and operand
+  const int wl = wid & (NW / 2 - 1);
   const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_piece_bytes = (unsigned)(4 * NDW * ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * 128);
   const int krow_w = wl * 4 + (lane >> 4), vrow_w = wl * 8 + (lane >> 3);
   const unsigned k_voff = (unsigned)(krow_w * ldk * 2) + (unsigned)(((lane & 15) ^ (krow_w & 15)) << 4);
@@ -1339,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
       rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (unsigned)(T_) * AT_K_BYTES + j * v_piece_bytes, 0, 0);
 
-  // fragment offsets (see v6): K rows read through the bit-2/bit-3 swap so a half-wave's P registers are 8 consecutive keys
+  // fragment offsets: K rows read through the bit-2/bit-3 swap so a half-wave's P registers are 8 consecutive keys
   int kaddr[8], vaddr[4];
   const int krow_rd = (fl & 0x13) | ((fl & 4) << 1) | ((fl & 8) >> 1);
 #pragma unroll
@@ -1368,17 +408,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + ((N_) & 1) * 8192 + kaddr[(N_) >> 1])                \
              : *reinterpret_cast<const bf16x8_t*>(vb + ((N_) & 3) * 4096 + vaddr[((N_) - 16) >> 2]))
 #define A8_MATRIX(N0_, N1_, VB_, KB_)                                                                          \
-  if (PROBE != 2) {                                                                                            \
+  {                                                                                                            \
     const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                        \
     const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                       \
-    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
     bf16x8_t fr[DEPTH];                                                                                        \
     _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A8_FRAG((N0_) + d);                              \
     _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                    \
       const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                             \
       if (n < 16) {                                                                                            \
         const int ks = n >> 1, u = n & 1;                                                                      \
-        sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, qf[ks], ks == 0 ? negm : sc[u], 0, 0, 0);          \
+        if (TUNE >= 1 && ks == 0) /* D early-clobber: the -m tuple stays a pure input */                       \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sc[u]) : "v"(f_), "v"(qf[0]), "v"(negm)); \
+        else                                                                                                   \
+          sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, qf[ks], ks == 0 ? negm : sc[u], 0, 0, 0);        \
       } else {                                                                                                 \
         const int T = n & 3, uh = (n - 16) >> 2;                                                               \
         i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};     \
@@ -1387,14 +430,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
       if (n + DEPTH < (N1_)) fr[(n - (N0_)) % DEPTH] = A8_FRAG(n + DEPTH);                                     \
       A8_SB();                                                                                                 \
     }                                                                                                          \
-    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
   }
   // vector half-step: softmax of the tile in sc -> packed bf16 P in pw
 #define A8_SOFTMAX(LAST_)                                                                                      \
-  if (PROBE == 1) {                                                                                            \
-    _Pragma("unroll") for (int e = 0; e < 16; ++e) pw[e] = __float_as_uint(sc[e >> 3][e & 7]) >> 8;            \
-  } else {                                                                                                     \
-    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                              \
+  {                                                                                                            \
     if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
       const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
@@ -1429,29 +469,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
       lsum[(e + 1) & 3] += p1;                                                                                 \
       pw[uu * 8 + (e >> 1)] = pack_bf2(p0, p1);                                                                \
     }                                                                                                          \
-    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                              \
+    if (TUNE >= 1) { /* the row sums belong to THIS half-step: without the pin hipcc sinks the adds behind the next PV MFMAs */ \
+      asm volatile("" : "+v"(lsum[0]), "+v"(lsum[1]), "+v"(lsum[2]), "+v"(lsum[3]));                           \
+      A8_SB();                                                                                                 \
+    }                                                                                                          \
   }
 
   // ---- prologue: K(0)
-  if (!DMA_LATE || wid >= NW / 2) {
+  if (wid >= NW / 2) {
     A8_DMA_K(0, 0)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---- global half-steps g = 0 .. 2 nt + 1; a wave's own step is gl = g - late (late = the upper half of the waves):
-  //      gl = 2t   : matrix half-step  PV(t-1) [t > 0]  +  QK^T(t) [t < nt]
+  //      gl = 2t   : matrix half-step  QK^T(t) [t < nt]  +  PV(t-1) [t > 0]
   //      gl = 2t+1 : vector half-step  softmax(t)
   // Written out per role (straight-line loops keep the accumulator tuples in place; a single loop with a phase switch made
   // the register allocator copy and spill them).  Every wave passes 2 nt + 2 barriers.
   int t = 0;
-#define A8_ISSUE(TG_) /* even half-step g = 2 TG_; PROBE 3: no operand movement after the first tile (timing only) */ \
-  if ((TG_) + 1 < nt && (PROBE != 3 || (TG_) == 0)) {          \
-    A8_DMA_K((TG_) + 1, ((TG_) + 1) & 1)                       \
-  }                                                            \
-  if ((TG_) < nt && (PROBE != 3 || (TG_) == 0)) {              \
-    A8_DMA_V((TG_), (TG_) & 1)                                 \
-  }                                                            \
+#define A8_ISSUE(TG_) /* even half-step g = 2 TG_ */ \
+  if ((TG_) + 1 < nt) {                               \
+    A8_DMA_K((TG_) + 1, ((TG_) + 1) & 1)              \
+  }                                                   \
+  if ((TG_) < nt) {                                   \
+    A8_DMA_V((TG_), (TG_) & 1)                        \
+  }                                                   \
   A8_SB();
   // the data issued in an even half-step is awaited at the end of the following odd one: two half-steps of flight
 #define A8_BAR_EVEN() __syncthreads();
@@ -1459,19 +502,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
   __syncthreads();
   if (wid < NW / 2) {
-    if (!DMA_LATE) {
-      A8_ISSUE(0)
-    }
     A8_MATRIX(0, 16, 0, 0)
     A8_BAR_EVEN()
-    for (; t < nt - 1; ++t) {
-      A8_SOFTMAX(false)
-      A8_BAR_ODD()
-      if (!DMA_LATE) {
-        A8_ISSUE(t + 1)
+    if constexpr (TUNE >= 1) {
+      // iteration t: softmax(t) | matrix {QK^T(t+1) from K buffer (t+1)&1, PV(t) from V^T buffer t&1}; t starts even
+      while (t < nt - 1) {
+        A8_SOFTMAX(false)
+        A8_BAR_ODD()
+        A8_MATRIX(0, 32, 0, 1)
+        A8_BAR_EVEN()
+        if (++t >= nt - 1) break;
+        A8_SOFTMAX(false)
+        A8_BAR_ODD()
+        A8_MATRIX(0, 32, 1, 0)
+        A8_BAR_EVEN()
+        ++t;
       }
-      A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
-      A8_BAR_EVEN()
+    } else {
+      for (; t < nt - 1; ++t) {
+        A8_SOFTMAX(false)
+        A8_BAR_ODD()
+        A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
+        A8_BAR_EVEN()
+      }
     }
     A8_SOFTMAX(true)
     A8_BAR_ODD()
@@ -1483,12 +536,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
     A8_BAR_EVEN()
     A8_MATRIX(0, 16, 0, 0)
     A8_BAR_ODD()
-    for (; t < nt - 1; ++t) {
-      A8_ISSUE(t + 1)
-      A8_SOFTMAX(false)
-      A8_BAR_EVEN()
-      A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
-      A8_BAR_ODD()
+    if constexpr (TUNE >= 1) {
+      while (t < nt - 1) {
+        A8_ISSUE(t + 1)
+        A8_SOFTMAX(false)
+        A8_BAR_EVEN()
+        A8_MATRIX(0, 32, 0, 1)
+        A8_BAR_ODD()
+        if (++t >= nt - 1) break;
+        A8_ISSUE(t + 1)
+        A8_SOFTMAX(false)
+        A8_BAR_EVEN()
+        A8_MATRIX(0, 32, 1, 0)
+        A8_BAR_ODD()
+        ++t;
+      }
+    } else {
+      for (; t < nt - 1; ++t) {
+        A8_ISSUE(t + 1)
+        A8_SOFTMAX(false)
+        A8_BAR_EVEN()
+        A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
+        A8_BAR_ODD()
+      }
     }
     A8_SOFTMAX(true)
     A8_BAR_EVEN()
@@ -1524,13 +594,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   }
 #endif
 }
-#undef AT_DMA_K
-#undef AT_LOAD_V
-#undef AT_WRITE_V
-#undef AT_QK
-
-
-
 
 // V [Sk, H*128] (token stride ldv) -> V^T [H][ldvt/64][128][64] bf16 (per head and 64-key tile a contiguous 16 KiB [dv][key] block: one
 // attention tile = one linear stream, like K's) with keys >= Sk zero-filled up to ldvt (a multiple of 64).  One tile per block, through LDS.
@@ -1566,22 +629,8 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const unsigned sho
 }  // namespace x2v
 using namespace x2v;
 
-template <int NW, bool SAFE_V>
-static int launch_attn(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                       int H, float scale, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, SAFE_V>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
-    if (rc != X2V_OK) return rc;
-    attr_set = true;
-  }
-  const int QB = NW * 32;
-  dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
-  hipLaunchKernelGGL((attn_fwd_kernel<NW, SAFE_V>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
-                     (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f);
-  X2V_LAUNCH_CHECK("attn launch");
-  return X2V_OK;
-}
+// which body x2v_attn_fwd_bf16_vt launches by default (kind 0); kind 1 launches the other one (A/B)
+#define X2V_ATTN_VT_DEFAULT_TUNE 1
 
 template <int NW, int THR>
 static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
@@ -1590,12 +639,8 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (Sk - 1) * ldv * 2 + AT_D * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32) - (int64_t)AT_KV * ldv * 2, X2V_E_SHAPE,
               "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<NW, THR>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
-    if (rc != X2V_OK) return rc;
-    attr_set = true;
-  }
+  int rc = ensure_dynamic_lds((const void*)attn_fwd_pipe_kernel<NW, THR>, AT_LDS_BYTES, "attn attr");
+  if (rc != X2V_OK) return rc;
   const int QB = NW * 32;
   dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
   hipLaunchKernelGGL((attn_fwd_pipe_kernel<NW, THR>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
@@ -1604,69 +649,14 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
   return X2V_OK;
 }
 
-template <int NW, int THR, bool UNROLL2, bool PRESCALED>
-static int launch_attn_v3(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
-                            int64_t Sk, int H, float scale, hipStream_t st) {
-  // buffer descriptors address 32 bits: the per-head K/V views must stay below 4 GiB
-  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (Sk - 1) * ldv * 2 + AT_D * 2;
-  X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32) - (int64_t)AT_KV * ldv * 2, X2V_E_SHAPE,
-              "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_v3_kernel<NW, THR, UNROLL2, PRESCALED>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
-    if (rc != X2V_OK) return rc;
-    attr_set = true;
-  }
-  const int QB = NW * 32;
-  dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
-  hipLaunchKernelGGL((attn_fwd_v3_kernel<NW, THR, UNROLL2, PRESCALED>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
-                     (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
-  X2V_LAUNCH_CHECK("attn launch");
-  return X2V_OK;
-}
-
-template <int NW, int THR, bool PRESCALED, int EXPERIMENT = 0>
-static int launch_attn_v4(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
-                            int64_t Sk, int H, float scale, hipStream_t st) {
-  // buffer descriptors address 32 bits: the per-head K/V views must stay below 4 GiB
-  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (Sk - 1) * ldv * 2 + AT_D * 2;
-  X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32) - (int64_t)AT_KV * ldv * 2, X2V_E_SHAPE,
-              "attn: K/V view spans >= 4 GiB (Sk=%lld, ld=%lld/%lld)", (long long)Sk, (long long)ldk, (long long)ldv);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)attn_fwd_v4_kernel<NW, THR, PRESCALED, EXPERIMENT>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES), "attn attr");
-    if (rc != X2V_OK) return rc;
-    attr_set = true;
-  }
-  const int QB = NW * 32;
-  dim3 grid((unsigned)((Sq + QB - 1) / QB), (unsigned)H);
-  hipLaunchKernelGGL((attn_fwd_v4_kernel<NW, THR, PRESCALED, EXPERIMENT>), grid, dim3(NW * 64), AT_LDS_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
-                     (const unsigned short*)v, ldv, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
-  X2V_LAUNCH_CHECK("attn launch");
-  return X2V_OK;
-}
-
-// KIND 0: v8 default; 1: v6 (in phase); 2..7: v8 variants for A/B measurements and timing probes (table in x2v_attn_fwd_bf16_vt)
-template <int KIND> struct V8Cfg { static constexpr int prio = 1, depth = 4, probe = 0; static constexpr bool late = true; };
-template <> struct V8Cfg<2> { static constexpr int prio = 1, depth = 4, probe = 0; static constexpr bool late = false; };
-template <> struct V8Cfg<3> { static constexpr int prio = 0, depth = 4, probe = 0; static constexpr bool late = true; };
-template <> struct V8Cfg<4> { static constexpr int prio = 1, depth = 2, probe = 0; static constexpr bool late = true; };
-template <> struct V8Cfg<5> { static constexpr int prio = 1, depth = 4, probe = 3; static constexpr bool late = true; };
-template <> struct V8Cfg<6> { static constexpr int prio = 1, depth = 4, probe = 1; static constexpr bool late = true; };
-template <> struct V8Cfg<7> { static constexpr int prio = 1, depth = 4, probe = 2; static constexpr bool late = true; };
-template <int NW, int THR, bool PRESCALED, int KIND>
-static int launch_attn_v6(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
+template <int NW, int THR, bool PRESCALED, int TUNE>
+static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                           int H, float scale, hipStream_t st) {
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (int64_t)AT_D * ldvt * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
-  auto kern = KIND == 1 ? attn_fwd_v6_kernel<NW, THR, PRESCALED>
-                        : attn_fwd_v8_kernel<NW, THR, PRESCALED, V8Cfg<KIND>::prio, V8Cfg<KIND>::depth, V8Cfg<KIND>::probe, V8Cfg<KIND>::late>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AT_K_BYTES), "attn attr");
-    if (rc != X2V_OK) return rc;
-    attr_set = true;
-  }
+  auto kern = attn_fwd_v8_kernel<NW, THR, PRESCALED, TUNE>;
+  int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
+  if (rc != X2V_OK) return rc;
   dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), 4 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
                      (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
@@ -1695,24 +685,22 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
               "attn_vt: rows must be 16-byte aligned, ldvt a multiple of 64");
   X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D, X2V_E_SHAPE, "attn_vt: token stride smaller than H*128");
   if (scale <= 0.f) scale = 0.08838834764831845f;
-  // bits 1-3 of the flag word pick a kernel for A/B measurements: 0 default (ping-pong, s_setprio in the matrix half-step, fragment
-  // prefetch depth 4, DMA issued by the vector-phase waves), 1 in-phase v6, 2 every wave issues DMA, 3 no s_setprio, 4 prefetch depth 2,
-  // 5/6/7 timing probes (no K/V movement after the first tile / no softmax / no matrix half-step: results invalid)
-  const int pre = q_prescaled & 1, kind = (q_prescaled >> 1) & 7;
-#define X2V_VT(K_)                                                                                                              \
-  case K_:                                                                                                                      \
-    return pre ? launch_attn_v6<8, 8, true, K_>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, (hipStream_t)stream)         \
-               : launch_attn_v6<8, 8, false, K_>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, (hipStream_t)stream);
+  // bit 0: q already carries scale*log2(e); bits 1.. select a kernel body for A/B measurements (0 = default)
+  const int pre = q_prescaled & 1, kind = q_prescaled >> 1;
+  hipStream_t st = (hipStream_t)stream;
   switch (kind) {
-    X2V_VT(0) X2V_VT(1) X2V_VT(2) X2V_VT(3) X2V_VT(4) X2V_VT(5) X2V_VT(6) X2V_VT(7)
+    case 0:
+      return pre ? launch_attn_vt<8, 8, true, X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
+                 : launch_attn_vt<8, 8, false, X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
+    case 1:
+      return pre ? launch_attn_vt<8, 8, true, 1 - X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
+                 : launch_attn_vt<8, 8, false, 1 - X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
+    default: set_error("attn_vt: unknown kernel selector %d", kind); return X2V_E_ARG;
   }
-#undef X2V_VT
-  return X2V_E_ARG;
 }
 
-// variant: 0 = default (= 6); v1 kernels: 1 = 4 waves, 2 = 8 waves, 3 = 4 waves + scalar-V validation path for the transpose read;
-// v2 software-pipelined kernels: 4 = 8 waves eager rescale, 5 = lazy rescale THR 4, 6 = lazy THR 8, 7 = 4 waves lazy THR 4;
-// v3 (scale folded into Q, running max as the MFMA C operand, x2-unrolled tile loop): 8 = THR 8, 9 = THR 4
+// variant: 0 = default (= 6); lazy-rescale threshold of the pipelined kernel: 4 = eager rescale (every tile), 5 = threshold 4, 6 = threshold 8
+// (base-2 units) — the three must agree to rounding (validation of the rare rescale branch)
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
                                          int64_t Sk, int H, int head_dim, float scale, int variant, void* stream) {
   if (Sq == 0 && Sk > 0 && H > 0) return X2V_OK;  // no query rows: nothing to write (empty shard)
@@ -1728,23 +716,8 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_variant(
   switch (variant) {
     case 0:
     case 6: return launch_attn_pipe<8, 8>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 2: return launch_attn<8, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 1: return launch_attn<4, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 3: return launch_attn<4, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 4: return launch_attn_pipe<8, -1>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     case 5: return launch_attn_pipe<8, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 7: return launch_attn_pipe<4, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 8: return launch_attn_v3<8, 8, false, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 9: return launch_attn_v3<8, 8, true, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 10: return launch_attn_v4<8, 8, false>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 9 | X2V_ATTN_Q_PRESCALED: return launch_attn_v3<8, 8, true, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 10 | X2V_ATTN_Q_PRESCALED: return launch_attn_v4<8, 8, true>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 101: return launch_attn_v4<8, 8, false, 1>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);  // timing probes, results invalid
-    case 102: return launch_attn_v4<8, 8, false, 2>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 104: return launch_attn_v4<8, 8, false, 4>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 105: return launch_attn_v4<8, 8, false, 5>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 106: return launch_attn_v4<8, 8, false, 6>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
-    case 103: return launch_attn_v4<8, 8, false, 3>(q, ldq, k, ldk, v, ldv, o, ldo, Sq, Sk, H, scale, st);
     default: set_error("attn: unknown variant %d", variant); return X2V_E_ARG;
   }
 }

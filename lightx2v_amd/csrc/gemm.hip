@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A
                                                       const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y, int64_t ldy, int64_t M,
                                                       int N, int nk, const unsigned short* __restrict__ resid, int64_t ldr,
                                                       const unsigned short* __restrict__ gate, const float* __restrict__ sx,
-                                                      const float* __restrict__ sw, int ntm, int ntn) {
+                                                      const float* __restrict__ sw, int ntm, int ntn, GemmBlocking gb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int a_kpb = gb.a_kpb > 0 && gb.a_kpb < nk ? gb.a_kpb : nk;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A
     char* as = smem + s * G_STAGE_BYTES + wid * (32 * 128);
     char* bs = as + GB_M * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_src[i] + (int64_t)kt * G_ROW_BYTES, as + i * 1024);
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + ((int64_t)(kt / a_kpb) * gb.a_cbs + (int64_t)(kt % a_kpb) * G_ROW_BYTES), as + i * 1024);  // K-blocked x
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(b_src[i] + (int64_t)kt * G_ROW_BYTES, bs + i * 1024);
   };
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const char* __restrict__ A
         }
         o = pack8(ov);
       }
-      *reinterpret_cast<uint4*>(Y + gm * ldy + gn) = o;
+      const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y
+      *reinterpret_cast<uint4*>(Y + gm * ldy + ycol) = o;
     }
   }
 }
@@ -254,24 +256,22 @@ namespace x2v {
 // gemm256.hip: the 256x256-tile ping-pong kernel for large shapes
 template <bool FP8>
 int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
-                     const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st);
+                     const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st, GemmBlocking gb);
 }  // namespace x2v
 
 using namespace x2v;
 
 template <bool FP8, int EPI>
 static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
-                       const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, hipStream_t st) {
+                       const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, hipStream_t st, GemmBlocking gb) {
   const int ntm = (int)((M + GB_M - 1) / GB_M), ntn = (N + GB_N - 1) / GB_N;
-  static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing threads set the same value
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)gemm_kernel<FP8, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES), "gemm attr");
+  {
+    int rc = ensure_dynamic_lds((const void*)gemm_kernel<FP8, EPI>, G_LDS_BYTES, "gemm attr");
     if (rc != X2V_OK) return rc;
-    attr_set = true;
   }
   hipLaunchKernelGGL((gemm_kernel<FP8, EPI>), dim3((unsigned)ntm * (unsigned)ntn), dim3(256), G_LDS_BYTES, st, (const char*)x, ldx_bytes, (const char*)w,
                      ldw_bytes, (const unsigned short*)bias, (unsigned short*)y, ldy, M, N, nk, (const unsigned short*)resid, ldr,
-                     (const unsigned short*)gate, sx, sw, ntm, ntn);
+                     (const unsigned short*)gate, sx, sw, ntm, ntn, gb);
   X2V_LAUNCH_CHECK("gemm launch");
   return X2V_OK;
 }
@@ -285,25 +285,26 @@ static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb) {
 }
 
 // variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel; bits 8..15 = m-tiles per scheduling
-// group of the 256x256 kernel (0 = default), bits 16.. = its schedule selector (tuning hook)
+// group of the 256x256 kernel (0 = default)
 template <bool FP8>
 static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N,
-                        int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int variant, hipStream_t st) {
+                        int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int variant, hipStream_t st,
+                        GemmBlocking gb = GemmBlocking()) {
   const int kind = variant & 0xff;
-  int gm_tiles = variant >> 8;
+  const int gm_tiles = (variant >> 8) & 0xff;
   const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
   if (kind == 2 && !fits256) {
     set_error("gemm: leading dimension too large for the 256x256 kernel");
     return X2V_E_SHAPE;
   }
   if (kind == 2 || (kind == 0 && choose_kernel(M, N, nk, ldxb, ldwb) == 2)) {
-    return gemm256_dispatch<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
+    return gemm256_dispatch<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st, gb);
   }
   switch (epilogue) {
-    case X2V_EPI_NONE: return launch_gemm<FP8, X2V_EPI_NONE>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
-    case X2V_EPI_GELU_TANH: return launch_gemm<FP8, X2V_EPI_GELU_TANH>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
-    case X2V_EPI_SILU: return launch_gemm<FP8, X2V_EPI_SILU>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st);
-    case X2V_EPI_RESIDUAL: return launch_gemm<FP8, X2V_EPI_RESIDUAL>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, st);
+    case X2V_EPI_NONE: return launch_gemm<FP8, X2V_EPI_NONE>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st, gb);
+    case X2V_EPI_GELU_TANH: return launch_gemm<FP8, X2V_EPI_GELU_TANH>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st, gb);
+    case X2V_EPI_SILU: return launch_gemm<FP8, X2V_EPI_SILU>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, st, gb);
+    case X2V_EPI_RESIDUAL: return launch_gemm<FP8, X2V_EPI_RESIDUAL>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, st, gb);
     default: set_error("gemm: unknown epilogue %d", epilogue); return X2V_E_ARG;
   }
 }

@@ -39,16 +39,16 @@ constexpr int T_LDS_BYTES = 256 * T_EPI_LD; // 135168 >= 8 * T_HALF_BYTES
 
 typedef __attribute__((address_space(3))) void* t_lds_ptr_t;
 
-template <bool FP8, int EPI, int LEAD, int KW, int SCHED, bool MX>
+template <bool FP8, int EPI, int LEAD, int KW, bool MX>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict__ A, int64_t lda_bytes, const char* __restrict__ W, int64_t ldw_bytes,
                                                          const unsigned short* __restrict__ bias, unsigned short* __restrict__ Y, int64_t ldy, int64_t M,
                                                          int N, int nk, const unsigned short* __restrict__ resid, int64_t ldr,
                                                          const unsigned short* __restrict__ gate, const float* __restrict__ sx,
                                                          const float* __restrict__ sw, int ntm, int ntn, int gm_tiles,
-                                                         const unsigned* __restrict__ SA, const unsigned* __restrict__ SB) {
+                                                         const unsigned* __restrict__ SA, const unsigned* __restrict__ SB, GemmBlocking gb) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(LEAD >= KW + 3 && LEAD <= 7, "see the hazard accounting in the header comment");
-  static_assert(!MX || (FP8 && SCHED == 0), "MX: block-scaled fp8");
+  static_assert(LEAD >= KW + 3 && LEAD <= 7 && LEAD >= 4, "see the hazard accounting in the header comment (and the A-half K offsets ak1/ak2)");
+  static_assert(!MX || FP8, "MX: block-scaled fp8");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -71,8 +71,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   // ---- buffer descriptors over this tile's valid rows (wave-uniform: kernel arguments + blockIdx only)
   const unsigned row_bytes = (unsigned)nk * 128u;
   const int rows_a = (int)min((int64_t)T_M, M - m0), rows_w = min(T_N, N - n0);
+  // K-blocked x (GemmBlocking, x2v_common.h): K-tile kt of a row lives at (kt / a_kpb) * a_cbs + (kt % a_kpb) * 128 bytes; the range covers
+  // the last block (rows past M of an earlier block alias the next block's rows: their results are never stored)
+  const int a_kpb = gb.a_kpb > 0 && gb.a_kpb < nk ? gb.a_kpb : nk;
+  const unsigned a_span = a_kpb < nk ? (unsigned)((nk - 1) / a_kpb) * gb.a_cbs + (unsigned)a_kpb * 128u : row_bytes;
   const __amdgpu_buffer_rsrc_t ra =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(A + m0 * lda_bytes), 0, (unsigned)((rows_a - 1) * lda_bytes) + row_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(A + m0 * lda_bytes), 0, (unsigned)((rows_a - 1) * lda_bytes) + a_span, 0x00020000);
+  // byte offsets of K-tiles t+1 and t+2 of x (the two tiles whose A halves the steady state issues) and their index within a K-block
+  unsigned ak1 = 0, ak2 = 0;
+  int akc1 = 0, akc2 = 0;
+#define T_AK_NEXT(OFF_, CNT_) { if (++(CNT_) == a_kpb) { (CNT_) = 0; (OFF_) += gb.a_cbs - (unsigned)(a_kpb - 1) * 128u; } else (OFF_) += 128u; }
+  T_AK_NEXT(ak1, akc1)
+  ak2 = ak1;
+  akc2 = akc1;
+  T_AK_NEXT(ak2, akc2)
+  const unsigned ak_first = ak1;  // tile 1, for the prologue
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * ldw_bytes), 0, (unsigned)((rows_w - 1) * ldw_bytes) + row_bytes, 0x00020000);
 
@@ -155,20 +168,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #define T_RD(DST_, SLOT_, RD_, EXTRA_) \
   _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) DST_[ks_] = *reinterpret_cast<const i32x4_t*>(smem + (SLOT_) * T_HALF_BYTES + (EXTRA_) + RD_[ks_]);
 
-  // 8 MFMAs (fp8: 4) of one phase.  SCHED 1: the phase's two DMA pieces are issued from inside the cluster (after
-  // MFMA #1 and #4), where they cost issue slots the matrix pipe hides, instead of lengthening the load segment.
-#define T_MFMA(MI0_, NJ_, WB_, DO_, J_, SLOT_, KOFF_)                                                                          \
+  // 8 MFMAs (fp8: 4) of one phase
+#define T_MFMA(MI0_, NJ_, WB_)                                                                                                 \
   if constexpr (!FP8) {                                                                                                        \
     _Pragma("unroll") for (int idx_ = 0; idx_ < 8; ++idx_) {                                                                   \
       const int ks_ = idx_ >> 1, i_ = idx_ & 1;                                                                                \
-      if (SCHED == 2 && (idx_ & 2)) continue; /* timing probe: half of the MFMAs (results invalid) */                            \
       acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WB_[ks_]),                  \
                                                                       __builtin_bit_cast(bf16x8_t, xa[i_][ks_]), acc[(MI0_) + i_][NJ_], 0, 0, 0); \
-      if (SCHED == 1 && (idx_ == 1 || idx_ == 4)) {                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
-        if (DO_) { if (idx_ == 1) { T_ISSUE1(J_, SLOT_, KOFF_, 0) } else { T_ISSUE1(J_, SLOT_, KOFF_, 1) } }                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
-      }                                                                                                                        \
     }                                                                                                                          \
   } else {                                                                                                                     \
     constexpr int kOne = 0x7f7f7f7f; /* e8m0 2^0 block scales */                                                               \
@@ -182,11 +188,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
         acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf_, xf_, acc[(MI0_) + i_][NJ_], 0, 0, 0, (int)sw_cur[NJ_], 0, (int)sx_cur[(MI0_) + i_]); \
       else                                                                                                                     \
         acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf_, xf_, acc[(MI0_) + i_][NJ_], 0, 0, 2, (int)sw_cur[NJ_], 2, (int)sx_cur[(MI0_) + i_]); \
-      if (SCHED == 1 && (idx_ == 0 || idx_ == 2)) {                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
-        if (DO_) { if (idx_ == 0) { T_ISSUE1(J_, SLOT_, KOFF_, 0) } else { T_ISSUE1(J_, SLOT_, KOFF_, 1) } }                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
-      }                                                                                                                        \
     }                                                                                                                          \
   }
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     if constexpr (MX && (Q_) == 0) {                                                                                           \
       if ((CHK_) ? (t + 1 < nk) : true) T_SC_LOAD(t + 1)                                                                        \
     }                                                                                                                          \
-    if (SCHED == 0 && live_) T_ISSUE(((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, (t + ((Q_) + LEAD) / 4) * 128)          \
+    if (live_) T_ISSUE(((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, ((((Q_) + LEAD) & 1) ? ((((Q_) + LEAD) / 4) == 1 ? ak1 : ak2) : (unsigned)((t + ((Q_) + LEAD) / 4) * 128)))          \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
     __builtin_amdgcn_s_barrier();                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
@@ -218,10 +219,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
        accumulators in place with empty asm statements on both sides of the cluster */                                       \
     T_PIN(((Q_) >> 1) * 2, (Q_) == 1 || (Q_) == 3)                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                             \
-    if constexpr ((Q_) == 0) { T_MFMA(0, 0, wb0, live_, ((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, (t + ((Q_) + LEAD) / 4) * 128) }      \
-    else if constexpr ((Q_) == 1) { T_MFMA(0, 1, wb1, live_, ((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, (t + ((Q_) + LEAD) / 4) * 128) } \
-    else if constexpr ((Q_) == 2) { T_MFMA(2, 0, wb0, live_, ((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, (t + ((Q_) + LEAD) / 4) * 128) } \
-    else { T_MFMA(2, 1, wb1, live_, ((Q_) + LEAD) & 3, ((TB_) * 4 + (Q_) + LEAD) & 7, (t + ((Q_) + LEAD) / 4) * 128) }                          \
+    if constexpr ((Q_) == 0) { T_MFMA(0, 0, wb0) }                                                                             \
+    else if constexpr ((Q_) == 1) { T_MFMA(0, 1, wb1) }                                                                        \
+    else if constexpr ((Q_) == 2) { T_MFMA(2, 0, wb0) }                                                                        \
+    else { T_MFMA(2, 1, wb1) }                                                                                                 \
     __builtin_amdgcn_s_setprio(0);                                                                                             \
     T_PIN(((Q_) >> 1) * 2, (Q_) == 1 || (Q_) == 3)                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
   }
 
+#define T_AK_ADVANCE() { ak1 = ak2; akc1 = akc2; T_AK_NEXT(ak2, akc2) }
   // ---- prologue: halves 0 .. LEAD-1 in flight, wait for B0 and A_a of K-tile 0, read B0
   {
     const int t = 0;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     if constexpr (MX) T_SC_LOAD(0)  // oldest loads in flight: complete after the prologue wait below
 #pragma unroll
     for (int g = 0; g < LEAD; ++g)
-      if (g < total) T_ISSUE(g & 3, g & 7, (g >> 2) * 128)
+      if (g < total) T_ISSUE(g & 3, g & 7, ((g & 1) ? ((g >> 2) ? ak_first : 0u) : (unsigned)((g >> 2) * 128)))
     // = the steady-state wait of "phase -1": leaves KW halves in flight, so B1 of K-tile 0 (read in phase 1 by the
     // wr = 0 waves, which see no later wait of the wr = 1 waves) has landed too
     if (total >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KW) : "memory");
@@ -259,25 +261,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     {
       const int t = tt;
       T_PHASE(0, 0, 0) T_PHASE(0, 1, 0) T_PHASE(0, 2, 0) T_PHASE(0, 3, 0)
+      T_AK_ADVANCE()
     }
     {
       const int t = tt + 1;
       T_PHASE(1, 0, 0) T_PHASE(1, 1, 0) T_PHASE(1, 2, 0) T_PHASE(1, 3, 0)
+      T_AK_ADVANCE()
     }
   }
   for (int tt = nmain; tt < nk; tt += 2) {
     {
       const int t = tt;
       T_PHASE(0, 0, 1) T_PHASE(0, 1, 1) T_PHASE(0, 2, 1) T_PHASE(0, 3, 1)
+      T_AK_ADVANCE()
     }
     if (tt + 1 < nk) {
       const int t = tt + 1;
       T_PHASE(1, 0, 1) T_PHASE(1, 1, 1) T_PHASE(1, 2, 1) T_PHASE(1, 3, 1)
+      T_AK_ADVANCE()
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups; every wave is past its last LDS read
   __builtin_amdgcn_sched_barrier(0);
 #undef T_PHASE
+#undef T_AK_ADVANCE
+#undef T_AK_NEXT
 #undef T_PIN
 #undef T_MFMA
 #undef T_RD
@@ -360,6 +368,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     const int64_t gmr = m0 + row;
     const int gn = n0 + cc * 8;
     if (gmr < M && gn < N) {
+      // N-blocked y (GemmBlocking): column block gn / y_cbw starts y_cbs elements after the previous one
+      const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;
       uint4 o = *reinterpret_cast<const uint4*>(smem + row * T_EPI_LD + cc * 16);
       if (EPI == X2V_EPI_RESIDUAL) {
         float yv[8], xv[8], ov[8];
@@ -376,59 +386,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
         }
         o = pack8(ov);
       }
-      *reinterpret_cast<uint4*>(Y + gmr * ldy + gn) = o;
+      *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = o;
     }
   }
 #endif
 }
 
-template <bool FP8, int EPI, int SCHED, bool MX = false>
-static int launch_gemm256_s(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N,
+template <bool FP8, int EPI, bool MX = false>
+static int launch_gemm256(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N,
                           int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st,
-                          const void* sa = nullptr, const void* sb = nullptr) {
+                          const void* sa = nullptr, const void* sb = nullptr, GemmBlocking gb = GemmBlocking()) {
   constexpr int LEAD = 6, KW = 3;
+  if (gm_tiles <= 0) gm_tiles = 4;  // m-tiles per scheduling group
   const int ntm = (int)((M + T_M - 1) / T_M), ntn = (N + T_N - 1) / T_N;
-  static bool attr_set = false;  // idempotent; racing threads set the same value
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)gemm256_kernel<FP8, EPI, LEAD, KW, SCHED, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES),
-                       "gemm256 attr");
+  {
+    int rc = ensure_dynamic_lds((const void*)gemm256_kernel<FP8, EPI, LEAD, KW, MX>, T_LDS_BYTES, "gemm256 attr");
     if (rc != X2V_OK) return rc;
-    attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<FP8, EPI, LEAD, KW, SCHED, MX>), dim3((unsigned)ntm * (unsigned)ntn), dim3(512), T_LDS_BYTES, st, (const char*)x, ldx_bytes,
+  hipLaunchKernelGGL((gemm256_kernel<FP8, EPI, LEAD, KW, MX>), dim3((unsigned)ntm * (unsigned)ntn), dim3(512), T_LDS_BYTES, st, (const char*)x, ldx_bytes,
                      (const char*)w, ldw_bytes, (const unsigned short*)bias, (unsigned short*)y, ldy, M, N, nk, (const unsigned short*)resid, ldr,
-                     (const unsigned short*)gate, sx, sw, ntm, ntn, gm_tiles, (const unsigned*)sa, (const unsigned*)sb);
+                     (const unsigned short*)gate, sx, sw, ntm, ntn, gm_tiles, (const unsigned*)sa, (const unsigned*)sb, gb);
   X2V_LAUNCH_CHECK("gemm256 launch");
   return X2V_OK;
-}
-
-template <bool FP8, int EPI>
-static int launch_gemm256(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N,
-                          int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st) {
-  // gm_tiles bits 8..: schedule selector (tuning hook): 0 = default (DMA issued in the load segment; measured 1-2 %
-  // ahead on the Wan-14B shapes), 1 = DMA issued from inside the MFMA cluster; timing probes with INVALID results (bf16, plain
-  // epilogue only): 2 = half of the MFMAs, 3 = no operand DMA after the prologue
-  const int sched = gm_tiles >> 8;
-  gm_tiles &= 0xff;
-  if (gm_tiles == 0) gm_tiles = 4;
-  if constexpr (!FP8 && EPI == X2V_EPI_NONE) {
-    if (sched == 2) return launch_gemm256_s<FP8, EPI, 2>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
-    if (sched == 3) return launch_gemm256_s<FP8, EPI, 3>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
-  }
-  if (sched == 1) return launch_gemm256_s<FP8, EPI, 1>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
-  return launch_gemm256_s<FP8, EPI, 0>(x, ldx_bytes, w, ldw_bytes, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
 }
 
 // Called by gemm.hip's dispatcher (arguments already validated there).  ld*_bytes < 16 MiB is required (32-bit
 // buffer offsets over a 256-row tile) and checked by the caller.
 template <bool FP8>
 int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
-                     const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st) {
+                     const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st, GemmBlocking gb) {
   switch (epilogue) {
-    case X2V_EPI_NONE: return launch_gemm256<FP8, X2V_EPI_NONE>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, gm_tiles, st);
-    case X2V_EPI_GELU_TANH: return launch_gemm256<FP8, X2V_EPI_GELU_TANH>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, gm_tiles, st);
-    case X2V_EPI_SILU: return launch_gemm256<FP8, X2V_EPI_SILU>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, gm_tiles, st);
-    case X2V_EPI_RESIDUAL: return launch_gemm256<FP8, X2V_EPI_RESIDUAL>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st);
+    case X2V_EPI_NONE: return launch_gemm256<FP8, X2V_EPI_NONE>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, gm_tiles, st, nullptr, nullptr, gb);
+    case X2V_EPI_GELU_TANH: return launch_gemm256<FP8, X2V_EPI_GELU_TANH>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, gm_tiles, st, nullptr, nullptr, gb);
+    case X2V_EPI_SILU: return launch_gemm256<FP8, X2V_EPI_SILU>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, sx, sw, gm_tiles, st, nullptr, nullptr, gb);
+    case X2V_EPI_RESIDUAL: return launch_gemm256<FP8, X2V_EPI_RESIDUAL>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st, nullptr, nullptr, gb);
     default: set_error("gemm: unknown epilogue %d", epilogue); return X2V_E_ARG;
   }
 }
@@ -436,17 +427,17 @@ int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, i
 int gemm256_mx_dispatch(int epilogue, const void* a, int64_t lda, const void* sa, const void* b, int64_t ldb, const void* sb, const void* bias, const float* alpha,
                         void* y, int64_t ldy, int64_t M, int N, int nk, const void* resid, int64_t ldr, const void* gate, hipStream_t st) {
   switch (epilogue) {
-    case X2V_EPI_NONE: return launch_gemm256_s<true, X2V_EPI_NONE, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
-    case X2V_EPI_GELU_TANH: return launch_gemm256_s<true, X2V_EPI_GELU_TANH, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
-    case X2V_EPI_SILU: return launch_gemm256_s<true, X2V_EPI_SILU, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
-    case X2V_EPI_RESIDUAL: return launch_gemm256_s<true, X2V_EPI_RESIDUAL, 0, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, resid, ldr, gate, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_NONE: return launch_gemm256<true, X2V_EPI_NONE, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_GELU_TANH: return launch_gemm256<true, X2V_EPI_GELU_TANH, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_SILU: return launch_gemm256<true, X2V_EPI_SILU, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, nullptr, 0, nullptr, alpha, nullptr, 4, st, sa, sb);
+    case X2V_EPI_RESIDUAL: return launch_gemm256<true, X2V_EPI_RESIDUAL, true>(a, lda, b, ldb, bias, y, ldy, M, N, nk, resid, ldr, gate, alpha, nullptr, 4, st, sa, sb);
     default: set_error("gemm_mxfp8: unknown epilogue %d", epilogue); return X2V_E_ARG;
   }
 }
 
 template int gemm256_dispatch<false>(int, const void*, int64_t, const void*, int64_t, const void*, void*, int64_t, int64_t, int, int, const void*, int64_t,
-                                     const void*, const float*, const float*, int, hipStream_t);
+                                     const void*, const float*, const float*, int, hipStream_t, GemmBlocking);
 template int gemm256_dispatch<true>(int, const void*, int64_t, const void*, int64_t, const void*, void*, int64_t, int64_t, int, int, const void*, int64_t,
-                                    const void*, const float*, const float*, int, hipStream_t);
+                                    const void*, const float*, const float*, int, hipStream_t, GemmBlocking);
 
 }  // namespace x2v

@@ -283,11 +283,9 @@ static int gemm_mxfp8_impl(const void* a, int64_t lda, const void* sa, const voi
     X2V_REQUIRE(resid != nullptr && ldr % 8 == 0 && ldr >= N && aligned16(resid) && (gate == nullptr || aligned16(gate)), X2V_E_ALIGN,
                 "gemm_mxfp8: residual epilogue needs a 16-byte aligned residual (and gate)");
   if (big) return gemm256_mx_dispatch(epilogue, a, lda, sa, b, ldb, sb, bias, alpha, y, ldy, M, N, K / 128, resid, ldr, gate, (hipStream_t)stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)gemm_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES), "gemm_mxfp8 attr");
+  {
+    int rc = ensure_dynamic_lds((const void*)gemm_mxfp8_kernel, MX_LDS_BYTES, "gemm_mxfp8 attr");
     if (rc != X2V_OK) return rc;
-    attr_set = true;
   }
   const int ntm = (int)((M + MX_M - 1) / MX_M), ntn = (N + MX_N - 1) / MX_N;
   hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3((unsigned)ntm * (unsigned)ntn), dim3(256), MX_LDS_BYTES, (hipStream_t)stream, (const char*)a, lda,

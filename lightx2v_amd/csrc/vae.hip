@@ -837,11 +837,9 @@ template <int NF, int KC>
 static int launch_vconv(const float* xp, int64_t fs, int64_t rs, int64_t ps, const float* w, int64_t wrs, const float* bias, const float* resid, float* y,
                         int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, hipStream_t st) {
   constexpr int lds = 2 * (VC_PIX + 32 * NF) * KC * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)vae_conv_kernel<NF, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "vae conv attr");
+  {
+    int rc = ensure_dynamic_lds((const void*)vae_conv_kernel<NF, KC>, lds, "vae conv attr");
     if (rc != X2V_OK) return rc;
-    attr_set = true;
   }
   const int64_t ptiles = (int64_t)T * (((int64_t)Hh * Ww + VC_PIX - 1) / VC_PIX);
   const int ncol = (Cout + 32 * NF - 1) / (32 * NF);
@@ -983,11 +981,9 @@ template <int NF>
 static int launch_vconv16(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
                           int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, hipStream_t st) {
   constexpr int lds = 2 * (VC_PIX + 32 * NF) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)vae_conv16_kernel<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "vae conv16 attr");
+  {
+    int rc = ensure_dynamic_lds((const void*)vae_conv16_kernel<NF>, lds, "vae conv16 attr");
     if (rc != X2V_OK) return rc;
-    attr_set = true;
   }
   const int64_t ptiles = (int64_t)T * (((int64_t)Hh * Ww + VC_PIX - 1) / VC_PIX);
   const int ncol = (Cout + 32 * NF - 1) / (32 * NF);
@@ -1002,11 +998,9 @@ template <int NF>
 static int launch_vconv16h(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
                            int Ww, int Cin, int Cout, int kt, int flags, hipStream_t st) {
   constexpr int lds = 2 * VH_A_BYTES + 2 * 32 * NF * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)vae_conv16h_kernel<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "vae conv16h attr");
+  {
+    int rc = ensure_dynamic_lds((const void*)vae_conv16h_kernel<NF>, lds, "vae conv16h attr");
     if (rc != X2V_OK) return rc;
-    attr_set = true;
   }
   const int tiles_x = (Ww + VH_TW - 1) / VH_TW, tiles_y = (Hh + VH_TH - 1) / VH_TH;
   const int ncol = (Cout + 32 * NF - 1) / (32 * NF);

@@ -3,6 +3,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "x2v_common.h"
 
 namespace x2v {
@@ -23,6 +27,21 @@ int check_hip(hipError_t e, const char* what) {
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: remember what was raised per (kernel, device), not per process.
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* what) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> raised;
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), what);
+  if (rc != X2V_OK) return rc;
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = raised[std::make_pair(kernel, dev)];
+  if (have >= bytes) return X2V_OK;
+  rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+  if (rc == X2V_OK) have = bytes;
+  return rc;
+}
 
 }  // namespace x2v
 

@@ -22,6 +22,8 @@ constexpr int kWave = 64;  // CDNA wavefront width
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 bool aligned16(const void* p);
+// Raise a kernel's dynamic-LDS cap to `bytes` on the current device (once per kernel and device; thread-safe).
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
 
 #define X2V_REQUIRE(cond, code, ...) \
   do {                               \
@@ -36,6 +38,17 @@ bool aligned16(const void* p);
     int _rc = ::x2v::check_hip(hipGetLastError(), what);            \
     if (_rc != X2V_OK) return _rc;                                  \
   } while (0)
+
+// Block addressing of the GEMM kernels (x2v_gemm_bf16_blocked): x may be stored as K-blocks — K-tile kt (128 bytes of a row) at
+// (kt / a_kpb) * a_cbs + (kt % a_kpb) * 128 bytes from the row's start — and y as N-blocks — column n at (n / y_cbw) * y_cbs + n % y_cbw
+// elements from the row's start.  These are the [N_ranks][S/N][(H/N)d] buffers of the Ulysses exchanges read / written in place.
+// a_kpb <= 0 / y_cbw <= 0: plain row-major.
+struct GemmBlocking {
+  int a_kpb = 0;        // K-tiles (128 B) per x block
+  unsigned a_cbs = 0;   // bytes between x blocks
+  int y_cbw = 0;        // columns per y block (a multiple of 8)
+  int64_t y_cbs = 0;    // elements between y blocks
+};
 
 // ---- bf16 <-> fp32 (device) -------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }

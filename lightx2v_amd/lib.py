@@ -177,9 +177,9 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
 
 
 ATTN_Q_PRESCALED = 0x100
-ATTN_V3 = 9  # v3 kernel, x2-unrolled (include/x2v.h)
 ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
 #                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
+ATTN_FAST_ALT = 13  # the same entry's alternative kernel body (A/B measurements; include/x2v.h)
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
 
 
@@ -289,14 +289,14 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
     init()
     if Sq == 0:
         return out2
-    if (variant & 0xFF) == ATTN_FAST:
+    if (variant & 0xFF) in (ATTN_FAST, ATTN_FAST_ALT):
         if vt is None:
             vt = transpose_heads(v2, num_heads)
         elif vt.dtype != torch.bfloat16 or not vt.is_cuda or not vt.is_contiguous() or tuple(vt.shape) != (num_heads, (Sk + 63) // 64, 128, 64):
             raise X2VError(f"attention: vt must be the contiguous bf16 [H, ceil(Sk/64), 128, 64] tensor of transpose_heads, got {tuple(vt.shape)}")
         _check(
             _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[1] * 64, _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
-                                      1 if (variant & ATTN_Q_PRESCALED) else 0, _stream()),
+                                      (1 if (variant & ATTN_Q_PRESCALED) else 0) | (((variant & 0xFF) - ATTN_FAST) << 1), _stream()),
             "attn_fwd_vt",
         )
         return out2

@@ -591,7 +591,7 @@ static void run_gemm() {
     int bad_runs = 0;
     ErrStat worst{};
     for (int run = 0; run < 20; ++run) {
-      X2V_OKAY(x2v_gemm_bf16_variant(dx.p, K, dw.p, K, nullptr, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, 2 | ((1 + run % 4) << 8) | ((run & 4) << 14), nullptr));
+      X2V_OKAY(x2v_gemm_bf16_variant(dx.p, K, dw.p, K, nullptr, dy.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, 2 | ((1 + run % 4) << 8), nullptr));
       HIP_OK(hipDeviceSynchronize());
       ErrStat e = compare(to_f(dy.host()), ref, 0, 0);
       if (e.bad) { ++bad_runs; worst = e; }
@@ -631,7 +631,7 @@ static void ref_attn(const std::vector<uint16_t>& q, const std::vector<uint16_t>
     }
 }
 
-// variant 11 = pre-transposed V path (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); everything else goes to the variant entry
+// variants 12, 13 = pre-transposed V path (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt, kernel selector 0 / 1); everything else goes to the variant entry
 struct AttnVt {
   DevBuf<uint16_t>* vt = nullptr;
   int64_t ldvt = 0;
@@ -644,8 +644,8 @@ struct AttnVt {
   }
 };
 static void attn_any(int variant, AttnVt& t, const void* q, const void* k, const void* v, void* o, int64_t Sq, int64_t Sk, int H) {
-  if (variant >= 11 && variant <= 18) {  // 11: in-phase v6; 12: the _vt default (v8 ping-pong); 13..15: v8 A/B kinds 2..4; 17/18: timing probes
-    const int kind = variant == 11 ? 1 : variant == 12 ? 0 : variant - 11;
+  if (variant == 12 || variant == 13) {  // 12: the _vt default (ping-pong); 13: its A/B alternative body
+    const int kind = variant - 12;
     X2V_OKAY(x2v_attn_fwd_bf16_vt(q, H * 128, k, H * 128, t.vt->p, t.ldvt, o, H * 128, Sq, Sk, H, 128, 0.f, kind << 1, nullptr));
   }
   else
@@ -668,7 +668,7 @@ static void run_attn() {
     ref_attn(q, k, v, sh.Sq, sh.Sk, sh.H, ref);
     AttnVt vt;
     vt.prepare(dv.p, sh.H * 128, sh.Sk, sh.H);
-    for (int variant = 0; variant <= 15; ++variant) {
+    for (int variant : {0, 4, 5, 6, 12, 13}) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, sh.Sq, sh.Sk, sh.H);
       HIP_OK(hipDeviceSynchronize());
@@ -695,7 +695,7 @@ static void run_attn() {
     ref_attn(q, k, v, S, S, H, ref);
     AttnVt vt;
     vt.prepare(dv.p, H * 128, S, H);
-    for (int variant : {6, 8, 9, 10, 11, 12, 13, 14, 15}) {
+    for (int variant : {4, 6, 12, 13}) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, S, S, H);
       HIP_OK(hipDeviceSynchronize());
@@ -703,7 +703,7 @@ static void run_attn() {
       snprintf(name, sizeof name, "attn anti-aligned keys + late spike variant=%d", variant);
       // v3/v4 round Q * scale * log2(e) to bf16 once more (relative 2^-9); keys 12x larger than any real (normalised) key
       // amplify that to ~0.03 in the exponent where the spike and the 299 other keys carry comparable weight
-      report(name, compare(to_f(dout.host()), ref, variant >= 8 ? 6e-2 : 6e-3, 0.016), 0.0);
+      report(name, compare(to_f(dout.host()), ref, variant >= 12 ? 6e-2 : 6e-3, 0.016), 0.0);
     }
   }
   // strided (fused-QKV style) views: ld = 3*H*128
@@ -904,13 +904,13 @@ static void run_bench(bool big) {
     fill_random(gate, rng, 0.5f);
     fill_random(y, rng, 1.f);
     const int iters = g.M * (double)g.N * g.K > 1e13 ? 3 : 10;
-    for (int variant : {1, 2 | (4 << 8) | (1 << 16), 2 | (4 << 8), 2 | (8 << 8)}) {
+    for (int variant : {1, 2 | (4 << 8), 2 | (8 << 8)}) {
       double ms = time_ms(iters, [&] {
         X2V_OKAY(x2v_gemm_bf16_variant(x.p, g.K, w.p, g.K, b.p, y.p, g.N, g.M, g.N, g.K, g.epi, g.epi == X2V_EPI_RESIDUAL ? y.p : nullptr, g.N,
                                        g.epi == X2V_EPI_RESIDUAL ? gate.p : nullptr, variant, nullptr));
       });
       const double tf = 2.0 * g.M * g.N * g.K / (ms * 1e-3) / 1e12;
-      printf("BENCH gemm_bf16 v=%d gm=%d sched=%d %-42s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)\n", variant & 255, (variant >> 8) & 255, variant >> 16, g.name, ms, tf, tf / 25.0);
+      printf("BENCH gemm_bf16 v=%d gm=%d %-42s %9.3f ms  %8.1f TFLOP/s  (%.1f%% of 2500)\n", variant & 255, (variant >> 8) & 255, g.name, ms, tf, tf / 25.0);
     }
   }
   if (big) {  // fp8 w8a8 GEMMs (config #4) on the 14B shapes
@@ -959,7 +959,7 @@ static void run_bench(bool big) {
       double ms = time_ms(5, [&] { X2V_OKAY(x2v_transpose_heads_bf16(v.p, a.H * 128, vt.vt->p, vt.ldvt, a.Sk, a.H, nullptr)); });
       printf("BENCH transpose_heads %-40s %9.3f ms  %8.1f GB/s\n", a.name, ms, 4.0 * a.Sk * a.H * 128 / ms / 1e6);
     }
-    for (int variant : {6, 9, 11, 12}) {
+    for (int variant : {6, 12, 13}) {
       const double flop = 4.0 * a.Sq * a.Sk * a.H * 128;
       const int iters = flop > 2e13 ? 1 : 5;
       double ms = time_ms(iters, [&] { attn_any(variant, vt, q.p, k.p, v.p, o.p, a.Sq, a.Sk, a.H); });
