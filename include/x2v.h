@@ -92,6 +92,13 @@ int x2v_rmsnorm_rope_scaled_bf16_variant(void* q, int64_t ldq, void* k, int64_t 
                                          int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode, float q_out_scale, int variant,
                                          void* stream);
 
+/* x2v_rmsnorm_rope_scaled_bf16 out of place into N-blocked outputs: q/k [S, H*128] are read, column e of token s is written to
+ * q_out / k_out[(e / block_cols) * block_stride + s * ldo + e % block_cols] — the seq->head send buffer [N_ranks][S/N][(H/N) d] of the
+ * Ulysses exchange (block_cols = (H/N)*128), replacing the reference's view + transpose + contiguous copy (all2all.py:29-33). */
+int x2v_rmsnorm_rope_blocked_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, void* q_out, void* k_out,
+                                  int64_t ldo, int block_cols, int64_t block_stride, int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps, int round_mode,
+                                  float q_out_scale, void* stream);
+
 /* In-place per-head RMSNorm (d = 128) of q and k [L, H*128] (token strides ldq/ldk, e.g. the column blocks of a fused
  * QKV GEMM output), followed for tokens < l_rope by the real-valued RoPE x*cos + rotate_half(x)*sin with bf16 tables
  * cos/sin [l_rope, 128] — replaces RMSWeightSgl.apply on [L,H,128] (rms_norm_weight.py:102-113; hunyuan
@@ -121,6 +128,18 @@ int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
  * 256x256 kernel (0 = default). */
 int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                           int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream);
+
+/* x2v_gemm_bf16 on block-strided operands — what lets the Ulysses exchange buffers (attentions/distributed/comm/all2all.py:6-89) be GEMM
+ * operands in place instead of being transposed by copies (all2all.py:29-33, :70-75,87):
+ *   x K-blocked (x_kblock > 0): element k of row m at x[(k / x_kblock) * x_kblock_stride + m * ldx + k % x_kblock] — the received
+ *     head->seq buffer [N_ranks][S/N][(H/N) d] read as the [S/N, H d] input of the output projection (x_kblock = (H/N) d, a multiple
+ *     of 64 elements dividing K; ldx >= x_kblock);
+ *   y N-blocked (y_nblock > 0): column n of row m at y[(n / y_nblock) * y_nblock_stride + m * ldy + n % y_nblock] — the q/k/v projection
+ *     writing straight into the seq->head send buffer [N_ranks][S/N][(H/N) d] (y_nblock a multiple of 8 dividing N; ldy >= y_nblock;
+ *     not with X2V_EPI_RESIDUAL).
+ * 0 disables either blocking (plain row-major).  The kernel is chosen by shape as in x2v_gemm_bf16. */
+int x2v_gemm_bf16_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kblock_stride, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy,
+                          int y_nblock, int64_t y_nblock_stride, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
 
 /* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape: 1 = the
  * 128x128 kernel, 2 = the 256x256 ping-pong kernel (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it
@@ -169,6 +188,11 @@ int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, i
 int x2v_gemm_fp8_variant(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                          int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, int variant,
                          void* stream);
+
+/* x2v_gemm_fp8 on block-strided operands (see x2v_gemm_bf16_blocked; x_kblock in e4m3 elements = bytes, a multiple of 128; sx stays [M]). */
+int x2v_gemm_fp8_blocked(const void* xq, int64_t ldx, int x_kblock, int64_t x_kblock_stride, const float* sx, const void* wq, int64_t ldw, const float* sw,
+                         const void* bias, void* y, int64_t ldy, int y_nblock, int64_t y_nblock_stride, int64_t M, int N, int K, int epilogue, const void* resid,
+                         int64_t ldr, const void* gate, void* stream);
 
 /* MXFP8 (OCP microscaling) activation / weight quantisation — replaces lightx2v_kernel.gemm.scaled_fp8_quant
  * (lightx2v_kernel/python/lightx2v_kernel/gemm.py:73-83, csrc/gemm/mxfp8_quant_kernels_sm120.cu:139-196): per 32 consecutive K

@@ -335,6 +335,57 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16_variant(cons
   return dispatch_epi<false>(epilogue, x, ldx * 2, w, ldw * 2, bias, y, ldy, M, N, K / GB_K, resid, ldr, gate, nullptr, nullptr, variant, (hipStream_t)stream);
 }
 
+static int check_blocking(const char* who, int K_bytes_per_row, int64_t x_kblock_bytes, int64_t x_kblock_stride_bytes, int N, int y_nblock, int64_t y_nblock_stride, int epilogue,
+                          GemmBlocking* gb) {
+  if (x_kblock_bytes > 0) {
+    X2V_REQUIRE(x_kblock_bytes % 128 == 0 && K_bytes_per_row % x_kblock_bytes == 0 && x_kblock_stride_bytes % 16 == 0 && x_kblock_stride_bytes > 0 &&
+                    x_kblock_stride_bytes < (1ll << 31),
+                X2V_E_SHAPE, "%s: x K-block of %lld bytes must be a multiple of 128 dividing the row; block stride a multiple of 16 bytes", who, (long long)x_kblock_bytes);
+    gb->a_kpb = (int)(x_kblock_bytes / 128);
+    gb->a_cbs = (unsigned)x_kblock_stride_bytes;
+  }
+  if (y_nblock > 0) {
+    X2V_REQUIRE(y_nblock % 8 == 0 && N % y_nblock == 0 && y_nblock_stride % 8 == 0, X2V_E_SHAPE, "%s: y N-block of %d columns must be a multiple of 8 dividing N=%d", who, y_nblock, N);
+    X2V_REQUIRE(epilogue != X2V_EPI_RESIDUAL, X2V_E_ARG, "%s: the residual epilogue reads y's layout from resid: not available with an N-blocked y", who);
+    gb->y_cbw = y_nblock;
+    gb->y_cbs = y_nblock_stride;
+  }
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kblock_stride, const void* w, int64_t ldw,
+                                                                            const void* bias, void* y, int64_t ldy, int y_nblock, int64_t y_nblock_stride, int64_t M, int N,
+                                                                            int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
+  X2V_REQUIRE(x && w && y, X2V_E_ARG, "gemm_bf16_blocked: null pointer");
+  X2V_REQUIRE(K > 0 && K % GB_K == 0, X2V_E_SHAPE, "gemm_bf16_blocked: K=%d must be a positive multiple of %d", K, GB_K);
+  X2V_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && aligned16(x) && aligned16(w), X2V_E_ALIGN, "gemm_bf16_blocked: operand rows must be 16-byte aligned");
+  X2V_REQUIRE(ldx >= (x_kblock > 0 ? x_kblock : K) && ldw >= K, X2V_E_SHAPE, "gemm_bf16_blocked: leading dimension smaller than the row");
+  int rc = check_common("gemm_bf16_blocked", y, ldy, M, y_nblock > 0 ? y_nblock : N, bias, epilogue, resid, ldr, gate);
+  if (rc != X2V_OK) return rc;
+  GemmBlocking gb;
+  rc = check_blocking("gemm_bf16_blocked", K * 2, (int64_t)x_kblock * 2, x_kblock_stride * 2, N, y_nblock, y_nblock_stride, epilogue, &gb);
+  if (rc != X2V_OK) return rc;
+  if (M == 0) return X2V_OK;
+  return dispatch_epi<false>(epilogue, x, ldx * 2, w, ldw * 2, bias, y, ldy, M, N, K / GB_K, resid, ldr, gate, nullptr, nullptr, 0, (hipStream_t)stream, gb);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8_blocked(const void* xq, int64_t ldx, int x_kblock, int64_t x_kblock_stride, const float* sx, const void* wq,
+                                                                           int64_t ldw, const float* sw, const void* bias, void* y, int64_t ldy, int y_nblock,
+                                                                           int64_t y_nblock_stride, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr,
+                                                                           const void* gate, void* stream) {
+  X2V_REQUIRE(xq && wq && y && sx && sw, X2V_E_ARG, "gemm_fp8_blocked: null pointer");
+  X2V_REQUIRE(K > 0 && K % 128 == 0, X2V_E_SHAPE, "gemm_fp8_blocked: K=%d must be a positive multiple of 128", K);
+  X2V_REQUIRE(ldx % 16 == 0 && ldw % 16 == 0 && aligned16(xq) && aligned16(wq) && aligned16(sw), X2V_E_ALIGN, "gemm_fp8_blocked: operand rows must be 16-byte aligned");
+  X2V_REQUIRE(ldx >= (x_kblock > 0 ? x_kblock : K) && ldw >= K, X2V_E_SHAPE, "gemm_fp8_blocked: leading dimension smaller than the row");
+  int rc = check_common("gemm_fp8_blocked", y, ldy, M, y_nblock > 0 ? y_nblock : N, bias, epilogue, resid, ldr, gate);
+  if (rc != X2V_OK) return rc;
+  GemmBlocking gb;
+  rc = check_blocking("gemm_fp8_blocked", K, x_kblock, x_kblock_stride, N, y_nblock, y_nblock_stride, epilogue, &gb);
+  if (rc != X2V_OK) return rc;
+  if (M == 0) return X2V_OK;
+  return dispatch_epi<true>(epilogue, xq, ldx, wq, ldw, bias, y, ldy, M, N, K / 128, resid, ldr, gate, sx, sw, 0, (hipStream_t)stream, gb);
+}
+
 extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                              int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
   return x2v_gemm_bf16_variant(x, ldx, w, ldw, bias, y, ldy, M, N, K, epilogue, resid, ldr, gate, 0, stream);

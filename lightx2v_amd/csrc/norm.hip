@@ -151,6 +151,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
   }
 }
 
+// Where the q|k norm+RoPE kernels write a row: in place (qo == nullptr), or out of place into N-blocked buffers — column e of token
+// `row` at (e / cbw) * cbs + row * ldo + e % cbw: the [N_ranks][S/N][(H/N) d] send buffer of the Ulysses seq->head exchange
+// (x2v_rmsnorm_rope_blocked_bf16), so no transposing copy stands between this kernel and the all-to-all.
+struct RopeOut {
+  unsigned short* qo = nullptr;
+  unsigned short* ko = nullptr;
+  int64_t ldo = 0, cbs = 0;
+  int cbw = 0;
+  __device__ __forceinline__ unsigned short* dst(int which, int64_t row, int e, unsigned short* inplace_row) const {
+    if (qo == nullptr) return inplace_row + e;
+    return (which == 0 ? qo : ko) + (int64_t)(e / cbw) * cbs + row * ldo + e % cbw;
+  }
+};
+
 // One complex rotation (a + i b) * (co + i si), then the optional output scale — written with explicit fused multiply-adds so every
 // kernel that rotates (per-row and streaming forms) rounds identically whatever the optimiser would contract on its own.
 __device__ __forceinline__ void rope_pair(float a, float bb, float co, float si, float oscale, float& o0, float& o1) {
@@ -164,7 +178,7 @@ template <int CH, int ROUND>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
                                                            const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
                                                            const float2* __restrict__ cs, int64_t S, int D, int64_t s0, int gf, int gh, int gw,
-                                                           float eps, float q_out_scale) {
+                                                           float eps, float q_out_scale, RopeOut ro) {
   __shared__ float red[4];
   const int t = threadIdx.x;
   const int64_t row = blockIdx.x;
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(unsigned short* __res
       }
       rope_pair(xn[2 * p], xn[2 * p + 1], co, si, oscale, o[2 * p], o[2 * p + 1]);
     }
-    *reinterpret_cast<uint4*>(base + e) = pack8(o);
+    *reinterpret_cast<uint4*>(ro.dst(blockIdx.y, row, e, base)) = pack8(o);
   }
 }
 
@@ -348,7 +362,7 @@ template <int CH, int ROUND>
 __global__ __launch_bounds__(256) void rmsnorm_rope_stream_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
                                                                   const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
                                                                   const float2* __restrict__ cs, int64_t S, int D, int64_t s0, int gf, int gh, int gw,
-                                                                  float eps, float q_out_scale) {
+                                                                  float eps, float q_out_scale, RopeOut ro) {
   __shared__ float red[4];
   __shared__ __attribute__((aligned(16))) float2 tab[2][64];  // by row parity: staging row n+1 never races readers of row n
   const int t = threadIdx.x;
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_stream_kernel(unsigned short
         const float co[4] = {f01.x, f01.z, f23.x, f23.z}, si[4] = {f01.y, f01.w, f23.y, f23.w};
 #pragma unroll
         for (int p = 0; p < 4; ++p) rope_pair(xn[2 * p], xn[2 * p + 1], co[p], si[p], oscale, o[2 * p], o[2 * p + 1]);
-        *reinterpret_cast<uint4*>(base + e) = pack8(o);
+        *reinterpret_cast<uint4*>(ro.dst(which, row, e, base)) = pack8(o);
       }
 #pragma unroll
       for (int c = 0; c < CH; ++c) cur[c] = nxt[c];
@@ -683,9 +697,8 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_bf16(void
   return x2v_rmsnorm_rope_scaled_bf16(q, ldq, k, ldk, wq, wk, rope_cs, S, H, s0, gf, gh, gw, eps, round_mode, 1.0f, stream);
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16_variant(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk,
-                                                                                           const void* rope_cs, int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps,
-                                                                                           int round_mode, float q_out_scale, int variant, void* stream) {
+static int rmsnorm_rope_impl(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs, int64_t S, int H, int64_t s0, int gf, int gh,
+                             int gw, float eps, int round_mode, float q_out_scale, int variant, RopeOut ro, void* stream) {
   X2V_REQUIRE(q && k && rope_cs, X2V_E_ARG, "rmsnorm_rope: null pointer");
   X2V_REQUIRE(variant >= 0 && variant <= 2, X2V_E_ARG, "rmsnorm_rope: unknown variant %d", variant);
   X2V_REQUIRE(q_out_scale > 0.f, X2V_E_ARG, "rmsnorm_rope: q_out_scale must be positive");
@@ -710,7 +723,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf
       // persistent form for long inputs (bit-identical results; see rmsnorm_rope_stream_kernel)
       auto go = [&](auto kern, int resident) {
         if (variant == 1 || resident <= 0 || (variant == 0 && S < 2 * (int64_t)resident)) return;
-        hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(S, resident)), dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
+        hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(S, resident)), dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale, ro);
         streamed = true;
       };
       if (round_mode == X2V_ROUND_REF) go(rmsnorm_rope_stream_kernel<CH, X2V_ROUND_REF>, resident_blocks<rmsnorm_rope_stream_kernel<CH, X2V_ROUND_REF>>());
@@ -718,14 +731,37 @@ extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf
     }
     if (streamed) return;
     if (round_mode == X2V_ROUND_REF)
-      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_REF>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
+      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_REF>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale, ro);
     else
-      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_FP32>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale);
+      hipLaunchKernelGGL((rmsnorm_rope_kernel<CH, X2V_ROUND_FP32>), grid, dim3(256), 0, st, qs, ldq, ks, ldk, wqs, wks, cs, S, D, s0, gf, gh, gw, eps, q_out_scale, ro);
   });
   if (rc != X2V_OK) return rc;
   X2V_REQUIRE(variant != 2 || streamed, X2V_E_SHAPE, "rmsnorm_rope: the streaming kernel covers D <= 8192 (D=%d)", D);
   X2V_LAUNCH_CHECK("rmsnorm_rope launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16_variant(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk,
+                                                                                           const void* rope_cs, int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps,
+                                                                                           int round_mode, float q_out_scale, int variant, void* stream) {
+  return rmsnorm_rope_impl(q, ldq, k, ldk, wq, wk, rope_cs, S, H, s0, gf, gh, gw, eps, round_mode, q_out_scale, variant, RopeOut(), stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_blocked_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* wq, const void* wk,
+                                                                                    const void* rope_cs, void* q_out, void* k_out, int64_t ldo, int block_cols,
+                                                                                    int64_t block_stride, int64_t S, int H, int64_t s0, int gf, int gh, int gw, float eps,
+                                                                                    int round_mode, float q_out_scale, void* stream) {
+  X2V_REQUIRE(q_out && k_out, X2V_E_ARG, "rmsnorm_rope_blocked: null output");
+  X2V_REQUIRE(block_cols > 0 && block_cols % 8 == 0 && (H * 128) % block_cols == 0 && ldo % 8 == 0 && ldo >= block_cols && block_stride % 8 == 0 && aligned16(q_out) &&
+                  aligned16(k_out),
+              X2V_E_SHAPE, "rmsnorm_rope_blocked: block_cols=%d must divide H*128 and be a multiple of 8; ldo / block_stride multiples of 8", block_cols);
+  RopeOut ro;
+  ro.qo = (unsigned short*)q_out;
+  ro.ko = (unsigned short*)k_out;
+  ro.ldo = ldo;
+  ro.cbw = block_cols;
+  ro.cbs = block_stride;
+  return rmsnorm_rope_impl((void*)q, ldq, (void*)k, ldk, wq, wk, rope_cs, S, H, s0, gf, gh, gw, eps, round_mode, q_out_scale, 0, ro, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_rmsnorm_rope_scaled_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* rope_cs,

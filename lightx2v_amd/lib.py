@@ -37,6 +37,11 @@ PROTOTYPES = {
     "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
     "x2v_gemm_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
+    "x2v_gemm_bf16_blocked": [_c_void_p, _i64, _i32, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "x2v_gemm_fp8_blocked": [_c_void_p, _i64, _i32, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64,
+                             _c_void_p, _c_void_p],
+    "x2v_rmsnorm_rope_blocked_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i64, _i32, _i64, _i32, _i32, _i32, _f32,
+                                      _i32, _f32, _c_void_p],
     "x2v_gemm_kernel_choice": [_i64, _i32, _i32, _i64, _i64, _i32],
     "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
     "x2v_transpose_heads_bf16": [_c_void_p, _i64, _c_void_p, _i64, _i64, _i32, _c_void_p],
@@ -201,6 +206,30 @@ def rmsnorm_rope_(q, k, wq, wk, rope_cs, grid, num_heads, s0=0, eps=1e-6, round_
     return q, k
 
 
+def rmsnorm_rope_blocked(q, k, wq, wk, rope_cs, grid, num_heads, q_out, k_out, s0=0, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0):
+    """x2v_rmsnorm_rope_blocked_bf16: RoPE3D(RMSNorm(q|k)) written out of place into N-blocked buffers q_out / k_out [B, S, H*128/B]
+    (the Ulysses seq->head send buffers)."""
+    q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
+    if rope_cs.dtype != torch.float32 or tuple(rope_cs.shape) != (1024, 64, 2) or not rope_cs.is_contiguous():
+        raise X2VError("rope_cs must be a contiguous float32 [1024,64,2] (cos,sin) table")
+    cb, cbs, ldo = _blocks3d(_bf16(q_out, "q_out"), "q_out")
+    if tuple(k_out.shape) != tuple(q_out.shape) or k_out.stride() != q_out.stride() or k_out.dtype != torch.bfloat16 or not k_out.is_cuda:
+        raise X2VError("rmsnorm_rope_blocked: q_out and k_out must have the same shape, strides and dtype")
+    if q_out.shape[0] * cb != num_heads * 128 or q_out.shape[1] != q2.shape[0]:
+        raise X2VError(f"rmsnorm_rope_blocked: outputs {tuple(q_out.shape)} do not hold [{q2.shape[0]}, {num_heads * 128}]")
+    gf, gh, gw = grid
+    wq, wk = _vec(wq, "norm_q weight", q2.shape[1]), _vec(wk, "norm_k weight", k2.shape[1])
+    init()
+    if q2.shape[0] == 0:
+        return q_out, k_out
+    _check(
+        _lib.x2v_rmsnorm_rope_blocked_bf16(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(wq), _p(wk), _p(rope_cs), _p(q_out), _p(k_out), ldo, cb, cbs, q2.shape[0], num_heads, s0, gf,
+                                           gh, gw, eps, round_mode, q_out_scale, _stream()),
+        "rmsnorm_rope_blocked",
+    )
+    return q_out, k_out
+
+
 def gate_residual_(x, y, gate=None):
     x2, y2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(y, "y"), "y")
     gate = _vec(gate, "gate", x2.shape[1])
@@ -219,8 +248,72 @@ def activation(x, act):
     return out
 
 
+def _blocks3d(t, name):
+    """A block-strided operand [B, M, c] (unit inner stride): returns (block columns, block stride, row stride)."""
+    if t.dim() != 3 or t.stride(2) != 1 or not t.is_cuda:
+        raise X2VError(f"{name}: a blocked operand is a 3-D device tensor [blocks, rows, cols] with unit inner stride, got {tuple(t.shape)} / {t.stride()}")
+    return t.shape[2], t.stride(0), t.stride(1)
+
+
+def gemm_blocked(x, weight_nk, bias=None, epilogue=EPI_NONE, out=None):
+    """x2v_gemm_bf16_blocked.  `x`: [M, K] or K-blocked [B, M, K/B]; `out`: None / [M, N] or N-blocked [B', M, N/B'] (preallocated) — the
+    Ulysses exchange buffers read / written in place.  Returns `out`."""
+    w2 = _row2d(_bf16(weight_nk, "weight"), "weight")
+    N, K = w2.shape
+    if x.dim() == 3:
+        kb, kbs, ldx = _blocks3d(_bf16(x, "x"), "x")
+        M = x.shape[1]
+        if kb * x.shape[0] != K:
+            raise X2VError(f"gemm_blocked: x blocks {tuple(x.shape)} do not make K={K}")
+    else:
+        x2 = _row2d(_bf16(x, "x"), "x")
+        kb, kbs, ldx, M = 0, 0, x2.stride(0), x2.shape[0]
+        if x2.shape[1] != K:
+            raise X2VError(f"gemm_blocked: x [M,{x2.shape[1]}] vs weight [{N},{K}]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    if out.dim() == 3:
+        nb, nbs, ldy = _blocks3d(_bf16(out, "out"), "out")
+        if nb * out.shape[0] != N or out.shape[1] != M:
+            raise X2VError(f"gemm_blocked: out blocks {tuple(out.shape)} do not make [{M}, {N}]")
+    else:
+        o2 = _row2d(_bf16(out, "out"), "out")
+        nb, nbs, ldy = 0, 0, o2.stride(0)
+        if tuple(o2.shape) != (M, N):
+            raise X2VError(f"gemm_blocked: out is {tuple(o2.shape)}, expected {(M, N)}")
+    if epilogue == EPI_RESIDUAL:
+        raise X2VError("gemm_blocked: use gemm(..., resid=) for the residual epilogue (x may be 3-D there)")
+    bias = _vec(bias, "gemm bias", N)
+    init()
+    if M == 0:
+        return out
+    _check(_lib.x2v_gemm_bf16_blocked(_p(x), ldx, kb, kbs, _p(w2), w2.stride(0), _p(bias), _p(out), ldy, nb, nbs, M, N, K, epilogue, None, 0, None, _stream()), "gemm_bf16_blocked")
+    return out
+
+
 def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=None, variant=0):
-    """y = epi(x @ weight_nk.T + bias); weight_nk is the checkpoint's [N,K] tensor.  variant: see x2v_gemm_bf16_variant."""
+    """y = epi(x @ weight_nk.T + bias); weight_nk is the checkpoint's [N,K] tensor.  variant: see x2v_gemm_bf16_variant.
+    A 3-D `x` ([B, M, K/B], K-blocked) or 3-D `out` ([B, M, N/B], N-blocked) goes through x2v_gemm_bf16_blocked."""
+    if x.dim() == 3 or (out is not None and out.dim() == 3):
+        if epilogue != EPI_RESIDUAL:
+            return gemm_blocked(x, weight_nk, bias, epilogue, out)
+        # residual epilogue on a K-blocked x (the Ulysses output projection): y = resid, row-major
+        w2 = _row2d(_bf16(weight_nk, "weight"), "weight")
+        N, K = w2.shape
+        kb, kbs, ldx = _blocks3d(_bf16(x, "x"), "x")
+        M = x.shape[1]
+        if kb * x.shape[0] != K or resid is None:
+            raise X2VError(f"gemm: K-blocked x {tuple(x.shape)} vs weight [{N},{K}] (residual epilogue needs resid)")
+        out2 = _row2d(_bf16(resid if out is None else out, "out"), "out")
+        r2 = _row2d(_bf16(resid, "resid"), "resid")
+        if tuple(out2.shape) != (M, N):
+            raise X2VError(f"gemm: out is {tuple(out2.shape)}, expected {(M, N)}")
+        init()
+        if M == 0:
+            return out2
+        _check(_lib.x2v_gemm_bf16_blocked(_p(x), ldx, kb, kbs, _p(w2), w2.stride(0), _p(_vec(bias, "gemm bias", N)), _p(out2), out2.stride(0), 0, 0, M, N, K, epilogue, _p(r2),
+                                          r2.stride(0), _p(_vec(gate, "gemm gate", N)), _stream()), "gemm_bf16_blocked")
+        return out2
     x2, w2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(weight_nk, "weight"), "weight")
     M, K = x2.shape
     N = w2.shape[0]

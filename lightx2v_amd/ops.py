@@ -54,6 +54,7 @@ class MMWeightHip(_Movable):
     operands.  Extra (optional) keyword arguments expose the fused epilogues to the fused block driver."""
 
     _tensor_attrs = ("weight", "bias")
+    accepts_blocked = True  # apply() takes a 3-D K-blocked input / N-blocked `out` (lib.gemm: the Ulysses exchange buffers in place)
 
     def __init__(self, weight_name, bias_name, lazy_load=False, lazy_load_file=None):
         self.weight_name, self.bias_name = weight_name, bias_name

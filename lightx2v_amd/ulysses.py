@@ -10,10 +10,16 @@ node: xGMI is a full mesh of point-to-point links, so an all-to-all puts one mes
 (7 x 12.1 MB at Wan-14B 720p, ≈79 us/link).  What the reference pays beyond the wire time is removed:
   * no host synchronisation (the reference calls torch.cuda.synchronize() twice per attention, attn.py:48,85);
     exchanges are stream-ordered on a side stream and joined with events;
-  * q/k/v exchanges run on the communication stream while the next projection GEMM runs on the compute
-    stream (k's exchange under the v GEMM; the wrapper issues them in that order);
-  * the head→seq exchange of the attention output needs no pre-transpose: [S, (H/N)d] is already the
-    [N, S/N, (H/N)d] send layout (the reference transposes twice, all2all.py:70-75,87).
+  * NO layout copies between the kernels and the collectives (the fused driver's path, `attend_blocked`): the exchange buffers
+    [N, S/N, (H/N)d] are kernel operands as they are.  v's projection writes the send buffer from its GEMM epilogue
+    (x2v_gemm_bf16_blocked, N-blocked y), the q/k norm+RoPE kernel writes q's and k's (x2v_rmsnorm_rope_blocked_bf16), the received
+    buffers ARE the attention's row-major [S, (H/N)d] operands, the attention output IS the head->seq send buffer, and the output
+    projection reads the received [N, S/N, (H/N)d] buffer as a K-blocked x.  The reference transposes with a copy on both sides of
+    both exchanges (all2all.py:29-33,41; :70-75,87);
+  * v's exchange runs on the communication stream under the q and k projections and the norm+RoPE kernel; the head->seq exchange is
+    issued in two halves (destination ranks [0, N/2) and [N/2, N)), the first under the attention of the second half's query rows.
+`seq2head` / `head2seq` / calling the object with row-major 2-D q, k, v keep the reference's functional forms (bit-equal to its
+all2all_* functions in the gloo tests) for callers that hold row-major tensors (the reference's op-by-op loop).
 """
 import torch
 import torch.distributed as dist
@@ -54,6 +60,8 @@ class UlyssesAttention:
         self.attn_fn = attn_fn or (lambda q, k, v, h, d, variant=0: lib.attention(q, k, v, h, d, variant=variant))
         self.overlap = overlap and torch.cuda.is_available()
         self.comm_stream = None
+        self._buffers = {}
+        self.copies = 0  # layout copies made by the row-major entry (the blocked entry makes none): asserted by the tests
 
     class _Pending:
         """An exchange already issued on the communication stream (result valid once the compute stream has joined it)."""
@@ -61,35 +69,121 @@ class UlyssesAttention:
         def __init__(self, src, out):
             self.src, self.out = src, out
 
-    def begin_exchange(self, x):
-        """Start seq→head of `x` on the communication stream now (stream-ordered after what has been enqueued on the
-        compute stream so far); the caller keeps enqueueing independent work and hands the result to __call__."""
-        if not (self.overlap and x.is_cuda):
-            return None
+    # ---- the fused driver's path: exchange buffers are kernel operands ---------------------------------------------------
+    def buffers(self, s_local, hd, dtype, device):
+        """The six [N, S/N, hd/N] exchange buffers of one attention (send q/k/v, receive q/k/v), the attention output (= head->seq
+        send buffer) and its receive buffer.  Allocated once per shape and reused by every layer: stream order makes that safe
+        (a layer's exchanges have been joined by the compute stream before the next layer's kernels write the buffers)."""
+        n, _ = _world(self.group)
+        key = (s_local, hd, dtype, str(device))
+        b = self._buffers.get(key)
+        if b is None:
+            mk = lambda: torch.empty((n, s_local, hd // n), dtype=dtype, device=device)  # noqa: E731
+            b = self._buffers[key] = {name: mk() for name in ("sq", "sk", "sv", "rq", "rk", "rv", "o", "ro")}
+        return b
+
+    def _comm(self):
         if self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream()
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
+        return self.comm_stream
+
+    def begin_exchange_blocked(self, send, recv):
+        """seq->head of one blocked send buffer [N, S/N, hd/N] into `recv` (same shape; viewed as row-major [S, hd/N] by the attention),
+        on the communication stream when overlapping, stream-ordered after what the compute stream has enqueued so far."""
+        if self.overlap and send.is_cuda:
+            cs = self._comm()
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                dist.all_to_all_single(recv, send, group=self.group)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+        return self._Pending(send, recv)
+
+    def attend_blocked(self, bufs, num_heads, head_dim=128, timer=None, variant=0, v_pending=None):
+        """q/k/v are in bufs["sq"/"sk"/"sv"] (v possibly already in flight: `v_pending`).  Returns bufs["ro"]: the received head->seq
+        buffer [N, S/N, hd/N] = the output projection's K-blocked input."""
+        n, r = _world(self.group)
+        if num_heads % n != 0:
+            raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
+        hl = num_heads // n
+        s_local, hdn = bufs["sq"].shape[1], bufs["sq"].shape[2]
+        S = n * s_local
+        use_streams = self.overlap and bufs["sq"].is_cuda
+        if use_streams:
+            cur, cs = torch.cuda.current_stream(), self._comm()
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):
+                dist.all_to_all_single(bufs["rq"], bufs["sq"], group=self.group)
+                dist.all_to_all_single(bufs["rk"], bufs["sk"], group=self.group)
+                if v_pending is None:
+                    dist.all_to_all_single(bufs["rv"], bufs["sv"], group=self.group)
+            cur.wait_stream(cs)
+        else:
+            dist.all_to_all_single(bufs["rq"], bufs["sq"], group=self.group)
+            dist.all_to_all_single(bufs["rk"], bufs["sk"], group=self.group)
+            if v_pending is None:
+                dist.all_to_all_single(bufs["rv"], bufs["sv"], group=self.group)
+        qh, kh, vh = (bufs[x].view(S, hdn) for x in ("rq", "rk", "rv"))
+        o = bufs["o"].view(S, hdn)
+        fast = self._default_attn and (variant & 0xFF) == lib.ATTN_FAST
+        vt = lib.transpose_heads(vh, hl) if fast else None  # the ping-pong kernel reads V^T (1/N of the single-GPU transposition)
+        # head->seq in two halves by destination rank: rows [0, split) of o go to ranks [0, N/2), the rest to ranks [N/2, N)
+        halves = [(0, n)] if n < 2 else [(0, n // 2), (n // 2, n)]
+        for (j0, j1) in halves:
+            rows = slice(j0 * s_local, j1 * s_local)
+
+            def fn(rows=rows):
+                if fast:
+                    return lib.attention(qh[rows], kh, vh, hl, head_dim, variant=variant, vt=vt, out=o[rows])
+                res = self.attn_fn(qh[rows], kh, vh, hl, head_dim, variant=variant) if variant else self.attn_fn(qh[rows], kh, vh, hl, head_dim)
+                if res.data_ptr() != o[rows].data_ptr():
+                    o[rows].copy_(res)
+                return o[rows]
+
+            timer("self", fn) if timer is not None else fn()
+            in_split = [s_local if j0 <= j < j1 else 0 for j in range(n)]
+            mine = j0 <= r < j1
+            out_split = [s_local if mine else 0] * n
+            recv = bufs["ro"].view(S, hdn) if mine else bufs["ro"].view(S, hdn)[:0]
+            if use_streams:
+                cs.wait_stream(cur)
+                with torch.cuda.stream(cs):
+                    dist.all_to_all_single(recv, o[rows], out_split, in_split, group=self.group)
+            else:
+                dist.all_to_all_single(recv, o[rows], out_split, in_split, group=self.group)
+        if use_streams:
+            cur.wait_stream(cs)
+        return bufs["ro"]
+
+    # ---- row-major entry (the reference's functional form) -----------------------------------------------------------------
+    def begin_exchange(self, x):
+        """Start seq→head of a row-major `x` [S/N, H*d] on the communication stream now (stream-ordered after what has been enqueued
+        on the compute stream so far); the caller keeps enqueueing independent work and hands the result to __call__."""
+        if not (self.overlap and x.is_cuda):
+            return None
+        cs = self._comm()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
             out = seq2head(x, self.group)
-        x.record_stream(self.comm_stream)
-        out.record_stream(self.comm_stream)
+        x.record_stream(cs)
+        out.record_stream(cs)
         return self._Pending(x, out)
 
     def __call__(self, q, k, v, num_heads, head_dim=128, timer=None, variant=0):
         n, _ = _world(self.group)
         if num_heads % n != 0:
             raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
+        self.copies += 4  # three transposing sends + the gather of the received output
         if self.overlap and q.is_cuda:
-            if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream()
+            cs = self._comm()
             cur = torch.cuda.current_stream()
-            self.comm_stream.wait_stream(cur)
-            with torch.cuda.stream(self.comm_stream):
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):
                 qh, kh = seq2head(q, self.group), seq2head(k, self.group)
                 vh = v.out if isinstance(v, self._Pending) else seq2head(v, self.group)
             for t in (q, k) + (() if isinstance(v, self._Pending) else (v,)):
-                t.record_stream(self.comm_stream)  # produced on the compute stream, read by the exchange
-            cur.wait_stream(self.comm_stream)
+                t.record_stream(cs)  # produced on the compute stream, read by the exchange
+            cur.wait_stream(cs)
             for t in (qh, kh, vh):
                 t.record_stream(cur)  # allocated under the communication stream, read by the attention kernel
         else:

@@ -278,12 +278,6 @@ class WanTransformerInfer:
     def infer_self_attn(self, weights, grid_sizes, x, seq_lens, freqs, shift_msa, scale_msa, gate_msa):
         """transformer_infer.py:321-396 + the `x.add_(y * gate_msa)` of :402 folded into the o-projection."""
         n1 = lib.layernorm(x, scale=scale_msa, shift=shift_msa, eps=weights.norm1.eps)  # norm1 has no affine (transformer_weights.py:127-129)
-        # Ulysses: v needs no norm/RoPE, so it is projected first and its seq→head exchange runs on the communication
-        # stream under the q and k projections and the norm+RoPE kernel
-        v = weights.self_attn_v.apply(n1)
-        v_pending = self.parallel_attention.begin_exchange(v) if hasattr(self.parallel_attention, "begin_exchange") else None
-        q = weights.self_attn_q.apply(n1)
-        k = weights.self_attn_k.apply(n1)
         grid = tuple(int(g) for g in grid_sizes[0].tolist())
         s_local = x.shape[0]
         if freqs.is_complex():  # driven by the reference's WanPreInfer: complex128 [1024, 64] (pre_infer.py:12-19)
@@ -293,18 +287,38 @@ class WanTransformerInfer:
         # default (fp32-statistics) mode: q leaves the norm+RoPE kernel already multiplied by softmax_scale*log2(e) inside
         # its one rounding, and the attention kernel variant that expects that skips the per-score FMA (x2v.h)
         fast = self.round_mode == lib.ROUND_FP32
-        lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads,
-                          s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode,
-                          q_out_scale=lib.ATTN_PRESCALE if fast else 1.0)
         variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if fast else 0
-        if self.parallel_attention is None:
+        rope_args = dict(s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode, q_out_scale=lib.ATTN_PRESCALE if fast else 1.0)
+        pa = self.parallel_attention
+        if pa is not None and hasattr(pa, "attend_blocked") and x.is_cuda and self._blocked_ok(weights):
+            # Ulysses without layout copies: the exchange buffers [N, S/N, (H/N)d] are kernel operands (ulysses.py)
+            b = pa.buffers(s_local, x.shape[1], x.dtype, x.device)
+            weights.self_attn_v.apply(n1, out=b["sv"])  # v needs no norm / RoPE: projected first, straight into its send buffer,
+            v_pending = pa.begin_exchange_blocked(b["sv"], b["rv"])  # and exchanged under the q / k projections and the norm+RoPE kernel
+            q = weights.self_attn_q.apply(n1)
+            k = weights.self_attn_k.apply(n1)
+            lib.rmsnorm_rope_blocked(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, b["sq"], b["sk"], **rope_args)
+            attn = pa.attend_blocked(b, self.num_heads, self.head_dim, timer=self._timed, variant=variant, v_pending=v_pending)
+            return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)  # K-blocked x
+        # Ulysses, row-major form: v is projected first and its seq→head exchange runs on the communication stream under the q and k
+        # projections and the norm+RoPE kernel
+        v = weights.self_attn_v.apply(n1)
+        v_pending = pa.begin_exchange(v) if hasattr(pa, "begin_exchange") else None
+        q = weights.self_attn_q.apply(n1)
+        k = weights.self_attn_k.apply(n1)
+        lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
+        if pa is None:
             # the ping-pong kernel reads V^T; transposed outside the timed launch so the hook times the attention kernel alone
             vt = lib.transpose_heads(v, self.num_heads) if fast else None
             attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant, vt=vt))
         else:
-            attn = self.parallel_attention(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed,
-                                           variant=variant)
+            attn = pa(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)
         return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
+
+    @staticmethod
+    def _blocked_ok(weights):
+        """The copy-free Ulysses path needs operator objects whose apply() takes block-strided operands (the bf16 class)."""
+        return all(getattr(getattr(weights, n), "accepts_blocked", False) for n in ("self_attn_v", "self_attn_o"))
 
     def infer_cross_attn(self, weights, x, context):
         """transformer_infer.py:398-465 (t2v) + the `x.add_(attn_out)` of :468 folded into the o-projection."""

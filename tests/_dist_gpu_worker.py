@@ -51,6 +51,9 @@ def main():
         sch.step_pre(0)
         model.infer(inputs)
         outs[mode] = sch.noise_pred.float().cpu()
+        if mode == "ulysses":
+            pa = model.transformer_infer.parallel_attention
+            assert pa.copies == 0 and pa._buffers, "the fused driver must take the copy-free blocked exchange path"
         sch.step_post()
         assert torch.isfinite(sch.latents).all()
     a, b = outs["single"], outs["ulysses"]

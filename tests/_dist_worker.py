@@ -32,6 +32,18 @@ def main():
     out = attn(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), H, d)
     assert torch.equal(out, full[sl]), (out.float() - full[sl].float()).abs().max()
 
+    # the fused driver's copy-free path: blocked exchange buffers in, blocked receive buffer out (no transposing copies inside)
+    s_loc, hdn = S // n, H * d // n
+    b = attn.buffers(s_loc, H * d, torch.bfloat16, "cpu")
+    for name, src in (("sq", q), ("sk", k), ("sv", v)):
+        b[name].copy_(src[sl].view(s_loc, n, hdn).transpose(0, 1))  # what the GEMM epilogue / norm+RoPE kernel write on the GPU
+    before = attn.copies
+    ro = attn.attend_blocked(b, H, d)
+    assert attn.copies == before, "the blocked path must not fall back to the transposing entry"
+    assert ro.shape == (n, s_loc, hdn)
+    assert torch.equal(ro.transpose(0, 1).reshape(s_loc, H * d), full[sl]), "blocked Ulysses attention differs from the single-process result"
+    assert torch.equal(ro.transpose(0, 1).reshape(s_loc, H * d), out), "blocked and row-major entries must agree bit for bit"
+
     # shard / gather around the block stack, including zero padding when S % N != 0
     x = torch.randn(S + 1, 8, generator=gen)
     xs = ulysses.pre_process(x)

@@ -116,3 +116,44 @@ def test_caches_follow_weight_updates():
     third = sch.noise_pred.clone()
     fresh.infer(inputs)
     assert torch.equal(sch.noise_pred, third), "re-loaded model must equal a freshly built one"
+
+
+def test_blocked_gemm_and_rope_equal_their_row_major_forms():
+    """x2v_gemm_bf16_blocked / x2v_rmsnorm_rope_blocked_bf16 (the Ulysses exchange buffers as kernel operands): N-blocked y, K-blocked x
+    and the out-of-place blocked norm+RoPE give exactly the bits of the row-major kernels followed by the reference's transposing copies
+    (comm/all2all.py:29-33, 70-75); both GEMM tilings."""
+    from lightx2v_amd import lib
+    from lightx2v_amd.wan import rope_cos_sin_table
+
+    gen = torch.Generator().manual_seed(4)
+    nb = 4
+    for M, K, N in ((300, 512, 1024), (4100, 2560, 5120)):  # 128x128 kernel / 256x256 kernel (5120 = 4 blocks of 10 K-tiles)
+        x = torch.randn(M, K, generator=gen).to(torch.bfloat16).cuda()
+        w = (torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16).cuda()
+        b = torch.randn(N, generator=gen).to(torch.bfloat16).cuda()
+        ref = lib.gemm(x, w, b)
+        out = torch.full((nb, M + 3, N // nb), 7.0, dtype=torch.bfloat16, device="cuda")[:, 1 : M + 1]  # strided rows inside a poisoned buffer
+        lib.gemm(x, w, b, out=out)
+        assert torch.equal(out.transpose(0, 1).reshape(M, N), ref), (M, K, N, "N-blocked y")
+        xb = x.view(M, nb, K // nb).transpose(0, 1).contiguous()  # [nb, M, K/nb]
+        assert torch.equal(lib.gemm(xb, w, b), ref), (M, K, N, "K-blocked x")
+        res = torch.randn(M, N, generator=gen).to(torch.bfloat16).cuda()
+        gate = torch.randn(N, generator=gen).to(torch.bfloat16).cuda()
+        r1, r2 = res.clone(), res.clone()
+        lib.gemm(x, w, b, epilogue=lib.EPI_RESIDUAL, resid=r1, gate=gate)
+        lib.gemm(xb, w, b, epilogue=lib.EPI_RESIDUAL, resid=r2, gate=gate)
+        assert torch.equal(r1, r2), (M, K, N, "K-blocked x, gate-residual epilogue")
+        assert torch.equal(lib.gemm(xb, w, b, epilogue=lib.EPI_GELU_TANH), lib.gemm(x, w, b, epilogue=lib.EPI_GELU_TANH))
+    # norm + RoPE into blocked outputs: both kernel forms (few rows -> per-row kernel, many rows -> streaming kernel)
+    H, grid = 4, (5, 30, 40)
+    tab = rope_cos_sin_table(128, "cuda")
+    wq, wk = (1 + 0.1 * torch.randn(H * 128, generator=gen)).to(torch.bfloat16).cuda(), (1 + 0.1 * torch.randn(H * 128, generator=gen)).to(torch.bfloat16).cuda()
+    for S in (77, 6000):
+        q = torch.randn(S, H * 128, generator=gen).to(torch.bfloat16).cuda()
+        k = torch.randn(S, H * 128, generator=gen).to(torch.bfloat16).cuda()
+        q1, k1 = q.clone(), k.clone()
+        lib.rmsnorm_rope_(q1, k1, wq, wk, tab, grid, H, s0=11, q_out_scale=lib.ATTN_PRESCALE)
+        qo = torch.full((2, S, H * 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        ko = torch.full((2, S, H * 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        lib.rmsnorm_rope_blocked(q, k, wq, wk, tab, grid, H, qo, ko, s0=11, q_out_scale=lib.ATTN_PRESCALE)
+        assert torch.equal(qo.transpose(0, 1).reshape(S, H * 128), q1) and torch.equal(ko.transpose(0, 1).reshape(S, H * 128), k1), S
