@@ -627,6 +627,12 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const unsigned sho
 }
 
 }  // namespace x2v
+namespace x2v {
+int attn_w64_dispatch(bool prescaled, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
+                      int H, float scale, hipStream_t st);  // attn64.hip
+int attn_w64_probe(int probe, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk, int H, float scale,
+                    hipStream_t st);
+}
 using namespace x2v;
 
 // which body x2v_attn_fwd_bf16_vt launches by default (kind 0); kind 1 launches the other one (A/B)
@@ -695,6 +701,8 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
     case 1:
       return pre ? launch_attn_vt<8, 8, true, 1 - X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
                  : launch_attn_vt<8, 8, false, 1 - X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
+    case 2: return attn_w64_dispatch(pre != 0, q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);  // 64 query rows per wave (attn64.hip)
+    case 3: case 4: case 5: return attn_w64_probe(kind - 2, q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);  // TEMPORARY timing probes
     default: set_error("attn_vt: unknown kernel selector %d", kind); return X2V_E_ARG;
   }
 }

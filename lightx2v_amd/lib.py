@@ -185,6 +185,7 @@ ATTN_Q_PRESCALED = 0x100
 ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
 #                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
 ATTN_FAST_ALT = 13  # the same entry's alternative kernel body (A/B measurements; include/x2v.h)
+ATTN_W64 = 14  # the same entry, 64 query rows per wave (csrc/attn64.hip)
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
 
 
@@ -382,7 +383,7 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
     init()
     if Sq == 0:
         return out2
-    if (variant & 0xFF) in (ATTN_FAST, ATTN_FAST_ALT):
+    if (variant & 0xFF) in (ATTN_FAST, ATTN_FAST_ALT, ATTN_W64):
         if vt is None:
             vt = transpose_heads(v2, num_heads)
         elif vt.dtype != torch.bfloat16 or not vt.is_cuda or not vt.is_contiguous() or tuple(vt.shape) != (num_heads, (Sk + 63) // 64, 128, 64):
