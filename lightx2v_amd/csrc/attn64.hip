@@ -146,11 +146,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int g = 0; g < 4; ++g) vaddr[g] = fl * 128 + ((((g << 1) | hi) ^ ((fl >> 1) & 7)) << 4);
   f32x16_t S[2][2], negm[2];  // scores of the tile in flight: [query block][key block]; -m as the C operand of the first QK^T step
-  f32x4_t pw[2][4];           // packed P: [query block][16-key group]
+  // packed P: [buffer][query block][16-key group].  Groups 0..2 of tile t+1 are produced while PV(t) still reads tile t's -> two buffers
+  // alternating by tile parity; group 3 is produced in the following Q phase, after PV(t) has read it -> buffer 0 only
+  f32x4_t pw[2][2][4];
 #pragma unroll
   for (int e = 0; e < 16; ++e) negm[0][e] = negm[1][e] = 0.f;
   float m_run[2] = {0.f, 0.f}, mx[2] = {0.f, 0.f}, pend_al[2] = {1.f, 1.f};
-  float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // row sums (two partial chains per query block)
+  float lsz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // row-sum share of the SPECULATIVE group 0 of the next tile (folded in or redone by decide)
   float pa[2], pb[2], pm[2][4];
   unsigned long long ts[16] = {};  // PROBE 3: cycle stamps
   bool force = true;     // first tile: adopt its row max in either direction
@@ -160,15 +163,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W6_SB() __builtin_amdgcn_sched_barrier(0)
 
   // ---- vector work, in slot-sized pieces -------------------------------------------------------------------------------------
-  // quarter C (0..31) of a tile's exp2 / row-sum / pack: unit (16-key group C>>3, query block (C>>2)&1), pair j = C&3
-  auto eq = [&](auto cc) {
+  // quarter C (0..31) of a tile's exp2 / row-sum / pack: unit (16-key group C>>3, query block (C>>2)&1), pair j = C&3, into P buffer PB.
+  // SPEC: the quarter runs BEFORE its tile's rescale decision (scores still relative to the old max): its sums go to lsz.
+  auto eq = [&](auto cc, auto pbc, auto specc) {
     constexpr int C = decltype(cc)::value, qb = (C >> 2) & 1, uh = C >> 3, j = C & 3, kb = uh >> 1, e = (uh & 1) * 8 + 2 * j;
+    constexpr int PB = uh == 3 ? 0 : decltype(pbc)::value;
+    constexpr bool SPEC = decltype(specc)::value;
     const float p0 = __builtin_amdgcn_exp2f(S[qb][kb][e]), p1 = __builtin_amdgcn_exp2f(S[qb][kb][e + 1]);
-    ls[qb][0] += p0;
-    ls[qb][1] += p1;
-    pw[qb][uh][j] = __uint_as_float(pack_bf2(p0, p1));
+    if constexpr (SPEC) {
+      if constexpr (j == 0) {
+        lsz[qb][0] = p0;
+        lsz[qb][1] = p1;
+      } else {
+        lsz[qb][0] += p0;
+        lsz[qb][1] += p1;
+      }
+    } else {
+      ls[qb][0] += p0;
+      ls[qb][1] += p1;
+    }
+    pw[PB][qb][uh][j] = __uint_as_float(pack_bf2(p0, p1));
     // pin the quarter into ITS slot: pure arithmetic is otherwise sunk towards its first use (past the MFMAs it should hide under)
-    asm volatile("" : "+v"(pw[qb][uh][j]), "+v"(ls[qb][0]), "+v"(ls[qb][1]));
+    if constexpr (SPEC) asm volatile("" : "+v"(pw[PB][qb][uh][j]), "+v"(lsz[qb][0]), "+v"(lsz[qb][1]));
+    else asm volatile("" : "+v"(pw[PB][qb][uh][j]), "+v"(ls[qb][0]), "+v"(ls[qb][1]));
   };
   // step I (0..21) of the row max of S: query block I&1, sub-step I>>1 (0..7: groups of 8 scores, key block 0 first; 8, 9: combine;
   // 10: the half-wave exchange)
@@ -204,9 +221,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r)
           if (u * 32 + (r & 7) + 8 * hi + 16 * (r >> 3) >= left) S[qb][u][r] = -1e30f;
   };
-  // the rescale decision for the tile whose scores are in S (cold: some row's max grew by more than THR, or first tile).  Everything but
-  // O is adjusted here; O (busy under the running PV phase) follows at the head of the next Q phase (scale_o).
-  auto decide = [&]() {
+  // group 0 of the tile in S, from scratch (after a mask or a rescale invalidated the speculative quarters): lsz and P buffer PB
+  auto redo_spec = [&](auto pbc) {
+    w6_for<0, 8>([&](auto cc) { eq(cc, pbc, std::true_type{}); });
+  };
+  // The rescale decision for the tile whose scores are in S, whose group 0 went (SPEC) speculatively into P buffer PB (cold: some row's
+  // max grew by more than THR, or first tile).  Everything but O is adjusted here; O (busy under the running PV phase) follows at the
+  // head of the next Q phase (scale_o).  The speculative row-sum share is relative to the old max like every earlier contribution, so the
+  // common factor covers it — but its exp2 may have overflowed, so it is recomputed with the packed words instead.
+  auto decide = [&](auto pbc, auto specc) {
+    constexpr bool SPEC = decltype(specc)::value;
     if (force || __any(fmaxf(mx[0], mx[1]) > (float)RESCALE_THR)) {
       w6_for<0, 2>([&](auto qc) {
         constexpr int qb = decltype(qc)::value;
@@ -227,6 +251,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       });
       pending = !force;
       force = false;
+      if constexpr (SPEC) redo_spec(pbc);
+    }
+    if constexpr (SPEC) {  // fold the (now final) group-0 share into the row sums
+      ls[0][0] += lsz[0][0];
+      ls[0][1] += lsz[0][1];
+      ls[1][0] += lsz[1][0];
+      ls[1][1] += lsz[1][1];
     }
   };
   auto scale_o = [&]() {
@@ -248,12 +279,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   ((G_) < 16 ? *reinterpret_cast<const bf16x8_t*>(smem + K_OFF + (KB_) * W6_TILE_BYTES + (((G_) & 15) >> 3) * 8192 + kaddr[(G_) & 7]) \
              : *reinterpret_cast<const bf16x8_t*>(smem + V_OFF + (VB_) * W6_TILE_BYTES + ((G_) & 3) * 4096 + vaddr[(((G_) - 16) & 15) >> 2]))
 
-  // One loop iteration for tile t: [Q(t+1) | exp/pack of tile t's key groups 2, 3 | DMA], then [PV(t) | max(t+1), decision, exp/pack of
-  // tile t+1's key groups 0, 1].  KN: K buffer holding tile t+1, VC: V^T buffer holding tile t; HAS_NEXT: t + 1 < nt.
+  // One loop iteration for tile t (P buffer PC = t & 1):
+  //   Q phase: QK^T(t+1) | group 3 of tile t (even slots < 16) | the 8 DMA pieces (odd slots < 16) | from slot 16: row max of S(t+1) over key
+  //            block 0 alternating with the SPECULATIVE group 0 of tile t+1 (-> P buffer PC ^ 1)
+  //   P phase: PV(t) | rest of the row max (slots 0..6), decision (slot 7), groups 1, 2 of tile t+1 (16 quarters over slots 8..31)
+  // KN: K buffer holding tile t+1, VC: V^T buffer holding tile t = PC; HAS_NEXT: t + 1 < nt.
   auto iter = [&](auto knc, auto vcc, auto hnc, int t) {
-    constexpr int KN = decltype(knc)::value, VC = decltype(vcc)::value;
+    constexpr int KN = decltype(knc)::value, VC = decltype(vcc)::value, PC = VC, PN = VC ^ 1;
     constexpr bool HAS_NEXT = decltype(hnc)::value;
     constexpr int G0 = HAS_NEXT ? 0 : 16;
+    using pc_t = std::integral_constant<int, PC>;
+    using pn_t = std::integral_constant<int, PN>;
     if constexpr (PROBE == 3) { if (t >= 200 && t < 204) ts[(t - 200) * 4 + 0] = __builtin_readcyclecounter(); }
     scale_o();
     W6_SB();
@@ -269,24 +305,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (qb == 0) fr[(g + 3) & 3] = W6_FRAG(KN, VC, g + 3);
       }
       if constexpr (PROBE != 2) {
-        // key group 3 of tile t (reads the key-block-1 tuples, overwritten from slot 16 on): one quarter every other slot
-        if constexpr (n < 16 && (n & 1) == 0) eq(std::integral_constant<int, 24 + (n >> 1)>{});
-        // row max of S(t+1), key block 0 (complete since slot 15): 8 steps behind the MFMAs' result latency
-        if constexpr (HAS_NEXT) {
-          constexpr int mi = n == 20 ? 0 : n == 22 ? 1 : n == 23 ? 2 : n == 24 ? 3 : n == 26 ? 4 : n == 27 ? 5 : n == 28 ? 6 : n == 30 ? 7 : -1;
-          if constexpr (mi >= 0) mstep(std::integral_constant<int, mi>{});
+        // group 3 of tile t (reads the key-block-1 tuples, overwritten from slot 16 on): one quarter every other slot
+        if constexpr (n < 16 && (n & 1) == 0) eq(std::integral_constant<int, (24 + (n >> 1))>{}, pc_t{}, std::false_type{});
+        if constexpr (HAS_NEXT && n >= 16) {
+          // key block 0 of S(t+1) is complete since slot 15 (>= 2 MFMA issues ago for every register read here)
+          if constexpr ((n & 1) == 0) mstep(std::integral_constant<int, ((n - 16) >> 1)>{});
+          else eq(std::integral_constant<int, ((n - 17) >> 1)>{}, pn_t{}, std::true_type{});
         }
       }
       if constexpr (HAS_NEXT) {
         if constexpr (ks == 0) w6_qk_first<qb * 8>(S[qb][kb], fr[g & 3], negm[qb]);
         else w6_qk_acc<qb * 8 + ks>(S[qb][kb], fr[g & 3]);
-        if constexpr (n >= 16 && (n & 1) == 1) {
-          constexpr int j = (n - 16) >> 1;
+        if constexpr (n < 16 && (n & 1) == 1 && PROBE != 1) {
           // unconditional: a tile past the end lies outside the buffer descriptor's range and lands as zeros in a buffer nobody reads
-          if constexpr (PROBE != 1) {
-            if constexpr (j < 4) dma_k(t + 2, KN ^ 1, j);
-            else dma_v(t + 1, VC ^ 1, j - 4);
-          }
+          constexpr int j = n >> 1;
+          if constexpr (j < 4) dma_k(t + 2, KN ^ 1, j);
+          else dma_v(t + 1, VC ^ 1, j - 4);
         }
       }
       W6_SB();
@@ -294,32 +328,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- P phase
     if constexpr (PROBE == 3) { if (t >= 200 && t < 204) ts[(t - 200) * 4 + 1] = __builtin_readcyclecounter(); }
     if constexpr (HAS_NEXT) {
-      if ((int64_t)(t + 2) * W6_KV > Sk) {  // ragged last tile: mask S(t+1) before its row max (once per block)
+      if ((int64_t)(t + 2) * W6_KV > Sk) {  // ragged last tile: mask S(t+1), then redo what ran on the unmasked key block 0 (once per block)
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         mask(t + 1);
-        w6_for<0, 8>([&](auto ic) { mstep(ic); });  // the key-block-0 steps ran in the Q phase on unmasked scores: redo them
+        w6_for<0, 8>([&](auto ic) { mstep(ic); });
+        redo_spec(pn_t{});
       }
     }
     w6_for<0, 32>([&](auto nc) {
       constexpr int n = decltype(nc)::value, g = 16 + (n >> 1), qb = n & 1, T = g & 3, uh = (g - 16) >> 2;
       constexpr int ring = HAS_NEXT ? g : g - 16;
       if constexpr (qb == 0 && g + 3 < 32) fr[(ring + 3) & 3] = W6_FRAG(KN, VC, g + 3);
-      w6_pv<qb * 4 + T>(fr[ring & 3], pw[qb][uh]);
+      w6_pv<qb * 4 + T>(fr[ring & 3], pw[uh == 3 ? 0 : PC][qb][uh]);
       if constexpr (HAS_NEXT && PROBE != 2) {
         if constexpr (n < 7) {  // row max, key block 1 and the combine steps (14 steps)
           mstep(std::integral_constant<int, 8 + 2 * n>{});
           mstep(std::integral_constant<int, 8 + 2 * n + 1>{});
         }
-        if constexpr (n == 7) decide();
-        // key groups 0, 1, 2 of tile t+1: the P words of group u are free once PV(t)'s slots 8u .. 8u+7 have issued
-        if constexpr (n >= 8) eq(std::integral_constant<int, n - 8>{});
+        if constexpr (n == 7) decide(pn_t{}, std::true_type{});
+        // groups 1, 2 of tile t+1 into the other P buffer: 16 quarters over slots 8..31 (two in every three slots)
+        if constexpr (n >= 8 && (n - 8) % 3 != 2) eq(std::integral_constant<int, 8 + ((n - 8) / 3) * 2 + (n - 8) % 3>{}, pn_t{}, std::false_type{});
       }
       W6_SB();
     });
     if constexpr (PROBE == 3) { if (t >= 200 && t < 204) ts[(t - 200) * 4 + 2] = __builtin_readcyclecounter(); }
   };
 
-  // ---- prologue: K(0), V^T(0), K(1) in flight; S(0), its row max, adoption of the max, key groups 0, 1
+  // ---- prologue: K(0), V^T(0), K(1) in flight; S(0), its row max, adoption of the max, groups 0..2 into P buffer 0
   {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma_k(0, 0, j);
@@ -340,8 +375,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     if ((int64_t)W6_KV > Sk) mask(0);
     w6_for<0, 22>([&](auto ic) { mstep(ic); });
-    decide();
-    w6_for<0, 24>([&](auto cc) { eq(cc); });
+    decide(std::integral_constant<int, 0>{}, std::false_type{});
+    w6_for<0, 24>([&](auto cc) { eq(cc, std::integral_constant<int, 0>{}, std::false_type{}); });
   }
 
   // ---- tiles: t even -> K(t+1) in buffer 1, V^T(t) in buffer 0; t odd -> the other way round.  The barrier in front of each iteration
@@ -351,16 +386,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int t = 0;
   while (t + 1 < nt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PROBE == 3) { if (t >= 200 && t < 204) ts[(t - 200) * 4 + 3] = __builtin_readcyclecounter(); }
     __builtin_amdgcn_s_barrier();
     iter(c1{}, c0{}, std::true_type{}, t);
     ++t;
     if (t + 1 >= nt) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PROBE == 3) { if (t >= 200 && t < 204) ts[(t - 200) * 4 + 3] = __builtin_readcyclecounter(); }
     __builtin_amdgcn_s_barrier();
     iter(c0{}, c1{}, std::true_type{}, t);
     ++t;
   }
-  // last tile t = nt - 1: its key groups 2, 3, then PV
+  // last tile t = nt - 1: its group 3, then PV
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (t & 1) iter(c0{}, c1{}, std::false_type{}, t);

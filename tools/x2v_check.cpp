@@ -1093,7 +1093,8 @@ static void run_single(int argc, char** argv) {
       std::vector<uint16_t> ho = o.host();
       const unsigned long long* d = reinterpret_cast<const unsigned long long*>(ho.data() + (size_t)S * H * 128 / 2);
       for (int i = 0; i < 4; ++i)
-        printf("  tile %d: Q phase %llu  P phase %llu  to next start %llu\n", 200 + i, d[i * 4 + 1] - d[i * 4 + 0], d[i * 4 + 2] - d[i * 4 + 1], i < 3 ? d[(i + 1) * 4] - d[i * 4 + 2] : 0ull);
+        printf("  tile %d: wait->start %llu  Q phase %llu  P phase %llu  P end -> next vmcnt wait done %llu\n", 200 + i, d[i * 4 + 0] - d[i * 4 + 3], d[i * 4 + 1] - d[i * 4 + 0],
+               d[i * 4 + 2] - d[i * 4 + 1], i < 3 ? d[(i + 1) * 4 + 3] - d[i * 4 + 2] : 0ull);
     }
   } else {
     const int64_t M = atoll(argv[2]);
