@@ -16,8 +16,8 @@ N > 1 shards the SAME video across ranks (strong scaling).
 
 Output: ONE JSON line on rank 0.  value = video frames/sec = frames / (infer_steps x step latency), denoise
 loop only (VAE decode excluded).  `roofline` is for the dominant kernel (self-attention forward:
-72 % of the step's FLOPs at 720p); `cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on
-a bounded sample of the same workload on this box's host cores.
+72 % of the step's FLOPs at 720p); `cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on this box's host cores:
+BASELINE config #1 in full (the reference's own CPU-runnable case), plus a FLOP-scaled estimate for the benched workload.
 """
 import argparse
 import contextlib
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--infer-steps", type=int, default=50, help="length of the full denoise schedule (frames/sec denominator)")
     ap.add_argument("--no-cfg", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=4.0, help="budget of the FLOP-scaled block sample (the config #1 leg runs in full)")
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
@@ -52,11 +52,12 @@ def parse():
     return ap.parse_args()
 
 
-def step_flops(dims, S, text_len, cfg_forwards):
+def step_flops(dims, S, text_len, cfg_forwards, cross_kv_cached=True):
     """Algorithmic FLOPs of one denoise step: per block GEMM = 12 S D^2 + 4 Lc D^2 + 4 S D F,
-    ATTN = 4 S^2 D + 4 S Lc D."""
+    ATTN = 4 S^2 D + 4 S Lc D.  The 4 Lc D^2 term (cross-attention K/V projections of the text) is step-invariant: with `cache_cross_kv`
+    (the default) it is computed once per prompt and is NOT part of a timed step, so it is not counted."""
     D, F, L = dims["dim"], dims["ffn_dim"], dims["num_layers"]
-    gemm = 12 * S * D * D + 4 * text_len * D * D + 4 * S * D * F
+    gemm = 12 * S * D * D + (0 if cross_kv_cached else 4 * text_len * D * D) + 4 * S * D * F
     attn = 4 * S * S * D + 4 * S * text_len * D
     return L * (gemm + attn) * cfg_forwards, L * attn * cfg_forwards
 
@@ -89,44 +90,96 @@ class AttnTimer:
 
 
 def cpu_baseline(dims, S_full, text_len, frames, infer_steps, cfg_forwards, budget_s):
-    """Times the CPU oracle (oracle/wan_oracle.py, a port of the reference's CPU path: torch bf16 addmm + torch_sdpa)
-    on a bounded sample: ONE transformer block of the workload's architecture at S_sample tokens, repeated for about
-    `budget_s` seconds; scaled to a full step by algorithmic FLOPs.  Baseline only — never the thing shipped."""
+    """The reference's CPU path (oracle/wan_oracle.py: torch bf16 addmm + torch_sdpa + the UniPC scheduler, pinned bit-exactly to the
+    reference) timed on this box's host cores.  Primary leg = BASELINE config #1 IN FULL, end to end: Wan2.1-T2V-1.3B, 256x256x17f
+    (S = 1280 tokens), 30 layers, 4 steps with CFG (8 forwards) + scheduler — no extrapolation.  Second field = one block of the benched
+    architecture at S = 1024 for a few seconds, scaled to the benched step by algorithmic FLOPs (an UNDER-estimate: attention is
+    quadratic in S).  Baseline only — never the thing shipped."""
     from lightx2v_amd import synth
     from oracle import wan_oracle as O
 
     threads = torch.get_num_threads()
-    d1 = dict(dims, num_layers=1)
-    wd = synth.synth_wan_weights(d1, seed=1)
-    S_s = 1024
-    grid = (4, 16, 16)
+    d1 = synth.WAN_DIMS["wan2.1-1.3b"]
+    wl1 = synth.WORKLOADS["wan1.3b_256x256x17f"]
+    wd = synth.synth_wan_weights(d1, seed=0)
+    lat, ctx, ctx_null = synth.synth_inputs(d1, wl1["target_shape"])
+    step_t = []
+    t0 = time.perf_counter()
+    O.denoise_loop(wd, d1, lat, ctx, ctx_null, 4, 8.0, 6.0, step_callback=lambda i, x: step_t.append(time.perf_counter()))
+    total = time.perf_counter() - t0
+    per_step = [b - a for a, b in zip([t0] + step_t[:-1], step_t)]
+    flop1, _ = step_flops(d1, synth.seq_len_of(wl1["target_shape"]), d1["text_len"], 2)
+    out = {
+        "value": wl1["frames"] / total,
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "workload": "BASELINE config #1: Wan2.1-T2V-1.3B bf16, 256x256x17f (1280 tokens), 4 steps, CFG",
+        "total_s": total,
+        "ms_per_step": [round(x * 1e3, 1) for x in per_step],
+        "tflops_per_s": flop1 * 4 / total / 1e12,
+        "sample": f"oracle denoise_loop (reference CPU path restated, pinned bit-exactly: torch bf16 addmm + torch_sdpa + UniPC), config #1 in full: "
+        f"4 CFG steps of the 30-layer 1.3B model at S=1280 in {total:.1f} s on {threads} threads = {wl1['frames'] / total:.3f} frames/s",
+    }
+    del wd
+    # second field: one block of the benched architecture, scaled by FLOPs
+    dd = dict(dims, num_layers=1)
+    wd = synth.synth_wan_weights(dd, seed=1)
+    S_s, grid = 1024, (4, 16, 16)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(S_s, dims["dim"], generator=g).to(torch.bfloat16)
     embed0 = (torch.randn(6, dims["dim"], generator=g) * 0.1).to(torch.bfloat16)
     context = torch.randn(text_len, dims["dim"], generator=g).to(torch.bfloat16)
     freqs = O.rope_freqs_table(128)
-    O.wan_block(wd, 0, d1, grid, x.clone(), embed0, freqs, context)  # warm-up
+    O.wan_block(wd, 0, dd, grid, x.clone(), embed0, freqs, context)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        O.wan_block(wd, 0, d1, grid, x.clone(), embed0, freqs, context)
+        O.wan_block(wd, 0, dd, grid, x.clone(), embed0, freqs, context)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 200:
             break
-    sec_per_block = el / n
-    flop_sample, _ = step_flops(d1, S_s, text_len, 1)
+    flop_sample, _ = step_flops(dd, S_s, text_len, 1, cross_kv_cached=False)
     flop_step, _ = step_flops(dims, S_full, text_len, cfg_forwards)
-    est_step_s = sec_per_block * flop_step / flop_sample
-    return {
-        "value": frames / (infer_steps * est_step_s),
-        "unit": "frames/s",
-        "cores": threads,
-        "kind": "port",
-        "ms_per_step_est": est_step_s * 1e3,
-        "sample": f"oracle wan_block (reference CPU path restated: torch bf16 addmm + torch_sdpa), 1 block of {dims['dim']}d/{dims['num_heads']}h at S={S_s}, "
-        f"{n} reps in {el:.1f}s ({sec_per_block * 1e3:.0f} ms/block, {flop_sample / sec_per_block / 1e12:.2f} TFLOP/s); scaled to the full step by algorithmic FLOPs "
-        f"(x{flop_step / flop_sample:.0f}; attention is quadratic in S so this UNDER-estimates the real CPU time)",
+    est = el / n * flop_step / flop_sample
+    out["benched_workload_estimate"] = {
+        "ms_per_step_est": est * 1e3,
+        "frames_per_s_est": frames / (infer_steps * est),
+        "sample": f"1 block of {dims['dim']}d/{dims['num_heads']}h at S={S_s}, {n} reps in {el:.1f} s ({el / n * 1e3:.0f} ms/block, {flop_sample / (el / n) / 1e12:.2f} TFLOP/s), "
+        f"scaled x{flop_step / flop_sample:.0f} by algorithmic FLOPs (under-estimates: attention is quadratic in S)",
     }
+    return out
+
+
+def ulysses_self_check(dist, world, rank):
+    """N > 1, before the timed region: a small Wan model (heads = 2 N) runs one CFG step sharded over the N ranks (the product Ulysses
+    path: RCCL all-to-alls on the blocked exchange buffers) and unsharded on every rank; the two noise predictions must agree to 5e-3
+    relative L2 on every rank (same kernels on re-partitioned rows).  The result travels in the JSON line so that a scaling record
+    proves N ranks really exchanged data."""
+    from lightx2v_amd import scheduler, synth, wan
+
+    dims = dict(synth.WAN_DIMS["wan-tiny"], dim=256 * world, num_heads=2 * world, ffn_dim=1024, num_layers=2)
+    ts = (16, 3, 8 * world, 12)  # tokens divisible by N
+    wd = synth.synth_wan_weights(dims, seed=3, device="cuda", gen_device="cuda")
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    outs = []
+    for pat in (None, "ulysses"):
+        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=pat)
+        model = wan.WanModel(cfg, wd)
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=lat)
+        model.set_scheduler(sch)
+        sch.step_pre(0)
+        model.infer(inputs)
+        outs.append(sch.noise_pred.float())
+    rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).reshape(1)
+    worst = rel.clone()
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    ok = bool(worst.item() < 5e-3)
+    if not ok:
+        raise SystemExit(f"bench: Ulysses self-check failed on rank {rank}: relative L2 {rel.item():.3e} (worst {worst.item():.3e})")
+    return {"ranks": world, "worst_rel_l2": worst.item(), "tolerance": 5e-3, "passed": ok}
 
 
 def main():
@@ -154,6 +207,8 @@ def main():
     enable_cfg = not (args.no_cfg or args.distill)
     if args.distill:
         args.infer_steps = 4
+        if args.warmup + args.steps > 4:  # the distilled schedule has 4 entries: wrap around instead of indexing past it
+            print(f"bench: --distill has a 4-step schedule; step indices wrap modulo 4 (warmup {args.warmup} + steps {args.steps})", file=sys.stderr)
     extra = {}
     if args.fp8:
         extra["mm_config"] = {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}
@@ -181,6 +236,7 @@ def main():
     model.transformer_infer.attn_time_hook = timer
 
     def one_step(i):
+        i = i % sch.infer_steps if args.distill else i
         sch.step_pre(i)
         model.infer(inputs)
         sch.step_post()
@@ -191,6 +247,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    sp_check = None
+    if world > 1:
+        sp_check = ulysses_self_check(dist, world, rank)
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -220,23 +279,34 @@ def main():
     flop_cross = 4.0 * s_local * dims["text_len"] * dims["num_heads"] * 128
     n_self, n_cross = timer.count("self"), timer.count("cross")
     ms_self, ms_cross = timer.total_ms("self"), timer.total_ms("cross")
+    # under Ulysses the self-attention of a layer is launched in two halves of the query rows (head->seq overlap, ulysses.py)
+    launches_per_attn = max(1, round(n_self / max(1, dims["num_layers"] * fwd * args.steps)))
+    flop_self /= launches_per_attn
     # roofline object = the self-attention launches of the dominant kernel (x2v::attn_fwd_v8_kernel: 99 % of the attention
     # FLOPs, 72 % of the step's); cross-attention runs a different instantiation and is reported beside it
     attn_ms = ms_self / max(n_self, 1)
     flop_launch = flop_self
     achieved = flop_launch / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic, traffic_note = None, "no PMC summary for this shape under profiles/"
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_attn_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_attn_traffic.json")
+    if not os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_attn_traffic.json")
     if world == 1 and os.path.exists(pmc_path):
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         if pmc.get("tokens") == S and pmc.get("heads") == heads_local:
             traffic, traffic_note = pmc["hbm_bytes_per_launch"], pmc["note"]
+    model_label = {"wan2.1-14b": "Wan2.1-14B", "wan2.1-1.3b": "Wan2.1-1.3B"}.get(wl["model"], wl["model"])
+    res_label = {"wan14b_720px81f": "720p 81f", "wan1.3b_480px49f": "480p 49f", "wan1.3b_256x256x17f": "256x256 17f"}.get(args.workload, args.workload)
+    fast_attn = not args.ref_rounding
     out = {
-        "metric": "denoise-step latency (ms) + video frames/sec, Wan2.1-14B 720p 81f @1/8 GPU",
+        "metric": f"denoise-step latency (ms) + video frames/sec, {model_label} {res_label} @{world}/8 GPU",
         "value": fps,
         "unit": "frames/s",
         "n_gpus": world,
+        "rccl_world": (dist.get_world_size() if dist is not None else 1),
+        "rccl_backend": (dist.get_backend() if dist is not None else None),
+        "sp_self_check": sp_check,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -260,7 +330,8 @@ def main():
             "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
         },
         "roofline": {
-            "kernel": "x2v::attn_fwd_v8_kernel<8, 8, true, 1, 4, 0, true> (self-attention launches)",
+            "kernel": ("x2v::attn_fwd_v8_kernel<8, 8, true, 1> (ping-pong, q prescaled; self-attention launches)" if fast_attn
+                       else "x2v::attn_fwd_pipe_kernel<8, 8> (reference-rounding mode; self-attention launches)"),
             "bound": "mfma",
             "achieved": achieved,
             "peak": BF16_MFMA_PEAK_TFLOPS,

@@ -178,6 +178,13 @@ int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk,
  * (mm_weight.py:236-245).  xq [M,K] bytes (ld = ldq), scale fp32 [M]. */
 int x2v_quant_fp8_rowwise(const void* x, int64_t ldx, void* xq, int64_t ldq, float* scale, int64_t M, int K, void* stream);
 
+/* x2v_layernorm_bf16 fused with x2v_quant_fp8_rowwise on its output: xq [M,D] e4m3 codes (ld = ldq) and sx [M] fp32 scales of the
+ * normalised (+affine, +modulated) row, bit-identical to the two calls in sequence — the w8a8 path's LayerNorm -> scaled_fp8_quant in front
+ * of the q/k/v and ffn_0 projections (transformer_infer.py:329-342,481-492 with mm_weight.py:236-245), without the bf16 round trip through
+ * HBM and quantised once for every projection that reads it.  512 < D <= 16384. */
+int x2v_layernorm_quant_fp8(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift, void* xq, int64_t ldq, float* sx,
+                            int64_t M, int D, float eps, void* stream);
+
 /* y[M,N] = epi((xq[M,K] . wq[N,K]^T) * sx[m] * sw[n] + bias[n]) → bf16 — replaces
  * torch.ops._C.cutlass_scaled_mm / sgl_kernel.fp8_scaled_mm (mm_weight.py:310-318,551-558,581-588).
  * e4m3fn operands, fp32 MFMA accumulate.  K % 128 == 0, N % 8 == 0. */

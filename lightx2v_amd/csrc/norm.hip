@@ -151,6 +151,96 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
   }
 }
 
+// LayerNorm (+affine, +adaLN modulate) fused with the per-token dynamic e4m3 quantisation of its output (w8a8 path): what the reference
+// runs as LNWeight.apply + mul_/add_ + scaled_fp8_quant in front of the q / k / v (or ffn_0) projections (mm_weight.py:236-245) — the
+// bf16 activation never goes to HBM, and the one quantised copy serves every projection that consumes it.  The normalised values are
+// rounded to bf16 exactly where layernorm_kernel rounds them (same expression order), so codes and scales are bit-identical to
+// x2v_layernorm_bf16 followed by x2v_quant_fp8_rowwise.  One block per row.
+template <int CH>
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const unsigned short* __restrict__ x, int64_t ldx, const unsigned short* __restrict__ w,
+                                                            const unsigned short* __restrict__ b, const unsigned short* __restrict__ scale,
+                                                            const unsigned short* __restrict__ shift, unsigned char* __restrict__ xq, int64_t ldq,
+                                                            float* __restrict__ sx, int D, float eps) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  RowRegs<CH, 4> r;
+  r.load(x + row * ldx, D, t);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += r.v[c][j];
+  s = block_sum<4>(s, red);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (r.ok[c]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = r.v[c][j] - mean;
+        q += d * d;
+      }
+    }
+  q = block_sum<4>(q, red);
+  const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!r.ok[c]) continue;
+    const int e = (c * 256 + t) * 8;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (r.v[c][j] - mean) * rstd;
+    if (w != nullptr) {
+      float wv[8];
+      unpack8(*reinterpret_cast<const uint4*>(w + e), wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= wv[j];
+    }
+    if (b != nullptr) {
+      float bv[8];
+      unpack8(*reinterpret_cast<const uint4*>(b + e), bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += bv[j];
+    }
+    if (scale != nullptr) {
+      float sc[8], sh[8];
+      unpack8(*reinterpret_cast<const uint4*>(scale + e), sc);
+      unpack8(*reinterpret_cast<const uint4*>(shift + e), sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float ln = rbf(o[j]);
+        float m = rbf(ln * rbf(1.0f + sc[j]));
+        o[j] = m + sh[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      r.v[c][j] = rbf(o[j]);  // the bf16 tensor the reference quantises
+      amax = fmaxf(amax, fabsf(r.v[c][j]));
+    }
+  }
+  amax = block_max<4>(amax, red);
+  const float qs = fmaxf(amax / 448.0f, 1.0f / (448.0f * 512.0f));  // quant_fp8_rowwise_kernel's scale rule
+  if (t == 0) sx[row] = qs;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!r.ok[c]) continue;
+    const int e = (c * 256 + t) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(r.v[c][j] / qs, -448.f), 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    *reinterpret_cast<uint2*>(xq + row * ldq + e) = make_uint2(lo, hi);
+  }
+}
+
 // Where the q|k norm+RoPE kernels write a row: in place (qo == nullptr), or out of place into N-blocked buffers — column e of token
 // `row` at (e / cbw) * cbs + row * ldo + e % cbw: the [N_ranks][S/N][(H/N) d] send buffer of the Ulysses seq->head exchange
 // (x2v_rmsnorm_rope_blocked_bf16), so no transposing copy stands between this kernel and the all-to-all.
@@ -684,6 +774,25 @@ extern "C" __attribute__((visibility("default"))) int x2v_layernorm_bf16_variant
     X2V_REQUIRE(variant != 2 || streamed, X2V_E_SHAPE, "layernorm: the streaming kernel covers 512 < D <= 8192 (D=%d)", D);
   }
   X2V_LAUNCH_CHECK("layernorm launch");
+  return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_layernorm_quant_fp8(const void* x, int64_t ldx, const void* w, const void* b, const void* scale, const void* shift,
+                                                                              void* xq, int64_t ldq, float* sx, int64_t M, int D, float eps, void* stream) {
+  X2V_REQUIRE(x && xq && sx, X2V_E_ARG, "layernorm_quant_fp8: null pointer");
+  X2V_REQUIRE((scale == nullptr) == (shift == nullptr), X2V_E_ARG, "layernorm_quant_fp8: scale and shift must be given together");
+  X2V_REQUIRE(D > 512 && D % 8 == 0 && D <= 16384, X2V_E_SHAPE, "layernorm_quant_fp8: D=%d must be a multiple of 8 in (512, 16384] (smaller rows: call the two kernels)", D);
+  X2V_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && aligned16(x) && ((uintptr_t)xq % 8) == 0 && aligned16(w) && aligned16(b) && aligned16(scale) && aligned16(shift), X2V_E_ALIGN,
+              "layernorm_quant_fp8: row alignment");
+  if (M <= 0) return X2V_OK;
+  const int ch = chunks_for(D, 4);
+  int rc = dispatch_ch(ch, D, [&](auto chc) {
+    constexpr int CH = decltype(chc)::value;
+    hipLaunchKernelGGL((layernorm_fp8_kernel<CH>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ldx, (const unsigned short*)w,
+                       (const unsigned short*)b, (const unsigned short*)scale, (const unsigned short*)shift, (unsigned char*)xq, ldq, sx, D, eps);
+  });
+  if (rc != X2V_OK) return rc;
+  X2V_LAUNCH_CHECK("layernorm_quant_fp8 launch");
   return X2V_OK;
 }
 

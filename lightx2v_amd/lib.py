@@ -48,6 +48,7 @@ PROTOTYPES = {
     "x2v_attn_fwd_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
+    "x2v_layernorm_quant_fp8": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _i32, _f32, _c_void_p],
     "x2v_quant_mxfp8_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_gemm_mxfp8_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p],
     "x2v_gemm_mxfp8_epi": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
@@ -410,6 +411,26 @@ def quant_fp8_rowwise(x):
     if M == 0:
         return xq, s
     _check(_lib.x2v_quant_fp8_rowwise(_p(x2), x2.stride(0), _p(xq), xq.stride(0), _p(s), M, K, _stream()), "quant_fp8_rowwise")
+    return xq, s
+
+
+def layernorm_quant_fp8(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6):
+    """(e4m3 codes [M, D], fp32 scales [M, 1]) of LN(x)[*w+b][*(1+scale)+shift] — x2v_layernorm_quant_fp8, bit-identical to
+    quant_fp8_rowwise(layernorm(...)).  Rows of <= 512 elements go through the two kernels."""
+    x2 = _row2d(_bf16(x, "x"), "x")
+    M, D = x2.shape
+    if D <= 512:
+        return quant_fp8_rowwise(layernorm(x2, weight, bias, scale, shift, eps))
+    if (scale is None) != (shift is None):
+        raise X2VError("layernorm_quant_fp8: scale and shift must be given together")
+    weight, bias = _vec(weight, "layernorm weight", D), _vec(bias, "layernorm bias", D)
+    scale, shift = _vec(scale, "layernorm scale", D), _vec(shift, "layernorm shift", D)
+    xq = torch.empty((M, D), dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+    init()
+    if M == 0:
+        return xq, s
+    _check(_lib.x2v_layernorm_quant_fp8(_p(x2), x2.stride(0), _p(weight), _p(bias), _p(scale), _p(shift), _p(xq), xq.stride(0), _p(s), M, D, eps, _stream()), "layernorm_quant_fp8")
     return xq, s
 
 

@@ -130,6 +130,11 @@ class MMWeightFp8Hip(_Movable):
         it once per LayerNorm output and hands the pair to every projection that consumes that tensor (`apply(..., quantized=)`)."""
         return lib.quant_fp8_rowwise(input_tensor)
 
+    @staticmethod
+    def layernorm_quantize(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6):
+        """LayerNorm (+affine, +modulate) and `quantize_input` of its output in one kernel (bit-identical to the two in sequence)."""
+        return lib.layernorm_quant_fp8(x, weight, bias, scale, shift, eps)
+
     def apply(self, input_tensor, epilogue=lib.EPI_NONE, resid=None, gate=None, out=None, row_slice=None, quantized=None):
         xq, sx = self.quantize_input(input_tensor) if quantized is None else quantized
         w, sw, b = self.weight, self.weight_scale, self.bias

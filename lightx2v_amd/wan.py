@@ -33,6 +33,18 @@ def _weight_signature(*ops_):
     return tuple(sig)
 
 
+def _ln_then_mm_input(op, x, weight=None, bias=None, scale=None, shift=None, eps=1e-6):
+    """LayerNorm feeding linear layers of operator class type(op): (bf16 activation | None, kwargs for op.apply).  Quantised classes get
+    the activation quantised ONCE for all consumers — fused into the LayerNorm kernel where the class offers it (fp8) — instead of once
+    inside every apply() (the reference quantises the same norm output three times for q, k, v: mm_weight.py:236-245)."""
+    if hasattr(op, "layernorm_quantize"):
+        return None, {"quantized": op.layernorm_quantize(x, weight, bias, scale, shift, eps)}
+    n = lib.layernorm(x, weight, bias, scale=scale, shift=shift, eps=eps)
+    if hasattr(op, "quantize_input"):
+        return n, {"quantized": op.quantize_input(n)}
+    return n, {}
+
+
 def _cfg(config, key, default=None):
     try:
         return config[key]
@@ -277,7 +289,8 @@ class WanTransformerInfer:
 
     def infer_self_attn(self, weights, grid_sizes, x, seq_lens, freqs, shift_msa, scale_msa, gate_msa):
         """transformer_infer.py:321-396 + the `x.add_(y * gate_msa)` of :402 folded into the o-projection."""
-        n1 = lib.layernorm(x, scale=scale_msa, shift=shift_msa, eps=weights.norm1.eps)  # norm1 has no affine (transformer_weights.py:127-129)
+        # norm1 has no affine (transformer_weights.py:127-129); quantised operator classes get n1 quantised once for q, k and v
+        n1, mmkw = _ln_then_mm_input(weights.self_attn_q, x, scale=scale_msa, shift=shift_msa, eps=weights.norm1.eps)
         grid = tuple(int(g) for g in grid_sizes[0].tolist())
         s_local = x.shape[0]
         if freqs.is_complex():  # driven by the reference's WanPreInfer: complex128 [1024, 64] (pre_infer.py:12-19)
@@ -302,10 +315,10 @@ class WanTransformerInfer:
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)  # K-blocked x
         # Ulysses, row-major form: v is projected first and its seq→head exchange runs on the communication stream under the q and k
         # projections and the norm+RoPE kernel
-        v = weights.self_attn_v.apply(n1)
+        v = weights.self_attn_v.apply(n1, **mmkw)
         v_pending = pa.begin_exchange(v) if hasattr(pa, "begin_exchange") else None
-        q = weights.self_attn_q.apply(n1)
-        k = weights.self_attn_k.apply(n1)
+        q = weights.self_attn_q.apply(n1, **mmkw)
+        k = weights.self_attn_k.apply(n1, **mmkw)
         lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
         if pa is None:
             # the ping-pong kernel reads V^T; transposed outside the timed launch so the hook times the attention kernel alone
@@ -322,8 +335,8 @@ class WanTransformerInfer:
 
     def infer_cross_attn(self, weights, x, context):
         """transformer_infer.py:398-465 (t2v) + the `x.add_(attn_out)` of :468 folded into the o-projection."""
-        n3 = lib.layernorm(x, weights.norm3.weight, weights.norm3.bias, eps=weights.norm3.eps)
-        q = weights.cross_attn_q.apply(n3)
+        n3, mmkw = _ln_then_mm_input(weights.cross_attn_q, x, weights.norm3.weight, weights.norm3.bias, eps=weights.norm3.eps)
+        q = weights.cross_attn_q.apply(n3, **mmkw)
         lib.rmsnorm(q, weights.cross_attn_norm_q.weight, weights.cross_attn_norm_q.eps, out=q, round_mode=self.round_mode)
         k, v = self._cross_kv(weights, context)
         attn = self._timed("cross", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim))
@@ -359,8 +372,8 @@ class WanTransformerInfer:
 
     def infer_ffn(self, weights, x, c_shift_msa, c_scale_msa, c_gate_msa):
         """transformer_infer.py:467-508: LN+modulate, ffn_0 (+GELU-tanh), ffn_2 (+`x.add_(y * c_gate)`)."""
-        n2 = lib.layernorm(x, scale=c_scale_msa, shift=c_shift_msa, eps=weights.norm2.eps)
-        h = weights.ffn_0.apply(n2, epilogue=lib.EPI_GELU_TANH)
+        n2, mmkw = _ln_then_mm_input(weights.ffn_0, x, scale=c_scale_msa, shift=c_shift_msa, eps=weights.norm2.eps)
+        h = weights.ffn_0.apply(n2, epilogue=lib.EPI_GELU_TANH, **mmkw)
         return weights.ffn_2.apply(h, epilogue=lib.EPI_RESIDUAL, resid=x, gate=c_gate_msa)
 
     def _timed(self, kind, fn):

@@ -157,3 +157,27 @@ def test_blocked_gemm_and_rope_equal_their_row_major_forms():
         ko = torch.full((2, S, H * 64), 7.0, dtype=torch.bfloat16, device="cuda")
         lib.rmsnorm_rope_blocked(q, k, wq, wk, tab, grid, H, qo, ko, s0=11, q_out_scale=lib.ATTN_PRESCALE)
         assert torch.equal(qo.transpose(0, 1).reshape(S, H * 128), q1) and torch.equal(ko.transpose(0, 1).reshape(S, H * 128), k1), S
+
+
+def test_layernorm_quant_fp8_is_the_two_kernels_fused():
+    """x2v_layernorm_quant_fp8 == x2v_quant_fp8_rowwise(x2v_layernorm_bf16(...)) bit for bit — plain, affine and modulated LayerNorm, ragged
+    row widths, both LayerNorm kernel forms on the unfused side (M small / large) — and the fp8 operator class consumes the shared pair."""
+    from lightx2v_amd import lib, registry
+
+    gen = torch.Generator().manual_seed(8)
+    for M, D in ((37, 1536), (3000, 5120), (64, 3072), (5, 256)):
+        x = (torch.randn(M, D, generator=gen) * 1.7 + 0.3).to(torch.bfloat16).cuda()
+        x[M // 2] = 0  # an all-zero token: the scale floor 1 / (448 * 512)
+        w, b = (1 + 0.1 * torch.randn(D, generator=gen)).to(torch.bfloat16).cuda(), (0.1 * torch.randn(D, generator=gen)).to(torch.bfloat16).cuda()
+        sc, sh = (0.2 * torch.randn(1, D, generator=gen)).to(torch.bfloat16).cuda(), (0.2 * torch.randn(1, D, generator=gen)).to(torch.bfloat16).cuda()
+        for kw in ({}, {"weight": w, "bias": b}, {"scale": sc, "shift": sh}):
+            xq, sx = lib.layernorm_quant_fp8(x, **kw)
+            rq, rs = lib.quant_fp8_rowwise(lib.layernorm(x, **kw))
+            assert torch.equal(sx, rs) and torch.equal(xq.view(torch.uint8), rq.view(torch.uint8)), (M, D, list(kw))
+    op = registry.MM_WEIGHT_REGISTER["W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip"]("w.weight", "w.bias")
+    op.set_config({"weight_auto_quant": True})
+    D, N = 1536, 512
+    op.load({"w.weight": (torch.randn(N, D, generator=gen) / math.sqrt(D)).to(torch.bfloat16).cuda(), "w.bias": torch.randn(N, generator=gen).to(torch.bfloat16).cuda()})
+    x = torch.randn(100, D, generator=gen).to(torch.bfloat16).cuda()
+    pair = op.layernorm_quantize(x, scale=sc[:, :D] if sc.shape[1] >= D else None, shift=sh[:, :D] if sh.shape[1] >= D else None)
+    assert torch.equal(op.apply(None, quantized=pair), op.apply(lib.layernorm(x, scale=sc[:, :D] if sc.shape[1] >= D else None, shift=sh[:, :D] if sh.shape[1] >= D else None)))

@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Second baseline of BASELINE.md §3: the reference's own op graph for one full denoise step (conditional + unconditional forward, CFG
+combine; the scheduler update is microseconds) executed by ROCm PyTorch on the SAME GPU — its `Default` operator classes are plain torch
+calls (common/ops/mm/mm_weight.py:81-88 torch.addmm; norm/layer_norm_weight.py:110 F.layer_norm; norm/rms_norm_weight.py:111-113 the
+bf16 chain; attn/attn_weight.py:229-239 F.scaled_dot_product_attention; wan/infer/utils.py:7-20,107-115 complex128 RoPE), so this
+script IS what the unmodified reference computes with `mm_type: Default`, `attention_type: torch_sdpa` on an MI355X (hipBLASLt GEMMs,
+AOTriton / math SDPA), without its runner / encoder plumbing.  `/root/reference` does not exist on the GPU box and `oracle/` is test
+infrastructure, so the op graph is restated here (tools/ never imports oracle/).
+
+    python tools/torch_step_baseline.py --workload wan1.3b_480px49f      (config #2)
+    python tools/torch_step_baseline.py --workload wan14b_720px81f       (config #3 on one GPU)
+
+Prints one JSON line: ms per step and per-op-class times; compare with `python bench.py --workload ...`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def mm(x, w, b):
+    return torch.addmm(b, x, w.t())
+
+
+def rms_norm(x, w, eps=1e-6):
+    x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+    return x * w
+
+
+def rope_params(max_seq_len, dim, theta=10000):
+    freqs = torch.outer(torch.arange(max_seq_len), 1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float64).div(dim)))
+    return torch.polar(torch.ones_like(freqs), freqs)
+
+
+def compute_freqs(c, grid, freqs):
+    f, h, w = grid
+    parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    return torch.cat([parts[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1), parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                      parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, 1, -1)
+
+
+def apply_rotary(x, freqs_i):
+    n, s = x.size(1), freqs_i.shape[0]
+    xi = torch.view_as_complex(x[:s].to(torch.float64).reshape(s, n, -1, 2))
+    return torch.view_as_real(xi * freqs_i).flatten(2).to(torch.bfloat16)
+
+
+def sdpa(q, k, v):
+    q, k, v = (t.unsqueeze(0).transpose(1, 2) for t in (q, k, v))
+    x = F.scaled_dot_product_attention(q, k, v).transpose(1, 2)
+    return x.reshape(x.shape[1], -1)
+
+
+class Timers:
+    def __init__(self):
+        self.ev = {}
+
+    def __call__(self, name, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        self.ev.setdefault(name, []).append((a, b))
+        return r
+
+    def totals(self):
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.ev.items()}
+
+
+def block(wd, i, H, grid, x, e0, freqs, context, T):
+    """wan/infer/transformer_infer.py:289-508, BF16 branch."""
+    p = f"blocks.{i}"
+    shift, scale, gate, c_shift, c_scale, c_gate = (wd[f"{p}.modulation"] + e0).chunk(6, dim=1)
+    n1 = T("elementwise", lambda: F.layer_norm(x, (x.shape[-1],), None, None, 1e-6).mul_(1 + scale.squeeze(0)).add_(shift.squeeze(0)))
+    s, d = n1.shape[0], x.shape[1] // H
+    a = f"{p}.self_attn"
+    q = T("gemm", lambda: mm(n1, wd[f"{a}.q.weight"], wd[f"{a}.q.bias"]))
+    k = T("gemm", lambda: mm(n1, wd[f"{a}.k.weight"], wd[f"{a}.k.bias"]))
+    v = T("gemm", lambda: mm(n1, wd[f"{a}.v.weight"], wd[f"{a}.v.bias"])).view(s, H, d)
+    q = T("elementwise", lambda: rms_norm(q, wd[f"{a}.norm_q.weight"])).view(s, H, d)
+    k = T("elementwise", lambda: rms_norm(k, wd[f"{a}.norm_k.weight"])).view(s, H, d)
+    fi = T("rope", lambda: compute_freqs(d // 2, grid, freqs))
+    q = T("rope", lambda: apply_rotary(q, fi))
+    k = T("rope", lambda: apply_rotary(k, fi))
+    attn = T("attention", lambda: sdpa(q, k, v))
+    y = T("gemm", lambda: mm(attn, wd[f"{a}.o.weight"], wd[f"{a}.o.bias"]))
+    T("elementwise", lambda: x.add_(y * gate.squeeze(0)))
+    n3 = T("elementwise", lambda: F.layer_norm(x, (x.shape[-1],), wd[f"{p}.norm3.weight"], wd[f"{p}.norm3.bias"], 1e-6))
+    c = f"{p}.cross_attn"
+    q = T("gemm", lambda: mm(n3, wd[f"{c}.q.weight"], wd[f"{c}.q.bias"]))
+    q = T("elementwise", lambda: rms_norm(q, wd[f"{c}.norm_q.weight"])).view(-1, H, d)
+    k = T("gemm", lambda: mm(context, wd[f"{c}.k.weight"], wd[f"{c}.k.bias"]))
+    k = rms_norm(k, wd[f"{c}.norm_k.weight"]).view(-1, H, d)
+    v = T("gemm", lambda: mm(context, wd[f"{c}.v.weight"], wd[f"{c}.v.bias"])).view(-1, H, d)
+    attn = T("attention", lambda: sdpa(q, k, v))
+    y = T("gemm", lambda: mm(attn, wd[f"{c}.o.weight"], wd[f"{c}.o.bias"]))
+    T("elementwise", lambda: x.add_(y))
+    n2 = T("elementwise", lambda: F.layer_norm(x, (x.shape[-1],), None, None, 1e-6).mul_(1 + c_scale.squeeze(0)).add_(c_shift.squeeze(0)))
+    h = T("gemm", lambda: mm(n2, wd[f"{p}.ffn.0.weight"], wd[f"{p}.ffn.0.bias"]))
+    h = T("elementwise", lambda: F.gelu(h, approximate="tanh"))
+    y = T("gemm", lambda: mm(h, wd[f"{p}.ffn.2.weight"], wd[f"{p}.ffn.2.bias"]))
+    T("elementwise", lambda: x.add_(y * c_gate.squeeze(0)))
+    return x
+
+
+def forward(wd, dims, lat, t, ctx, freqs, T):
+    """pre_infer.py:29-120 + block loop + post_infer.py:15-50."""
+    D, H = dims["dim"], dims["num_heads"]
+    x = F.conv3d(lat.unsqueeze(0), wd["patch_embedding.weight"], wd["patch_embedding.bias"], stride=(1, 2, 2))
+    grid = tuple(x.shape[2:])
+    x = x.flatten(2).transpose(1, 2).squeeze(0).contiguous()
+    half = 128
+    pos = t.flatten().to(torch.float64)
+    sin = torch.outer(pos, torch.pow(10000, -torch.arange(half, device=pos.device).to(pos).div(half)))
+    emb = torch.cat([torch.cos(sin), torch.sin(sin)], dim=1).to(torch.bfloat16)
+    emb = mm(F.silu(mm(emb, wd["time_embedding.0.weight"], wd["time_embedding.0.bias"])), wd["time_embedding.2.weight"], wd["time_embedding.2.bias"])
+    e0 = mm(F.silu(emb), wd["time_projection.1.weight"], wd["time_projection.1.bias"]).unflatten(1, (6, D)).squeeze(0)
+    tl = dims.get("text_len", 512)
+    c = torch.cat([ctx, ctx.new_zeros(tl - ctx.size(0), ctx.size(1))])
+    c = mm(F.gelu(mm(c, wd["text_embedding.0.weight"], wd["text_embedding.0.bias"]), approximate="tanh"), wd["text_embedding.2.weight"], wd["text_embedding.2.bias"])
+    for i in range(dims["num_layers"]):
+        x = block(wd, i, H, grid, x, e0, freqs, c, T)
+    e = (wd["head.modulation"] + emb.unsqueeze(1)).chunk(2, dim=1)
+    x = F.layer_norm(x, (D,), None, None, 1e-6).mul_(1 + e[1].squeeze(0)).add_(e[0].squeeze(0))
+    x = mm(x, wd["head.head.weight"], wd["head.head.bias"])
+    f, h, w = grid
+    return torch.einsum("fhwpqrc->cfphqwr", x.view(f, h, w, 1, 2, 2, 16)).reshape(16, f, h * 2, w * 2).float()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="wan1.3b_480px49f")
+    ap.add_argument("--steps", type=int, default=1)
+    args = ap.parse_args()
+    from lightx2v_amd import synth
+
+    wl = synth.WORKLOADS[args.workload]
+    dims = synth.WAN_DIMS[wl["model"]]
+    wd = synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda")
+    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    lat, ctx, ctx_null = lat.cuda().to(torch.bfloat16), ctx[0].cuda(), ctx_null[0].cuda()
+    d = dims["dim"] // dims["num_heads"]
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1).cuda()
+    t = torch.tensor([999], device="cuda")
+    with torch.no_grad():
+        warm = Timers()
+        wd1 = dict(dims, num_layers=1)
+        forward(wd, wd1, lat, t, ctx, freqs, warm)  # one-layer warm-up (library / kernel selection)
+        torch.cuda.synchronize()
+        T = Timers()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cond = forward(wd, dims, lat, t, ctx, freqs, T)
+            uncond = forward(wd, dims, lat, t, ctx_null, freqs, T)
+            pred = uncond + 6.0 * (cond - uncond)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+    assert torch.isfinite(pred).all()
+    tot = T.totals()
+    print(json.dumps({"baseline": "reference op graph (Default mm = torch.addmm, torch_sdpa, complex128 RoPE) on ROCm PyTorch, same GPU", "workload": args.workload,
+                      "tokens": synth.seq_len_of(wl["target_shape"]), "ms_per_step": el * 1e3, "frames_per_s_50_steps": wl["frames"] / (50 * el),
+                      "ms_by_op_class_per_step": {k: v / args.steps for k, v in tot.items()}, "torch": torch.__version__,
+                      "device": torch.cuda.get_device_name(0), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))
+
+
+if __name__ == "__main__":
+    main()
