@@ -25,11 +25,16 @@ def test_step_flops_match_survey_table(bench):
         wl = synth.WORKLOADS[name]
         dims = synth.WAN_DIMS[wl["model"]]
         assert synth.seq_len_of(wl["target_shape"]) == S
-        total, attn = bench.step_flops(dims, S, dims["text_len"], 2)
+        total, attn = bench.step_flops(dims, S, dims["text_len"], 2, cross_kv_cached=False)  # the survey's table counts every GEMM of the reference block
         L = dims["num_layers"]
         assert attn / (2 * L) == pytest.approx(attn_blk, rel=2e-3)
         assert (total - attn) / (2 * L) == pytest.approx(gemm_blk, rel=2e-3)
         assert total == pytest.approx(step, rel=2e-3)
+    # what a timed step really executes: the text K/V projections (4 Lc D^2 per block) are step-invariant and cached (wan.py cache_cross_kv)
+    d14 = synth.WAN_DIMS["wan2.1-14b"]
+    full, _ = bench.step_flops(d14, 75600, 512, 2, cross_kv_cached=False)
+    timed, _ = bench.step_flops(d14, 75600, 512, 2)
+    assert full - timed == 2 * d14["num_layers"] * 4 * 512 * d14["dim"] ** 2 and timed / full > 0.999
     # the distilled config runs one forward per step: half the CFG step
     dims = synth.WAN_DIMS["wan2.1-14b"] if "wan2.1-14b" in synth.WAN_DIMS else synth.WAN_DIMS[synth.WORKLOADS["wan14b_720px81f"]["model"]]
     assert bench.step_flops(dims, 75600, 512, 1)[0] * 2 == bench.step_flops(dims, 75600, 512, 2)[0]
