@@ -168,8 +168,8 @@ int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt,
 
 /* x2v_attn_fwd_bf16 on a pre-transposed V (x2v_transpose_heads_bf16) — the "ping-pong" kernel the fused block drivers launch for
  * self-attention (transformer_infer.py:369-379): V^T is staged by LDS-DMA and read as plain 16-byte fragments, the softmax scale * log2(e)
- * lives in q.  q_prescaled bit 0: q already carries scale*log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16 folded it into
- * q's one rounding), else the kernel multiplies and re-rounds q itself; bits 1..: kernel-body selector for A/B measurements (0 = default). */
+ * lives in q.  q_prescaled = 1: q already carries scale*log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16 folded it into
+ * q's one rounding); 0: the kernel multiplies and re-rounds q itself. */
 int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                          int H, int head_dim, float scale, int q_prescaled, void* stream);
 

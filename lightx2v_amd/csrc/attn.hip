@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //     is the same wave's previous half-step), q carries scale*log2(e) (PRESCALED: folded in by the producer), so P = exp2(S') with
 //     no per-score FMA; rescale stays lazy (cold branch, threshold RESCALE_THR in base-2 units);
 //   * one score buffer: nothing spills at 2 waves per SIMD.
-// TUNE = 1 (round 2; what the .s of TUNE = 0 showed in the matrix half-step, which sets the kernel's pace):
+// Round 2 (what the .s of the round-1 body showed in the matrix half-step; +3.9 %, profiles/r02_attn_pingpong_tune_ab.log):
 //   (a) hipcc computed the second score chain IN the registers of the -m tuple and copied it out afterwards (s_nop 8 + 8 v_mov_b64
 //       between QK^T and PV, and 8 more v_mov_b64 per tile to restore -m): the first MFMA of each chain now goes through an asm
 //       statement whose output is early-clobber, so -m stays a pure input and nothing is copied;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //       into the vector half-step;
 //   (c) the tile loop is unrolled x2 so that both LDS buffer indices are compile-time: every fragment address is
 //       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
-template <int NW, int RESCALE_THR, bool PRESCALED, int TUNE>
+template <int NW, int RESCALE_THR, bool PRESCALED>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
                                                                    const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
       const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                             \
       if (n < 16) {                                                                                            \
         const int ks = n >> 1, u = n & 1;                                                                      \
-        if (TUNE >= 1 && ks == 0) /* D early-clobber: the -m tuple stays a pure input */                       \
+        if (ks == 0) /* D early-clobber: the -m tuple stays a pure input */                                    \
           asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sc[u]) : "v"(f_), "v"(qf[0]), "v"(negm)); \
         else                                                                                                   \
           sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, qf[ks], ks == 0 ? negm : sc[u], 0, 0, 0);        \
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
       lsum[(e + 1) & 3] += p1;                                                                                 \
       pw[uu * 8 + (e >> 1)] = pack_bf2(p0, p1);                                                                \
     }                                                                                                          \
-    if (TUNE >= 1) { /* the row sums belong to THIS half-step: without the pin hipcc sinks the adds behind the next PV MFMAs */ \
+    { /* the row sums belong to THIS half-step: without the pin hipcc sinks the adds behind the next PV MFMAs */ \
       asm volatile("" : "+v"(lsum[0]), "+v"(lsum[1]), "+v"(lsum[2]), "+v"(lsum[3]));                           \
       A8_SB();                                                                                                 \
     }                                                                                                          \
@@ -504,27 +504,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   if (wid < NW / 2) {
     A8_MATRIX(0, 16, 0, 0)
     A8_BAR_EVEN()
-    if constexpr (TUNE >= 1) {
-      // iteration t: softmax(t) | matrix {QK^T(t+1) from K buffer (t+1)&1, PV(t) from V^T buffer t&1}; t starts even
-      while (t < nt - 1) {
-        A8_SOFTMAX(false)
-        A8_BAR_ODD()
-        A8_MATRIX(0, 32, 0, 1)
-        A8_BAR_EVEN()
-        if (++t >= nt - 1) break;
-        A8_SOFTMAX(false)
-        A8_BAR_ODD()
-        A8_MATRIX(0, 32, 1, 0)
-        A8_BAR_EVEN()
-        ++t;
-      }
-    } else {
-      for (; t < nt - 1; ++t) {
-        A8_SOFTMAX(false)
-        A8_BAR_ODD()
-        A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
-        A8_BAR_EVEN()
-      }
+    // iteration t: softmax(t) | matrix {QK^T(t+1) from K buffer (t+1)&1, PV(t) from V^T buffer t&1}; t starts even (x2: constant buffer offsets)
+    while (t < nt - 1) {
+      A8_SOFTMAX(false)
+      A8_BAR_ODD()
+      A8_MATRIX(0, 32, 0, 1)
+      A8_BAR_EVEN()
+      if (++t >= nt - 1) break;
+      A8_SOFTMAX(false)
+      A8_BAR_ODD()
+      A8_MATRIX(0, 32, 1, 0)
+      A8_BAR_EVEN()
+      ++t;
     }
     A8_SOFTMAX(true)
     A8_BAR_ODD()
@@ -536,29 +527,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
     A8_BAR_EVEN()
     A8_MATRIX(0, 16, 0, 0)
     A8_BAR_ODD()
-    if constexpr (TUNE >= 1) {
-      while (t < nt - 1) {
-        A8_ISSUE(t + 1)
-        A8_SOFTMAX(false)
-        A8_BAR_EVEN()
-        A8_MATRIX(0, 32, 0, 1)
-        A8_BAR_ODD()
-        if (++t >= nt - 1) break;
-        A8_ISSUE(t + 1)
-        A8_SOFTMAX(false)
-        A8_BAR_EVEN()
-        A8_MATRIX(0, 32, 1, 0)
-        A8_BAR_ODD()
-        ++t;
-      }
-    } else {
-      for (; t < nt - 1; ++t) {
-        A8_ISSUE(t + 1)
-        A8_SOFTMAX(false)
-        A8_BAR_EVEN()
-        A8_MATRIX(0, 32, t & 1, (t + 1) & 1)
-        A8_BAR_ODD()
-      }
+    while (t < nt - 1) {
+      A8_ISSUE(t + 1)
+      A8_SOFTMAX(false)
+      A8_BAR_EVEN()
+      A8_MATRIX(0, 32, 0, 1)
+      A8_BAR_ODD()
+      if (++t >= nt - 1) break;
+      A8_ISSUE(t + 1)
+      A8_SOFTMAX(false)
+      A8_BAR_EVEN()
+      A8_MATRIX(0, 32, 1, 0)
+      A8_BAR_ODD()
+      ++t;
     }
     A8_SOFTMAX(true)
     A8_BAR_EVEN()
@@ -627,16 +608,7 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const unsigned sho
 }
 
 }  // namespace x2v
-namespace x2v {
-int attn_w64_dispatch(bool prescaled, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                      int H, float scale, hipStream_t st);  // attn64.hip
-int attn_w64_probe(int probe, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk, int H, float scale,
-                    hipStream_t st);
-}
 using namespace x2v;
-
-// which body x2v_attn_fwd_bf16_vt launches by default (kind 0); kind 1 launches the other one (A/B)
-#define X2V_ATTN_VT_DEFAULT_TUNE 1
 
 template <int NW, int THR>
 static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
@@ -655,12 +627,12 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
   return X2V_OK;
 }
 
-template <int NW, int THR, bool PRESCALED, int TUNE>
+template <int NW, int THR, bool PRESCALED>
 static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                           int H, float scale, hipStream_t st) {
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (int64_t)AT_D * ldvt * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
-  auto kern = attn_fwd_v8_kernel<NW, THR, PRESCALED, TUNE>;
+  auto kern = attn_fwd_v8_kernel<NW, THR, PRESCALED>;
   int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
   if (rc != X2V_OK) return rc;
   dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H);
@@ -691,20 +663,10 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
               "attn_vt: rows must be 16-byte aligned, ldvt a multiple of 64");
   X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D, X2V_E_SHAPE, "attn_vt: token stride smaller than H*128");
   if (scale <= 0.f) scale = 0.08838834764831845f;
-  // bit 0: q already carries scale*log2(e); bits 1.. select a kernel body for A/B measurements (0 = default)
-  const int pre = q_prescaled & 1, kind = q_prescaled >> 1;
+  X2V_REQUIRE((q_prescaled & ~1) == 0, X2V_E_ARG, "attn_vt: q_prescaled must be 0 or 1");
   hipStream_t st = (hipStream_t)stream;
-  switch (kind) {
-    case 0:
-      return pre ? launch_attn_vt<8, 8, true, X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
-                 : launch_attn_vt<8, 8, false, X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
-    case 1:
-      return pre ? launch_attn_vt<8, 8, true, 1 - X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
-                 : launch_attn_vt<8, 8, false, 1 - X2V_ATTN_VT_DEFAULT_TUNE>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
-    case 2: return attn_w64_dispatch(pre != 0, q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);  // 64 query rows per wave (attn64.hip)
-    case 3: case 4: case 5: return attn_w64_probe(kind - 2, q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);  // TEMPORARY timing probes
-    default: set_error("attn_vt: unknown kernel selector %d", kind); return X2V_E_ARG;
-  }
+  return (q_prescaled & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
+                           : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
 }
 
 // variant: 0 = default (= 6); lazy-rescale threshold of the pipelined kernel: 4 = eager rescale (every tile), 5 = threshold 4, 6 = threshold 8

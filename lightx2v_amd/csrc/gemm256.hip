@@ -12,7 +12,7 @@
 //     B0 | A_a | B1 | A_b by LDS-DMA (buffer_load ... lds, 16 B/lane) into a ring of 8 slots (two K-tiles), LEAD
 //     half-tiles ahead of their use; the swizzle  chunk ^= (row>>1)&7  is applied on the per-lane SOURCE offset and
 //     on the ds_read_b128 address (the DMA destination is lane-linear);
-//   * a K-tile is four phases of 8 MFMAs (32x32x16; fp8: 4 of the MX-scaled 32x32x64) per wave:
+//   * a K-tile is four phases of 16 MFMAs (bf16: 16x16x32, two per 32x32 quadrant pair; fp8: 4 of the MX-scaled 32x32x64) per wave:
 //         q0: read A_a      -> acc[0..1][0] += A_a.B0        q1: read B1 -> acc[0..1][1] += A_a.B1
 //         q2: read A_b      -> acc[2..3][0] += A_b.B0        q3: read next tile's B0 -> acc[2..3][1] += A_b.B1
 //     each phase = {fragment ds_reads + one half-tile of DMA issue | s_barrier | MFMAs | counted vmcnt | s_barrier};
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(LEAD >= KW + 3 && LEAD <= 7 && LEAD >= 4, "see the hazard accounting in the header comment (and the A-half K offsets ak1/ak2)");
   static_assert(!MX || FP8, "MX: block-scaled fp8");
+  // bf16 runs on v_mfma_f32_16x16x32_bf16: at the board's power limit (where this kernel lives) the 16x16 shape delivers ~11 % more FLOP/s
+  // than 32x32x16 for the same LDS fragment traffic (tools/probes/mfma_power_probe.hip, profiles/r02_mfma_power_probe.log)
+  constexpr bool MI16 = !FP8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -112,7 +115,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   //      instruction's own k order (first 16 bytes of a lane = k fh*16.., last 16 = k 32+fh*16..), which matters once the
   //      hardware applies block scales (MX); with unit scales any map shared by A and B would do.
   int rd_a[4], rd_b[4];
-  {
+  if constexpr (MI16) {
+    // 16x16x32: a lane reads row r16 of a 16-row block, 16-byte chunk ks*4 + g16 (k = 8 g16 .. 8 g16 + 7 of the 32-wide step); slot b*2 + ks =
+    // 16-row block b of the wave's 32 rows, k-step ks.  With the same chunk ^= (row>>1)&7 image the four lane groups of a ds_read_b128 still
+    // cover sixteen distinct 16-byte columns of the 256-byte bank line (rows of equal parity never share a chunk within a group).
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int swz = (r16 >> 1) & 7;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int o = (b * 16 + r16) * 128 + ((((ks << 2) | g16) ^ swz) << 4);
+        rd_a[b * 2 + ks] = o + wr * 4096;
+        rd_b[b * 2 + ks] = o + wc * 4096;
+      }
+  } else {
     const int swz = (fl >> 1) & 7;
     const int lp = fh ^ swz;
 #pragma unroll
@@ -124,13 +141,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     }
   }
 
+  // accumulators of the wave's 4 x 2 set of 32x32 regions: one 32x32 MFMA tile each (fp8), or 2 x 2 tiles of 16x16 (bf16): acc4[mi][nj][xh*2+wh]
   f32x16_t acc[4][2];
+  f32x4_t acc4[4][2][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        acc4[i][j][e >> 2][e & 3] = 0.f;
+      }
   i32x4_t xa[2][4], wb0[4], wb1[4];
 
   // ---- MX block scales: per operand row and K-tile one dword = the 4 e8m0 bytes of its 32-wide k blocks, tables [K/128][rows]
@@ -169,16 +191,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) DST_[ks_] = *reinterpret_cast<const i32x4_t*>(smem + (SLOT_) * T_HALF_BYTES + (EXTRA_) + RD_[ks_]);
 
   // 8 MFMAs (fp8: 4) of one phase
-#define T_MFMA(MI0_, NJ_, WB_)                                                                                                 \
-  if constexpr (!FP8) {                                                                                                        \
-    _Pragma("unroll") for (int idx_ = 0; idx_ < 8; ++idx_) {                                                                   \
+#define T_MFMA(MI0_, NJ_, WB_, I0_, I1_)                                                                                                 \
+  if constexpr (MI16) {                                                                                                        \
+    _Pragma("unroll") for (int idx_ = (I0_); idx_ < (I1_); ++idx_) {                                                            \
+      const int ks_ = idx_ >> 3, wh_ = (idx_ >> 2) & 1, i_ = (idx_ >> 1) & 1, xh_ = idx_ & 1;                                  \
+      acc4[(MI0_) + i_][NJ_][xh_ * 2 + wh_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                         \
+          __builtin_bit_cast(bf16x8_t, WB_[wh_ * 2 + ks_]), __builtin_bit_cast(bf16x8_t, xa[i_][xh_ * 2 + ks_]), acc4[(MI0_) + i_][NJ_][xh_ * 2 + wh_], 0, 0, 0); \
+    }                                                                                                                          \
+  } else if constexpr (!FP8) {                                                                                                 \
+    _Pragma("unroll") for (int idx_ = (I0_) / 2; idx_ < (I1_) / 2; ++idx_) {                                                                   \
       const int ks_ = idx_ >> 1, i_ = idx_ & 1;                                                                                \
       acc[(MI0_) + i_][NJ_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WB_[ks_]),                  \
                                                                       __builtin_bit_cast(bf16x8_t, xa[i_][ks_]), acc[(MI0_) + i_][NJ_], 0, 0, 0); \
     }                                                                                                                          \
   } else {                                                                                                                     \
     constexpr int kOne = 0x7f7f7f7f; /* e8m0 2^0 block scales */                                                               \
-    _Pragma("unroll") for (int idx_ = 0; idx_ < 4; ++idx_) {                                                                   \
+    _Pragma("unroll") for (int idx_ = (I0_) / 4; idx_ < (I1_) / 4; ++idx_) {                                                   \
       const int s_ = idx_ >> 1, i_ = idx_ & 1;                                                                                 \
       const i32x8_t wf_ = __builtin_shufflevector(WB_[2 * s_], WB_[2 * s_ + 1], 0, 1, 2, 3, 4, 5, 6, 7);                       \
       const i32x8_t xf_ = __builtin_shufflevector(xa[i_][2 * s_], xa[i_][2 * s_ + 1], 0, 1, 2, 3, 4, 5, 6, 7);                 \
@@ -191,7 +219,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     }                                                                                                                          \
   }
 
-#define T_PIN(MI0_, NJ_) asm volatile("" : "+v"(acc[(MI0_)][NJ_]), "+v"(acc[(MI0_) + 1][NJ_]));
+#define T_MFMA_Q(Q_, I0_, I1_)                                                                                                 \
+  if constexpr ((Q_) == 0) { T_MFMA(0, 0, wb0, I0_, I1_) }                                                                     \
+  else if constexpr ((Q_) == 1) { T_MFMA(0, 1, wb1, I0_, I1_) }                                                                \
+  else if constexpr ((Q_) == 2) { T_MFMA(2, 0, wb0, I0_, I1_) }                                                                \
+  else { T_MFMA(2, 1, wb1, I0_, I1_) }
+
+#define T_PIN(MI0_, NJ_)                                                                                                       \
+  if constexpr (MI16)                                                                                                          \
+    asm volatile("" : "+v"(acc4[(MI0_)][NJ_][0]), "+v"(acc4[(MI0_)][NJ_][1]), "+v"(acc4[(MI0_)][NJ_][2]), "+v"(acc4[(MI0_)][NJ_][3]), \
+                 "+v"(acc4[(MI0_) + 1][NJ_][0]), "+v"(acc4[(MI0_) + 1][NJ_][1]), "+v"(acc4[(MI0_) + 1][NJ_][2]), "+v"(acc4[(MI0_) + 1][NJ_][3])); \
+  else                                                                                                                         \
+    asm volatile("" : "+v"(acc[(MI0_)][NJ_]), "+v"(acc[(MI0_) + 1][NJ_]));
 
   // One phase.  TB_ = K-tile parity (compile time), Q_ = phase within the tile, t = K-tile index (run time);
   // CHK_ = 0: steady state (every phase issues its half-tile; counted wait), 1: tail (issue / wait by run-time test).
@@ -219,10 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
        accumulators in place with empty asm statements on both sides of the cluster */                                       \
     T_PIN(((Q_) >> 1) * 2, (Q_) == 1 || (Q_) == 3)                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                             \
-    if constexpr ((Q_) == 0) { T_MFMA(0, 0, wb0) }                                                                             \
-    else if constexpr ((Q_) == 1) { T_MFMA(0, 1, wb1) }                                                                        \
-    else if constexpr ((Q_) == 2) { T_MFMA(2, 0, wb0) }                                                                        \
-    else { T_MFMA(2, 1, wb1) }                                                                                                 \
+    T_MFMA_Q(Q_, 0, 16)                                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                                             \
     T_PIN(((Q_) >> 1) * 2, (Q_) == 1 || (Q_) == 3)                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
@@ -230,6 +266,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
     if (live_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KW + ((CHK_) == 0 && (Q_) < KW ? NSC : 0)) : "memory");            \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
     if constexpr (MX && (Q_) == 3) T_SC_ADOPT()                                                                                \
+    /* (issuing the last 4 or 8 MFMAs of the cluster behind this barrier, so that the other wave of the SIMD starts while they   \
+       drain, measured 8-10 % SLOWER: profiles/r02_gemm256_mi16_trail_ab.log) */                                                \
     __builtin_amdgcn_s_barrier();                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                         \
   }
@@ -288,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #undef T_AK_NEXT
 #undef T_PIN
 #undef T_MFMA
+#undef T_MFMA_Q
 #undef T_RD
 #undef T_ISSUE
 #undef T_ISSUE1
@@ -295,7 +334,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 #undef T_SC_ADOPT
 
   // ---- epilogue phase 1: acc (+scales, bias, activation) -> bf16 -> LDS [256][T_EPI_LD]
-  //      acc[mi][nj][r]: tile row mi*64 + wr*32 + fl, tile col nj*128 + wc*32 + (r&3) + 8*(r>>2) + 4*fh
+  //      32x32 tiles: acc[mi][nj][4g+e]  = tile row mi*64 + wr*32 + fl,               tile col nj*128 + wc*32 + 8*g + 4*fh + e
+  //      16x16 tiles: acc4[mi][nj][g][e] = tile row mi*64 + wr*32 + (g>>1)*16 + r16,  tile col nj*128 + wc*32 + (g&1)*16 + 4*g16 + e
+  const int e_r16 = lane & 15, e_g16 = lane >> 4;
   //      All per-column operands (bias, fp8 channel scales) are fetched up front in one batch: one L2 round trip.
   uint2 bv[2][4];
   float4 swv[2][4];
@@ -304,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      int gn = n0 + nj * 128 + wc * 32 + 8 * g + 4 * fh;
+      int gn = n0 + nj * 128 + wc * 32 + (MI16 ? (g & 1) * 16 + 4 * e_g16 : 8 * g + 4 * fh);
       gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
       bv[nj][g] = make_uint2(0u, 0u);
       if (bias != nullptr) bv[nj][g] = *reinterpret_cast<const uint2*>(bias + gn);
@@ -323,15 +364,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
   }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const int ml = mi * 64 + wr * 32 + fl;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = nj * 128 + wc * 32 + 8 * g + 4 * fh;
+        const int ml = mi * 64 + wr * 32 + (MI16 ? (g >> 1) * 16 + e_r16 : fl);
+        const int nl = nj * 128 + wc * 32 + (MI16 ? (g & 1) * 16 + 4 * e_g16 : 8 * g + 4 * fh);
         float vv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = acc[mi][nj][4 * g + e];
+        for (int e = 0; e < 4; ++e) vv[e] = MI16 ? acc4[mi][nj][g][e] : acc[mi][nj][4 * g + e];
         if constexpr (MX) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] *= mx_alpha;

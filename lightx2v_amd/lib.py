@@ -185,8 +185,6 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
 ATTN_Q_PRESCALED = 0x100
 ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
 #                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
-ATTN_FAST_ALT = 13  # the same entry's alternative kernel body (A/B measurements; include/x2v.h)
-ATTN_W64 = 14  # the same entry, 64 query rows per wave (csrc/attn64.hip)
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
 
 
@@ -384,14 +382,14 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
     init()
     if Sq == 0:
         return out2
-    if (variant & 0xFF) in (ATTN_FAST, ATTN_FAST_ALT, ATTN_W64):
+    if (variant & 0xFF) == ATTN_FAST:
         if vt is None:
             vt = transpose_heads(v2, num_heads)
         elif vt.dtype != torch.bfloat16 or not vt.is_cuda or not vt.is_contiguous() or tuple(vt.shape) != (num_heads, (Sk + 63) // 64, 128, 64):
             raise X2VError(f"attention: vt must be the contiguous bf16 [H, ceil(Sk/64), 128, 64] tensor of transpose_heads, got {tuple(vt.shape)}")
         _check(
             _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[1] * 64, _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
-                                      (1 if (variant & ATTN_Q_PRESCALED) else 0) | (((variant & 0xFF) - ATTN_FAST) << 1), _stream()),
+                                      1 if (variant & ATTN_Q_PRESCALED) else 0, _stream()),
             "attn_fwd_vt",
         )
         return out2
@@ -558,6 +556,25 @@ def _f32c(t, name):
     return t
 
 
+def _f32dense(t, name, dim=None, numel=None):
+    """None passes through; otherwise a contiguous float32 device tensor (of rank `dim` / `numel` elements when given)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise X2VError(f"{name}: expected a contiguous float32 device tensor, got {t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
+    if dim is not None and t.dim() != dim:
+        raise X2VError(f"{name}: expected rank {dim}, got shape {tuple(t.shape)}")
+    if numel is not None and t.numel() != numel:
+        raise X2VError(f"{name}: expected {numel} elements, got shape {tuple(t.shape)}")
+    return t
+
+
+def _dev_view(t, name, dtypes):
+    if t.dtype not in dtypes or not t.is_cuda:
+        raise X2VError(f"{name}: expected a device tensor of {' / '.join(str(d) for d in dtypes)}, got {t.dtype} on {t.device}")
+    return t
+
+
 def vae_conv(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0, w_row_stride=None, cin=None):
     """Implicit-GEMM convolution over a zero-bordered buffer (x2v_vae_conv_f32).  `xp`: tensor VIEW whose first element is
     what tap (0,0,0) of output pixel (0,0,0) reads; strides = (frame, row, pixel) in floats; weight [Cout,kt,kh,kw,Cin]
@@ -589,14 +606,15 @@ def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0
 
 def vae_prep(x, y_view, y_strides, gamma=None, a=None, b=None, silu=False, upsample=False):
     """x [T,H,W,C] contiguous fp32 -> y_view (first element = destination of pixel (0,0,0)); y_strides = (frame, row) in floats."""
-    T, H, W, C = x.shape
+    T, H, W, C = _f32dense(x, "vae_prep x", 4).shape
+    for nm, t in (("gamma", gamma), ("a", a), ("b", b)):
+        _f32dense(t, f"vae_prep {nm}", numel=C)
+    _dev_view(y_view, "vae_prep y", (torch.float32, torch.float16))
     init()
     if y_view.dtype == torch.float16:  # operand buffer of the 16-bit convolution: channel axis possibly padded (pixel stride from the view)
-        _f32c(x, "vae_prep x")
         _check(_lib.x2v_vae_prep_f16(_p(x), _p(y_view), T, H, W, C, _p(gamma), _p(a), _p(b), int(silu), int(upsample), y_strides[0], y_strides[1], y_view.stride(2), _stream()),
                "vae_prep_f16")
         return
-    _f32c(x, "vae_prep x"), _f32c(y_view, "vae_prep y")
     _check(_lib.x2v_vae_prep_f32(_p(x), _p(y_view), T, H, W, C, _p(gamma), _p(a), _p(b), int(silu), int(upsample), y_strides[0], y_strides[1], _stream()), "vae_prep")
 
 
@@ -611,7 +629,16 @@ def softmax_rows_(s, scale):
 def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0):
     """In place on q, k [L, H*128] views (unit inner stride, any token stride): per-head RMSNorm + real RoPE on the
     first l_rope tokens (x2v_headnorm_rope_bf16)."""
+    _row2d(_bf16(q, "headnorm_rope q"), "headnorm_rope q"), _row2d(_bf16(k, "headnorm_rope k"), "headnorm_rope k")
     L = q.shape[0]
+    if q.shape != k.shape or q.shape[1] != num_heads * 128:
+        raise X2VError(f"headnorm_rope: q {tuple(q.shape)} and k {tuple(k.shape)} must both be [L, {num_heads}*128]")
+    if not 0 <= l_rope <= L:
+        raise X2VError(f"headnorm_rope: l_rope={l_rope} outside [0, {L}]")
+    wq, wk = _vec(wq, "headnorm_rope wq", 128), _vec(wk, "headnorm_rope wk", 128)
+    cos, sin = _vec(cos, "headnorm_rope cos"), _vec(sin, "headnorm_rope sin")
+    if l_rope and (cos is None or sin is None or cos.numel() < l_rope * 128 or sin.numel() < l_rope * 128):
+        raise X2VError(f"headnorm_rope: cos/sin must be bf16 tables of at least [{l_rope}, 128]")
     init()
     _check(_lib.x2v_headnorm_rope_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, q_out_scale, _stream()),
            "headnorm_rope")
@@ -619,7 +646,9 @@ def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mo
 
 def vae_prep_ex(x, y_view, y_strides, mul=None, add=None, silu=False, clamp01=False, up_hw=False, up_t=False):
     """fp32 x [T,H,W,C] → y_view (fp32, or fp16 for the 16-bit convolution's operand buffer; strides in elements of y)."""
-    T, H, W, C = x.shape
+    T, H, W, C = _f32dense(x, "vae_prep_ex x", 4).shape
+    _f32dense(mul, "vae_prep_ex mul", numel=C), _f32dense(add, "vae_prep_ex add", numel=C)
+    _dev_view(y_view, "vae_prep_ex y", (torch.float32, torch.float16))
     init()
     if y_view.dtype == torch.float16:
         _check(_lib.x2v_vae_prep_ex_f16(_p(x), _p(y_view), T, H, W, C, _p(mul), _p(add), int(silu), int(clamp01), int(up_hw), int(up_t), y_strides[0], y_strides[1], _stream()),
@@ -639,7 +668,10 @@ def vae_replicate_border_(buf, lead, pad):
 
 def groupnorm_affine(x, groups, gamma, beta, eps=1e-6):
     """x [..., C] contiguous fp32 → (mul[C], add[C]) such that GroupNorm(x)[..., c] = x[..., c]*mul[c] + add[c]."""
-    c = x.shape[-1]
+    c = _f32dense(x, "groupnorm_affine x").shape[-1]
+    if groups <= 0 or c % groups:
+        raise X2VError(f"groupnorm_affine: {c} channels do not split into {groups} groups")
+    _f32dense(gamma, "groupnorm_affine gamma", numel=c), _f32dense(beta, "groupnorm_affine beta", numel=c)
     npix = x.numel() // c
     ws = torch.empty(2 * groups, dtype=torch.float64, device=x.device)
     mul, add = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
@@ -649,7 +681,12 @@ def groupnorm_affine(x, groups, gamma, beta, eps=1e-6):
 
 
 def softmax_rows_causal_(s, scale, hw, n_keys=None):
+    _dev_view(s, "softmax_rows_causal", (torch.float32,))
+    if s.dim() != 2 or s.stride(1) != 1:
+        raise X2VError(f"softmax_rows_causal: expected a 2-D fp32 tensor with unit inner stride, got {tuple(s.shape)} strides {s.stride()}")
     M, N = s.shape
+    if hw <= 0 or not 0 <= (N if n_keys is None else n_keys) <= N:
+        raise X2VError(f"softmax_rows_causal: hw={hw}, n_keys={n_keys} for {N} columns")
     init()
     _check(_lib.x2v_softmax_rows_causal_f32(_p(s), s.stride(0), M, N, float(scale), hw, N if n_keys is None else n_keys, _stream()), "softmax_rows_causal")
     return s
@@ -658,7 +695,12 @@ def softmax_rows_causal_(s, scale, hw, n_keys=None):
 def blend_axis_(a, b, axis, extent):
     """b[.., idx, ..] = a[.., na-extent+idx, ..]*(1-idx/extent) + b*(idx/extent) along `axis` of two contiguous fp32 tensors
     that agree in every other dimension."""
+    _f32dense(a, "blend_axis a"), _f32dense(b, "blend_axis b")
+    if a.dim() != b.dim():
+        raise X2VError(f"blend_axis: ranks differ: {tuple(a.shape)} vs {tuple(b.shape)}")
     axis = axis % a.dim()
+    if any(x_ != y_ for i_, (x_, y_) in enumerate(zip(a.shape, b.shape)) if i_ != axis):
+        raise X2VError(f"blend_axis: {tuple(a.shape)} and {tuple(b.shape)} must agree outside axis {axis}")
     outer = 1
     for d in a.shape[:axis]:
         outer *= d

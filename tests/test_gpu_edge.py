@@ -61,7 +61,7 @@ def test_ragged_rows_do_not_touch_neighbours(lib, M):
     assert (big[0] == 7.0).all() and (big[M + 1] == 7.0).all()
     q, k, v = bf(M, H * 128, seed=10), bf(M + 3, H * 128, seed=11), bf(M + 3, H * 128, seed=12)
     ref = lib.attention(q, k, v, H)
-    for variant in (lib.ATTN_FAST, lib.ATTN_FAST_ALT):
+    for variant in (lib.ATTN_FAST,):
         big = torch.full((M + 2, H * 128 + 128), 7.0, dtype=torch.bfloat16, device="cuda")
         out = big[1 : M + 1, : H * 128]
         lib.attention(q, k, v, H, out=out, variant=variant)
@@ -74,7 +74,7 @@ def test_strided_views_match_contiguous(lib):
     S, H = 130, 2
     qkv = bf(S, 3 * H * 128, seed=20)
     q, k, v = qkv[:, : H * 128], qkv[:, H * 128 : 2 * H * 128], qkv[:, 2 * H * 128 :]
-    for variant in (0, lib.ATTN_FAST, lib.ATTN_FAST_ALT):
+    for variant in (0, lib.ATTN_FAST):
         a = lib.attention(q, k, v, H, variant=variant)
         b = lib.attention(q.contiguous(), k.contiguous(), v.contiguous(), H, variant=variant)
         assert torch.equal(a, b), f"attention variant {variant}: strided != contiguous"

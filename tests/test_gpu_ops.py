@@ -103,7 +103,7 @@ def test_attention_fast_variants(lib, golden_ops):
     """The ping-pong kernel folds scale*log2(e) into q (one more bf16 rounding of q, relative 2^-9) — compared with the golden
     outputs at twice the default tolerance; it runs on the pre-transposed V (transposition checked exactly).  Both kernel bodies."""
     g = golden_ops
-    for variant in (lib.ATTN_FAST, lib.ATTN_FAST_ALT):
+    for variant in (lib.ATTN_FAST,):
         o = lib.attention(dev(g["attn_q"]), dev(g["attn_k"]), dev(g["attn_v"]), 2, variant=variant)
         assert_bf16_close(o, g["attn_o"], ulps=0.256, atol=8e-3, name=f"self attention variant {variant}")
         o = lib.attention(dev(g["attn_q"]), dev(g["xattn_k"]), dev(g["xattn_v"]), 2, variant=variant)
@@ -114,7 +114,7 @@ def test_attention_fast_variants(lib, golden_ops):
         qkv = torch.randn(max(Sq, Sk), 3 * H * 128, generator=gen).to(torch.bfloat16).cuda()
         q, k, v = qkv[:Sq, : H * 128], qkv[:Sk, H * 128 : 2 * H * 128], qkv[:Sk, 2 * H * 128 :]
         ref = lib.attention(q, k, v, H)
-        for var in (lib.ATTN_FAST, lib.ATTN_FAST_ALT):
+        for var in (lib.ATTN_FAST,):
             got = lib.attention(q, k, v, H, variant=var)
             assert_bf16_close(got, ref.cpu(), ulps=0.256, atol=8e-3, name=f"ping-pong ({var}) vs default Sq={Sq} Sk={Sk} H={H}")
         vt = lib.transpose_heads(v, H)

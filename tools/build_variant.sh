@@ -1,0 +1,15 @@
+#!/bin/bash
+# Builds a copy of libx2v_hip.so with extra compiler flags into tools/probes/ab/<tag>/ for A/B runs on the GPU box:
+#   tools/build_variant.sh trail8 -DX2V_G256_TRAIL=8        then      LD_LIBRARY_PATH=tools/probes/ab/trail8 tools/x2v_check pgemm ...
+set -e
+cd "$(dirname "$0")/.."
+tag=$1; shift
+out=tools/probes/ab/$tag
+mkdir -p $out/obj
+for s in x2v_api norm gemm gemm256 attn quant_fp8 conv3d vae mx sched; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I include -I lightx2v_amd/csrc "$@" -c lightx2v_amd/csrc/$s.hip -o $out/obj/$s.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libx2v_hip.so $out/obj/*.o
+rm -rf $out/obj
+ls -la $out/libx2v_hip.so

@@ -1,3 +1,7 @@
+// ARCHIVED EXPERIMENT (round 2), not part of libx2v_hip.so: self-attention with 64 query rows per wave, one wave per SIMD, accumulators and Q in
+// hand-allocated AGPRs.  Measured 0.97-1.0x the ping-pong kernel (profiles/r02_attn_w64_vs_pingpong.log, r02_pmc_attn_pingpong_vs_w64_S75600_H5.txt):
+// a single wave per SIMD cannot issue the softmax VALU work beside its own MFMAs (tools/probes/mfma_filler_probe.hip).  It was wired in as
+// selector 2 of x2v_attn_fwd_bf16_vt (attn_w64_dispatch) while it was measured; compiles with  hipcc --offload-arch=gfx950 -I include -I lightx2v_amd/csrc -c.
 // Self-attention forward, 64 query rows per wave, one wave per SIMD ("w64"; x2v_attn_fwd_bf16_vt kernel selector 2).
 //
 // Bound: MFMA.  Same operands, numerics and LDS images as the ping-pong kernel of attn.hip (V pre-transposed, q carrying

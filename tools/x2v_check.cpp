@@ -644,10 +644,8 @@ struct AttnVt {
   }
 };
 static void attn_any(int variant, AttnVt& t, const void* q, const void* k, const void* v, void* o, int64_t Sq, int64_t Sk, int H) {
-  if (variant >= 12 && variant <= 17) {  // 12: the _vt default (ping-pong); 13: its A/B alternative body; 14: 64 rows per wave (attn64.hip)
-    const int kind = variant - 12;
-    X2V_OKAY(x2v_attn_fwd_bf16_vt(q, H * 128, k, H * 128, t.vt->p, t.ldvt, o, H * 128, Sq, Sk, H, 128, 0.f, kind << 1, nullptr));
-  }
+  if (variant == 12)  // the ping-pong kernel on a pre-transposed V
+    X2V_OKAY(x2v_attn_fwd_bf16_vt(q, H * 128, k, H * 128, t.vt->p, t.ldvt, o, H * 128, Sq, Sk, H, 128, 0.f, 0, nullptr));
   else
     X2V_OKAY(x2v_attn_fwd_bf16_variant(q, H * 128, k, H * 128, v, H * 128, o, H * 128, Sq, Sk, H, 128, 0.f, variant, nullptr));
 }
@@ -668,7 +666,7 @@ static void run_attn() {
     ref_attn(q, k, v, sh.Sq, sh.Sk, sh.H, ref);
     AttnVt vt;
     vt.prepare(dv.p, sh.H * 128, sh.Sk, sh.H);
-    for (int variant : {0, 4, 5, 6, 12, 13, 14}) {
+    for (int variant : {0, 4, 5, 6, 12}) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, sh.Sq, sh.Sk, sh.H);
       HIP_OK(hipDeviceSynchronize());
@@ -695,7 +693,7 @@ static void run_attn() {
     ref_attn(q, k, v, S, S, H, ref);
     AttnVt vt;
     vt.prepare(dv.p, H * 128, S, H);
-    for (int variant : {4, 6, 12, 13, 14}) {
+    for (int variant : {4, 6, 12}) {
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, S, S, H);
       HIP_OK(hipDeviceSynchronize());
@@ -1089,13 +1087,6 @@ static void run_single(int argc, char** argv) {
     vt.prepare(v.p, H * 128, S, H);
     double ms = time_ms(iters, [&] { attn_any(variant, vt, q.p, k.p, v.p, o.p, S, S, H); });
     printf("pattn variant=%d S=%lld H=%d: %.3f ms %.1f TFLOP/s\n", variant, (long long)S, H, ms, 4.0 * S * S * H * 128 / ms / 1e9);
-    if (variant == 17) {  // cycle stamps of the w64 timing probe: [tile][start, after Q phase, after P phase]
-      std::vector<uint16_t> ho = o.host();
-      const unsigned long long* d = reinterpret_cast<const unsigned long long*>(ho.data() + (size_t)S * H * 128 / 2);
-      for (int i = 0; i < 4; ++i)
-        printf("  tile %d: wait->start %llu  Q phase %llu  P phase %llu  P end -> next vmcnt wait done %llu\n", 200 + i, d[i * 4 + 0] - d[i * 4 + 3], d[i * 4 + 1] - d[i * 4 + 0],
-               d[i * 4 + 2] - d[i * 4 + 1], i < 3 ? d[(i + 1) * 4 + 3] - d[i * 4 + 2] : 0ull);
-    }
   } else {
     const int64_t M = atoll(argv[2]);
     const int N = atoi(argv[3]), K = atoi(argv[4]);
