@@ -108,6 +108,13 @@ int x2v_rmsnorm_rope_blocked_bf16(const void* q, int64_t ldq, const void* k, int
 int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab, const void* sin_tab, int64_t L,
                            int H, int64_t l_rope, float eps, int round_mode, float q_out_scale, void* stream);
 
+/* x2v_headnorm_rope_bf16 in place on HEAD-BLOCKED q and k: heads [j*heads_per_block, (j+1)*heads_per_block) of all L tokens form the matrix
+ * [L][heads_per_block*128] (token stride ld) that starts j*block_stride elements into the buffer — the [N_ranks][S/N][(H/N) d] send buffer of
+ * the Ulysses exchange, written in that layout by x2v_gemm_bf16_blocked (replaces the reference's view + transpose + contiguous copy of
+ * q/k/v in front of all_to_all, attentions/distributed/ulysses/attn.py:36-46 / comm/all2all.py:29-33). */
+int x2v_headnorm_rope_blocked_bf16(void* q, void* k, int64_t ld, int heads_per_block, int64_t block_stride, const void* wq, const void* wk, const void* cos_tab,
+                                   const void* sin_tab, int64_t L, int H, int64_t l_rope, float eps, int round_mode, float q_out_scale, void* stream);
+
 /* x[M,D] = bf16(x + bf16(y * gate)) (gate [D] bf16, NULL = plain add) — replaces `x.add_(y * gate)`
  * (transformer_infer.py:402,468,503) for callers that do not fuse it into the GEMM epilogue. */
 int x2v_gate_residual_bf16(void* x, int64_t ldx, const void* y, int64_t ldy, const void* gate, int64_t M, int D, void* stream);

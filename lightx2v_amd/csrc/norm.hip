@@ -613,15 +613,18 @@ template <int ROUND>
 __global__ __launch_bounds__(256) void headnorm_rope_kernel(unsigned short* __restrict__ q, int64_t ldq, unsigned short* __restrict__ k, int64_t ldk,
                                                             const unsigned short* __restrict__ wq, const unsigned short* __restrict__ wk,
                                                             const unsigned short* __restrict__ cosb, const unsigned short* __restrict__ sinb, int64_t L,
-                                                            int H, int64_t l_rope, float eps, float q_out_scale) {
+                                                            int H, int64_t l_rope, float eps, float q_out_scale, int hpb, int64_t cbs) {
   const int sub = threadIdx.x & 15;
   const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= L * H) return;  // whole 16-lane groups leave together; the shuffles below stay inside a group
   const int64_t tok = row / H;
   const int head = (int)(row - tok * H);
-  unsigned short* base = blockIdx.y == 0 ? q + tok * ldq : k + tok * ldk;
+  // head-blocked operand (hpb < H): heads [j hpb, (j+1) hpb) of every token form the matrix [L][hpb*128] (token stride ld) that starts
+  // j * cbs elements into the buffer — the [N_ranks][S/N][(H/N) d] send buffer of the Ulysses exchange
+  const int hb = head / hpb;
+  unsigned short* base = (blockIdx.y == 0 ? q + tok * ldq : k + tok * ldk) + hb * cbs;
   const unsigned short* w = blockIdx.y == 0 ? wq : wk;
-  unsigned short* p = base + head * 128 + sub * 8;
+  unsigned short* p = base + (head - hb * hpb) * 128 + sub * 8;
   const float oscale = (blockIdx.y == 0 && ROUND != X2V_ROUND_REF) ? q_out_scale : 1.f;
   float v[8], wv[8];
   unpack8(*reinterpret_cast<const uint4*>(p), v);
@@ -916,14 +919,15 @@ extern "C" __attribute__((visibility("default"))) int x2v_sinusoid_embed_bf16(co
   return X2V_OK;
 }
 
-extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab,
-                                                                             const void* sin_tab, int64_t L, int H, int64_t l_rope, float eps, int round_mode,
-                                                                             float q_out_scale, void* stream) {
+static int headnorm_rope_impl(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab, const void* sin_tab, int64_t L, int H,
+                              int64_t l_rope, float eps, int round_mode, float q_out_scale, int hpb, int64_t cbs, void* stream) {
   X2V_REQUIRE(q_out_scale > 0.f, X2V_E_ARG, "headnorm_rope: q_out_scale must be positive");
   X2V_REQUIRE(q && k, X2V_E_ARG, "headnorm_rope: null pointer");
   X2V_REQUIRE(L > 0 && H > 0 && l_rope >= 0 && l_rope <= L, X2V_E_SHAPE, "headnorm_rope: bad shape L=%lld H=%d l_rope=%lld", (long long)L, H, (long long)l_rope);
   X2V_REQUIRE(l_rope == 0 || (cos_tab && sin_tab), X2V_E_ARG, "headnorm_rope: rope tables missing");
-  X2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldq >= (int64_t)H * 128 && ldk >= (int64_t)H * 128 && aligned16(q) && aligned16(k) && aligned16(wq) && aligned16(wk) &&
+  X2V_REQUIRE(hpb > 0 && H % hpb == 0 && cbs >= 0 && cbs % 8 == 0, X2V_E_SHAPE, "headnorm_rope: bad head blocking (H=%d, heads per block %d, block stride %lld)", H, hpb,
+              (long long)cbs);
+  X2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldq >= (int64_t)hpb * 128 && ldk >= (int64_t)hpb * 128 && aligned16(q) && aligned16(k) && aligned16(wq) && aligned16(wk) &&
                   aligned16(cos_tab) && aligned16(sin_tab),
               X2V_E_ALIGN, "headnorm_rope: rows must be 16-byte aligned");
   const int64_t rows = L * H;
@@ -931,10 +935,24 @@ extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_bf16(voi
   dim3 grid((unsigned)((rows + 15) / 16), 2);
   if (round_mode == X2V_ROUND_REF)
     hipLaunchKernelGGL((headnorm_rope_kernel<X2V_ROUND_REF>), grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)q, ldq, (unsigned short*)k, ldk,
-                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps, q_out_scale);
+                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps, q_out_scale, hpb,
+                       cbs);
   else
     hipLaunchKernelGGL((headnorm_rope_kernel<X2V_ROUND_FP32>), grid, dim3(256), 0, (hipStream_t)stream, (unsigned short*)q, ldq, (unsigned short*)k, ldk,
-                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps, q_out_scale);
+                       (const unsigned short*)wq, (const unsigned short*)wk, (const unsigned short*)cos_tab, (const unsigned short*)sin_tab, L, H, l_rope, eps, q_out_scale, hpb,
+                       cbs);
   X2V_LAUNCH_CHECK("headnorm_rope launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_bf16(void* q, int64_t ldq, void* k, int64_t ldk, const void* wq, const void* wk, const void* cos_tab,
+                                                                             const void* sin_tab, int64_t L, int H, int64_t l_rope, float eps, int round_mode,
+                                                                             float q_out_scale, void* stream) {
+  return headnorm_rope_impl(q, ldq, k, ldk, wq, wk, cos_tab, sin_tab, L, H, l_rope, eps, round_mode, q_out_scale, H, 0, stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_headnorm_rope_blocked_bf16(void* q, void* k, int64_t ld, int heads_per_block, int64_t block_stride, const void* wq,
+                                                                                     const void* wk, const void* cos_tab, const void* sin_tab, int64_t L, int H, int64_t l_rope,
+                                                                                     float eps, int round_mode, float q_out_scale, void* stream) {
+  return headnorm_rope_impl(q, ld, k, ld, wq, wk, cos_tab, sin_tab, L, H, l_rope, eps, round_mode, q_out_scale, heads_per_block, block_stride, stream);
 }

@@ -202,6 +202,19 @@ class HunyuanTransformerInfer:
         e = lambda *s: torch.empty(s, dtype=BF16, device=dev)  # noqa: E731
         return dict(mod=e(L, D), qkv=e(L, 3 * D), cat=e(L, D + F), hid=e(L, F))
 
+    def _blocked(self, *ops):
+        """The copy-free Ulysses path (ulysses.UlyssesHunyuanAttention.attend_blocked): the exchange buffers are GEMM / norm operands.
+        Needs operators that take block-strided operands (the bf16 class) and head blocks that are whole K tiles."""
+        pa = self.parallel_attention
+        return (pa is not None and hasattr(pa, "attend_blocked") and self._qs != 1.0 and pa.blocked_ok(self.hidden_size, self.mlp_hidden_dim)
+                and all(getattr(o, "accepts_blocked", False) for o in ops))
+
+    def _attend_blocked(self, bufs, qkv_txt):
+        D = self.hidden_size
+        n_img, n_valid, n_txt = self._sp_lens
+        txt = (qkv_txt[:, :D], qkv_txt[:, D : 2 * D], qkv_txt[:, 2 * D :])
+        return self.parallel_attention.attend_blocked(bufs, txt, (n_valid, n_txt), self.heads_num, variant=lib.ATTN_FAST | lib.ATTN_Q_PRESCALED)
+
     def _attention(self, q, k, v, out):
         variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if self._qs != 1.0 else 0
         if self.parallel_attention is not None:  # Ulysses (reference hook: transformer_infer.py:130-144,358-369)
@@ -220,10 +233,26 @@ class HunyuanTransformerInfer:
         # LN + modulate → fused QKV, image and text rows of the same buffers
         lib.layernorm(img, scale=i_sc1, shift=i_sh1, eps=1e-6, out=mod[:n_img])
         lib.layernorm(txt, scale=t_sc1, shift=t_sh1, eps=1e-6, out=mod[n_img:])
+        cos, sin = freqs_cis
+        if self._blocked(weights.img_attn_qkv, weights.img_attn_proj, weights.txt_attn_proj):
+            # Ulysses, copy-free: the image QKV GEMM writes the head-blocked send buffers, norm + RoPE run in place on them, the output
+            # projections read the received [N, rows, hd/N] buffers as K-blocked x (attentions/distributed/ulysses/attn.py:36-46,75-91 without
+            # its transposing copies)
+            bufs = self.parallel_attention.buffers(n_img, x.shape[0] - n_img, D, self.mlp_hidden_dim, BF16, x.device)
+            snd = bufs["snd"]
+            weights.img_attn_qkv.apply(mod[:n_img], out=snd.view(-1, n_img, snd.shape[3]))
+            weights.txt_attn_qkv.apply(mod[n_img:], out=qkv[n_img:])
+            lib.headnorm_rope_blocked_(snd[0], snd[1], weights.img_attn_q_norm.weight, weights.img_attn_k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
+            lib.headnorm_rope_(qkv[n_img:, :D], qkv[n_img:, D : 2 * D], weights.txt_attn_q_norm.weight, weights.txt_attn_k_norm.weight, None, None, H, 0, 1e-6, self.round_mode,
+                               self._qs)
+            a_img, a_txt = self._attend_blocked(bufs, qkv[n_img:])
+            nb = snd.shape[1]
+            weights.img_attn_proj.apply(a_img[:nb], epilogue=lib.EPI_RESIDUAL, resid=img, gate=i_g1)
+            weights.txt_attn_proj.apply(a_txt[:nb], epilogue=lib.EPI_RESIDUAL, resid=txt, gate=t_g1)
+            return self._double_block_mlp(weights, img, txt, n_img, mod, ws, i_sh2, i_sc2, i_g2, t_sh2, t_sc2, t_g2, x)
         weights.img_attn_qkv.apply(mod[:n_img], out=qkv[:n_img])
         weights.txt_attn_qkv.apply(mod[n_img:], out=qkv[n_img:])
         q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
-        cos, sin = freqs_cis
         lib.headnorm_rope_(q[:n_img], k[:n_img], weights.img_attn_q_norm.weight, weights.img_attn_k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
         lib.headnorm_rope_(q[n_img:], k[n_img:], weights.txt_attn_q_norm.weight, weights.txt_attn_k_norm.weight, None, None, H, 0, 1e-6, self.round_mode, self._qs)
         attn = ws["cat"][:, :D]
@@ -231,6 +260,9 @@ class HunyuanTransformerInfer:
         # x += proj(attn) * gate1 ; x += fc2(gelu(fc1(LN(x)*(1+scale2)+shift2))) * gate2   — per stream
         weights.img_attn_proj.apply(attn[:n_img], epilogue=lib.EPI_RESIDUAL, resid=img, gate=i_g1)
         weights.txt_attn_proj.apply(attn[n_img:], epilogue=lib.EPI_RESIDUAL, resid=txt, gate=t_g1)
+        return self._double_block_mlp(weights, img, txt, n_img, mod, ws, i_sh2, i_sc2, i_g2, t_sh2, t_sc2, t_g2, x)
+
+    def _double_block_mlp(self, weights, img, txt, n_img, mod, ws, i_sh2, i_sc2, i_g2, t_sh2, t_sc2, t_g2, x):
         lib.layernorm(img, scale=i_sc2, shift=i_sh2, eps=1e-6, out=mod[:n_img])
         lib.layernorm(txt, scale=t_sc2, shift=t_sh2, eps=1e-6, out=mod[n_img:])
         hid = ws["hid"]
@@ -250,11 +282,28 @@ class HunyuanTransformerInfer:
         # linear1 = [qkv | mlp] rows of one checkpoint tensor, two epilogues: through the operator (bf16 / fp8 / mxfp8 alike), the
         # activation quantised once when the operator is a quantised one
         l1 = weights.linear1
+        cos, sin = freqs_cis
+        if self._blocked(l1, weights.linear2):
+            # Ulysses, copy-free: linear2's input cat(attn, mlp) (transformer_infer.py:377) exists only as the K-blocked buffers a_img / a_txt —
+            # blocks [0, N) are the receive buffers of the head->seq exchange / the text gather, the rest is written N-blocked by the GELU GEMM
+            bufs = self.parallel_attention.buffers(n_img, txt_seq_len, D, self.mlp_hidden_dim, BF16, x.device)
+            snd, a_img, a_txt = bufs["snd"], bufs["a_img"], bufs["a_txt"]
+            nb = snd.shape[1]
+            qkv_rows, mlp_rows = slice(0, 3 * D), slice(3 * D, None)
+            l1.apply(mod[:n_img], out=snd.view(-1, n_img, snd.shape[3]), row_slice=qkv_rows)
+            l1.apply(mod[n_img:], out=qkv[n_img:], row_slice=qkv_rows)
+            l1.apply(mod[:n_img], epilogue=lib.EPI_GELU_TANH, out=a_img[nb:], row_slice=mlp_rows)
+            l1.apply(mod[n_img:], epilogue=lib.EPI_GELU_TANH, out=a_txt[nb:], row_slice=mlp_rows)
+            lib.headnorm_rope_blocked_(snd[0], snd[1], weights.q_norm.weight, weights.k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
+            lib.headnorm_rope_(qkv[n_img:, :D], qkv[n_img:, D : 2 * D], weights.q_norm.weight, weights.k_norm.weight, None, None, H, 0, 1e-6, self.round_mode, self._qs)
+            self._attend_blocked(bufs, qkv[n_img:])
+            weights.linear2.apply(a_img, epilogue=lib.EPI_RESIDUAL, resid=x[:n_img], gate=gate)
+            weights.linear2.apply(a_txt, epilogue=lib.EPI_RESIDUAL, resid=x[n_img:], gate=gate)
+            return x
         pre = {"quantized": l1.quantize_input(mod)} if hasattr(l1, "quantize_input") else {}
         l1.apply(mod, out=qkv, row_slice=slice(0, 3 * D), **pre)                                          # qkv rows of linear1
         l1.apply(mod, epilogue=lib.EPI_GELU_TANH, out=cat[:, D:], row_slice=slice(3 * D, None), **pre)    # mlp rows, GELU, into linear2's input
         q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
-        cos, sin = freqs_cis
         lib.headnorm_rope_(q, k, weights.q_norm.weight, weights.k_norm.weight, cos, sin, H, n_img, 1e-6, self.round_mode, self._qs)
         self._attention(q, k, v, cat[:, :D])
         weights.linear2.apply(cat, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate)

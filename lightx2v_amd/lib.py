@@ -32,6 +32,7 @@ PROTOTYPES = {
     "x2v_rmsnorm_rope_scaled_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _i32, _c_void_p],
     "x2v_rmsnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_rmsnorm_rope_scaled_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _c_void_p],
+    "x2v_headnorm_rope_blocked_bf16": [_c_void_p, _c_void_p, _i64, _i32, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _f32, _c_void_p],
     "x2v_headnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _f32, _c_void_p],
     "x2v_gate_residual_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_activation_bf16": [_c_void_p, _c_void_p, _i64, _i32, _c_void_p],
@@ -642,6 +643,25 @@ def headnorm_rope_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mo
     init()
     _check(_lib.x2v_headnorm_rope_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, q_out_scale, _stream()),
            "headnorm_rope")
+
+
+def headnorm_rope_blocked_(q, k, wq, wk, cos, sin, num_heads, l_rope, eps=1e-6, round_mode=ROUND_FP32, q_out_scale=1.0):
+    """headnorm_rope_ in place on head-blocked q, k [N, L, (H/N)*128] (contiguous: the send buffers of the Ulysses exchange)."""
+    for t, nm in ((q, "q"), (k, "k")):
+        if t.dim() != 3 or t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous():
+            raise X2VError(f"headnorm_rope_blocked {nm}: expected a contiguous bf16 device tensor [N, L, (H/N)*128], got {t.dtype} {tuple(t.shape)}")
+    nb, L, bc = q.shape
+    if q.shape != k.shape or bc % 128 or nb * bc != num_heads * 128:
+        raise X2VError(f"headnorm_rope_blocked: q {tuple(q.shape)} / k {tuple(k.shape)} do not hold {num_heads} heads of 128 in equal blocks")
+    if not 0 <= l_rope <= L:
+        raise X2VError(f"headnorm_rope_blocked: l_rope={l_rope} outside [0, {L}]")
+    wq, wk = _vec(wq, "headnorm_rope wq", 128), _vec(wk, "headnorm_rope wk", 128)
+    cos, sin = _vec(cos, "headnorm_rope cos"), _vec(sin, "headnorm_rope sin")
+    if l_rope and (cos is None or sin is None or cos.numel() < l_rope * 128 or sin.numel() < l_rope * 128):
+        raise X2VError(f"headnorm_rope_blocked: cos/sin must be bf16 tables of at least [{l_rope}, 128]")
+    init()
+    _check(_lib.x2v_headnorm_rope_blocked_bf16(_p(q), _p(k), bc, bc // 128, L * bc, _p(wq), _p(wk), _p(cos), _p(sin), L, num_heads, l_rope, eps, round_mode, q_out_scale, _stream()),
+           "headnorm_rope_blocked")
 
 
 def vae_prep_ex(x, y_view, y_strides, mul=None, add=None, silu=False, clamp01=False, up_hw=False, up_t=False):

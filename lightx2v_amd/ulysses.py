@@ -270,15 +270,119 @@ class UlyssesHunyuanAttention:
     (the reference calls torch.cuda.synchronize() twice per attention, attn.py:48,85); receive buffers are row ranges of
     the joint attention operands, so there is no torch.cat."""
 
-    def __init__(self, group=None, attn_fn=None):
+    def __init__(self, group=None, attn_fn=None, overlap=True):
         self.group = group
         self.attn_fn = attn_fn
+        self.overlap = overlap and torch.cuda.is_available()
+        self.comm_stream = None
+        self._buffers = {}
+        self.copies = 0  # image-row layout copies made by the row-major entry (the blocked entry makes none): asserted by the tests
 
+    # ---- the fused driver's path: exchange buffers are kernel operands ---------------------------------------------------
+    def buffers(self, n_img, n_txt, hd, mlp, dtype, device):
+        """Exchange buffers of one joint attention, allocated once per shape and reused by every block (stream order makes that safe):
+          snd   [3, N, n_img, hd/N]      image q | k | v, head-blocked: written by the fused-QKV GEMM (N-blocked output, column block c of
+                                         the 3*hd outputs = snd.view(3N, ...)[c]) and normalised / rotated in place
+          joint [3, N*n_img + n_txt, hd/N] the attention operands: rows [0, N*n_img) receive the image exchange, the rest this rank's heads
+                                         of the (replicated) text
+          o     [N*n_img + n_txt, hd/N]   attention output; its image rows are the head->seq send buffer
+          a_img [N + mlp/(hd/N), n_img, hd/N], a_txt [... , n_txt, ...]   K-blocked input of the projection that follows: blocks [0, N)
+                                         receive head->seq (image) / the all-gather over heads (text); the further blocks hold the MLP branch
+                                         of a single block (written N-blocked by linear1's GELU GEMM), so that linear2 reads
+                                         cat(attn, mlp) (transformer_infer.py:377) without anybody assembling it."""
+        n, _ = _world(self.group)
+        key = (n_img, n_txt, hd, mlp, dtype, str(device))
+        b = self._buffers.get(key)
+        if b is None:
+            hdn = hd // n
+            e = lambda *sh: torch.empty(sh, dtype=dtype, device=device)  # noqa: E731
+            b = self._buffers[key] = dict(snd=e(3, n, n_img, hdn), joint=e(3, n * n_img + n_txt, hdn), o=e(n * n_img + n_txt, hdn),
+                                          a_img=e(n + mlp // hdn, n_img, hdn), a_txt=e(n + mlp // hdn, n_txt, hdn))
+        return b
+
+    def blocked_ok(self, hd, mlp):
+        """K-blocked GEMM operands advance in whole 64-element K tiles."""
+        n, _ = _world(self.group)
+        return hd % n == 0 and (hd // n) % 128 == 0 and mlp % (hd // n) == 0
+
+    def attend_blocked(self, bufs, txt_qkv, segs_txt, num_heads, variant=0):
+        """Image q/k/v are in bufs["snd"] (head-blocked), text q/k/v in the row-major views `txt_qkv` [n_txt, H*128] each.
+        Returns (a_img, a_txt) whose first N blocks hold the attention output of this rank's image rows / of the text rows, all heads."""
+        n, r = _world(self.group)
+        if num_heads % n != 0:
+            raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
+        snd, joint, o, a_img, a_txt = (bufs[x] for x in ("snd", "joint", "o", "a_img", "a_txt"))
+        n_img, hdn = snd.shape[2], snd.shape[3]
+        n_txt, tot = a_txt.shape[1], n * snd.shape[2]
+        n_valid = segs_txt[0]
+        hl = num_heads // n
+        use_streams = self.overlap and snd.is_cuda
+        cur = cs = None
+        if use_streams:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            cur, cs = torch.cuda.current_stream(), self.comm_stream
+
+        def on_comm(fn):
+            if use_streams:
+                cs.wait_stream(cur)
+                with torch.cuda.stream(cs):
+                    fn()
+            else:
+                fn()
+
+        def seq2head():
+            for i in range(3):
+                dist.all_to_all_single(joint[i][:tot].view(n, n_img, hdn), snd[i], group=self.group)
+
+        on_comm(seq2head)
+        for i in range(3):  # this rank's heads of the text tokens (n_txt x hd/N: a few hundred rows), beside the exchange
+            joint[i][tot:].copy_(txt_qkv[i][:, r * hdn : (r + 1) * hdn])
+        if use_streams:
+            cur.wait_stream(cs)
+        jq, jk, jv = joint[0], joint[1], joint[2]
+        nq = tot + n_valid
+        fast = self.attn_fn is None and (variant & 0xFF) == lib.ATTN_FAST
+        vt = lib.transpose_heads(jv[:nq], hl) if fast else None
+
+        def attend(rows):
+            if fast:
+                lib.attention(jq[rows], jk[:nq], jv[:nq], hl, 128, out=o[rows], variant=variant, vt=vt)
+            elif self.attn_fn is not None:
+                self.attn_fn(jq[rows], jk[:nq], jv[:nq], hl, o[rows])
+            else:
+                lib.attention(jq[rows], jk[:nq], jv[:nq], hl, 128, out=o[rows], variant=variant)
+
+        # head->seq of the image rows in two halves by destination rank: the first half's exchange runs under the second half's attention
+        halves = [(0, n)] if n < 2 else [(0, n // 2), (n // 2, n)]
+        for hi, (j0, j1) in enumerate(halves):
+            last = hi == len(halves) - 1
+            attend(slice(j0 * n_img, nq if last else j1 * n_img))  # the valid text queries ride with the last half
+            if last and n_valid < n_txt:  # the padded text tokens attend among themselves (second cu_seqlens segment)
+                pad = slice(nq, tot + n_txt)
+                if self.attn_fn is not None:
+                    self.attn_fn(jq[pad], jk[pad], jv[pad], hl, o[pad])
+                else:
+                    lib.attention(jq[pad], jk[pad], jv[pad], hl, 128, out=o[pad], variant=variant)
+            in_split = [n_img if j0 <= j < j1 else 0 for j in range(n)]
+            mine = j0 <= r < j1
+            out_split = [n_img if mine else 0] * n
+            recv = a_img[:n].view(tot, hdn) if mine else a_img[:n].view(tot, hdn)[:0]
+            send = o[j0 * n_img : j1 * n_img]
+            on_comm(lambda recv=recv, send=send, out_split=out_split, in_split=in_split: dist.all_to_all_single(recv, send, out_split, in_split, group=self.group))
+        # text rows: every rank holds all text tokens for its heads -> gather the head blocks (block j = rank j's heads)
+        on_comm(lambda: dist.all_gather_into_tensor(a_txt[:n].view(n * n_txt, hdn), o[tot:], group=self.group))
+        if use_streams:
+            cur.wait_stream(cs)
+        return a_img, a_txt
+
+    # ---- row-major entry (the reference's functional form) -----------------------------------------------------------------
     def __call__(self, q, k, v, n_img, segs_txt, num_heads, out, variant=0):
         """q, k, v: [n_img_local + n_txt, H*128] views; out: same rows, H*128 columns.  segs_txt = (n_valid_txt, n_txt)."""
         n, r = _world(self.group)
         if num_heads % n != 0:
             raise lib.X2VError(f"Ulysses needs num_heads % world_size == 0 (H={num_heads}, N={n})")
+        self.copies += 4  # three transposing sends + the gather of the received output
         hd = q.shape[1]
         hdn = hd // n
         n_txt = q.shape[0] - n_img

@@ -2,8 +2,9 @@
 
 reference: lightx2v/models/video_encoders/hf/wan/vae.py — WanVAE.decode :931-957 → WanVAE_.decode :713-738 →
 Decoder3d.forward :436-489 → ResidualBlock :185-223 / AttentionBlock :226-262 / Resample :70-159 / CausalConv3d :19-44.
-Same class and method names, same state-dict tensor names (`decoder.*`, `conv2.*`), same chunking (one latent frame
-at a time through a decoder that carries a 2-frame cache per causal conv), fp32 like the reference (vae.py:794).
+Same class and method names, same state-dict tensor names (`decoder.*`, `conv2.*`), same cache-carrying decoder (a 2-frame
+cache per causal conv; the reference feeds it one latent frame at a time, here `chunk_frames` at a time with bit-identical
+output), fp32 like the reference (vae.py:794).
 
 What is laid out differently for the MI355X (288 GB HBM, fp32-input MFMA):
   * activations are channels-last [T, H, W, C] so both implicit-GEMM operands are K-contiguous;
@@ -188,8 +189,14 @@ class Decoder3d:
 class WanVAE_:
     """reference: vae.py:640-760 (decode side)."""
 
-    def __init__(self, sd, dim=96, z_dim=16, device="cuda", conv16=False):
+    def __init__(self, sd, dim=96, z_dim=16, device="cuda", conv16=False, chunk_frames=4):
+        """chunk_frames: latent frames per pass through the decoder after the first one.  The reference pushes ONE latent frame at a time
+        through its cache-carrying decoder (vae.py:722-736) to bound memory; every kernel here reduces each output pixel in an order that
+        does not depend on how many frames share the launch, and the 2-frame caches are the leading frames of the conv input buffers, so
+        any chunking gives bit-identical output — larger chunks only fill the GPU better in the low-resolution stages
+        (90x160 latents: 57 workgroups per frame and 32 output channels) and launch 4x fewer kernels."""
         self.dim, self.z_dim, self.device, self.conv16 = dim, z_dim, device, conv16
+        self.chunk_frames = max(1, int(chunk_frames))
         self.sd = sd
         self.conv2_w = sd["conv2.weight"].to(device=device, dtype=torch.float32).reshape(z_dim, z_dim).contiguous()
         self.conv2_b = sd["conv2.bias"].to(device=device, dtype=torch.float32).contiguous()
@@ -206,7 +213,9 @@ class WanVAE_:
         lib.vae_prep(zl, zn, (h * w * zc, w * zc), a=scale[1].float().contiguous(), b=scale[0].float().contiguous())
         x = torch.empty_like(zn)
         lib.vae_conv(zn, (h * w * zc, w * zc, zc), self.conv2_w, x, t, h, w, bias=self.conv2_b)
-        outs = [self.decoder.forward(x[i : i + 1]) for i in range(t)]
+        # the first latent frame goes alone: it is the one chunk without temporal upsampling (Resample "Rep", vae.py:113-115)
+        bounds = [0, 1] + list(range(1 + self.chunk_frames, t, self.chunk_frames)) + ([t] if t > 1 else [])
+        outs = [self.decoder.forward(x[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
         self.decoder.clear_cache()
         video = torch.cat(outs, dim=0)  # [T_out, H, W, 3]
         return video.permute(3, 0, 1, 2).unsqueeze(0).contiguous()
@@ -215,14 +224,14 @@ class WanVAE_:
 class WanVAE:
     """reference: vae.py:789-957 (decode side; `use_tiling` is not built)."""
 
-    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False, conv16=False):
+    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False, conv16=False, chunk_frames=4):
         """conv16: opt-in fast decode — fp16 operands for the 3x3(x3) convolutions on the 16-bit MFMA (fp32 accumulation, residual
         stream, norms and attention).  Off by default: the reference decodes in fp32 (vae.py:794) and so does this class."""
         self.device, self.parallel = device, parallel
         self.mean = torch.tensor(synth.WAN_VAE_MEAN, dtype=torch.float32, device=device)
         self.inv_std = 1.0 / torch.tensor(synth.WAN_VAE_STD, dtype=torch.float32, device=device)
         self.scale = [self.mean, self.inv_std]
-        self.model = WanVAE_(sd, dim=dim, z_dim=z_dim, device=device, conv16=conv16)
+        self.model = WanVAE_(sd, dim=dim, z_dim=z_dim, device=device, conv16=conv16, chunk_frames=chunk_frames)
 
     def decode_dist(self, zs, world_size, cur_rank, split_dim):
         """reference: vae.py:883-929 — each rank decodes its slab of the latent (split along H = dim 2 or W = dim 3) plus a

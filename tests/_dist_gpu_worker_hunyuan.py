@@ -38,6 +38,9 @@ def main():
         sch.step_pre(1)
         model.infer(inputs)
         outs[mode] = sch.noise_pred.float().cpu()
+        if mode == "ulysses":
+            pa = model.transformer_infer.parallel_attention
+            assert pa.copies == 0 and pa._buffers, "the fused driver must take the copy-free blocked exchange path (double and single blocks)"
         assert sch.latents.shape == lat.shape
     a, b = outs["single"], outs["ulysses"]
     assert a.shape == b.shape

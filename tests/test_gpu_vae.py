@@ -103,6 +103,32 @@ def test_vae_decode_matches_reference_fixture():
     assert torch.equal(out, out2)
 
 
+def test_vae_decode_frame_batched_is_bit_identical():
+    """chunk_frames latent frames per decoder pass (default 4) against the reference's one-frame-at-a-time chunking (vae.py:722-736):
+    every kernel reduces an output pixel in an order independent of the number of frames in the launch and the conv caches are the
+    leading frames of the input buffers, so the decoded video must be EQUAL bit for bit — fp32 and the opt-in fp16-operand form, with
+    chunk sizes that do / do not divide T - 1 (T = 6: chunks 1+5, 1+2+2+1, 1+3+2, 1+4+1)."""
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import synth, vae
+
+    gld = load_file(os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
+    dim, seed = int(gld["dim"]), int(gld["seed"])
+    sd = synth.synth_wan_vae_weights(dim=dim, seed=seed)
+    z = torch.randn(16, 6, 8, 8, generator=torch.Generator().manual_seed(5)).cuda()
+    for conv16 in (False, True):
+        ref = vae.WanVAE(sd, dim=dim, conv16=conv16, chunk_frames=1).decode(z)
+        assert ref.shape == (1, 3, 21, 64, 64) and torch.isfinite(ref).all()
+        for g in (2, 3, 4, 5, 8):
+            m = vae.WanVAE(sd, dim=dim, conv16=conv16, chunk_frames=g)
+            out = m.decode(z)
+            assert torch.equal(out, ref), f"chunk_frames={g} conv16={conv16}: max |d| = {(out - ref).abs().max().item():.3e}"
+            assert torch.equal(m.decode(z), ref)  # second decode on the grown buffers
+    # the committed fixture through the default chunking
+    out = vae.WanVAE(sd, dim=dim).decode(gld["z"].cuda())
+    _check(out[0], gld["decoded"], "WanVAE.decode (chunk_frames=4) vs reference fixture")
+
+
 def test_vae_decode_fp16_operands_opt_in():
     """Opt-in fast decode (WanVAE(conv16=True)): fp16 operands for the 3x3(x3) convolutions, everything else fp32 — against the fp32
     fixture generated from the reference.  Stated tolerance on outputs in [-1, 1]: |d| <= 2e-2, relative L2 <= 1e-2.  The tiny model's
