@@ -131,7 +131,8 @@ int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
 
 /* Same, selecting the kernel (tuning / validation hook).  variant & 0xff: 0 = by shape (what x2v_gemm_bf16 does:
  * the 256x256-tile ping-pong kernel of gemm256.hip when the grid fills the chip, else the 128x128 kernel of
- * gemm.hip), 1 = 128x128 kernel, 2 = 256x256 kernel; variant >> 8 = m-tiles per scheduling group of the
+ * gemm.hip), 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (two waves per SIMD; fp8's and mxfp8's large-shape kernel), 3 = 256x256
+ * single-stream kernel (one software-pipelined wave per SIMD; bf16 only, its large-shape kernel); variant >> 8 = m-tiles per scheduling group of the
  * 256x256 kernel (0 = default). */
 int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                           int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream);
@@ -149,7 +150,7 @@ int x2v_gemm_bf16_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kb
                           int y_nblock, int64_t y_nblock_stride, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
 
 /* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape: 1 = the
- * 128x128 kernel, 2 = the 256x256 ping-pong kernel (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it
+ * 128x128 kernel, 2 = the 256x256 ping-pong kernel (fp8), 3 = the 256x256 single-stream kernel (bf16) (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it
  * compared with the oracle is the one the dispatcher takes for a model's shapes. */
 int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8);
 

@@ -257,6 +257,9 @@ namespace x2v {
 template <bool FP8>
 int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
                      const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st, GemmBlocking gb);
+// gemm256s.hip: the same tile as one software-pipelined wave per SIMD (bf16)
+int gemm256s_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
+                      const void* resid, int64_t ldr, const void* gate, int gm_tiles, hipStream_t st, GemmBlocking gb);
 }  // namespace x2v
 
 using namespace x2v;
@@ -278,13 +281,17 @@ static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t 
 
 // The shape rule of variant 0 (one place: the dispatcher and x2v_gemm_kernel_choice both ask it): the 256^2 kernel wants at least
 // ~one full round of tiles (256 CUs), a K loop longer than its pipeline, and 32-bit buffer offsets over a 256-row tile.
-static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb) {
+// bf16 takes the single-stream form of the 256^2 tile (3), fp8 / mxfp8 the ping-pong form (2).
+#ifndef X2V_GEMM256_BF16_KERNEL
+#define X2V_GEMM256_BF16_KERNEL 3
+#endif
+static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb, bool fp8) {
   const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
   const int64_t tiles256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
-  return (fits256 && tiles256 >= 192 && nk >= 8) ? 2 : 1;
+  return (fits256 && tiles256 >= 192 && nk >= 8) ? (fp8 ? 2 : X2V_GEMM256_BF16_KERNEL) : 1;
 }
 
-// variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel; bits 8..15 = m-tiles per scheduling
+// variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel, 3 = 256x256 single-stream kernel (bf16); bits 8..15 = m-tiles per scheduling
 // group of the 256x256 kernel (0 = default)
 template <bool FP8>
 static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N,
@@ -293,11 +300,19 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
   const int kind = variant & 0xff;
   const int gm_tiles = (variant >> 8) & 0xff;
   const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
-  if (kind == 2 && !fits256) {
-    set_error("gemm: leading dimension too large for the 256x256 kernel");
+  if ((kind == 2 || kind == 3) && !fits256) {
+    set_error("gemm: leading dimension too large for the 256x256 kernels");
     return X2V_E_SHAPE;
   }
-  if (kind == 2 || (kind == 0 && choose_kernel(M, N, nk, ldxb, ldwb) == 2)) {
+  if (kind == 3 && FP8) {
+    set_error("gemm: the single-stream 256x256 kernel is bf16 only");
+    return X2V_E_ARG;
+  }
+  const int chosen = kind == 0 ? choose_kernel(M, N, nk, ldxb, ldwb, FP8) : kind;
+  if constexpr (!FP8) {
+    if (chosen == 3) return gemm256s_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
+  }
+  if (chosen == 2) {
     return gemm256_dispatch<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st, gb);
   }
   switch (epilogue) {
@@ -410,5 +425,5 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* x
 
 extern "C" __attribute__((visibility("default"))) int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8) {
   if (M <= 0 || N <= 0 || K <= 0) return X2V_E_SHAPE;
-  return fp8 ? choose_kernel(M, N, K / 128, ldx, ldw) : choose_kernel(M, N, K / GB_K, ldx * 2, ldw * 2);
+  return fp8 ? choose_kernel(M, N, K / 128, ldx, ldw, true) : choose_kernel(M, N, K / GB_K, ldx * 2, ldw * 2, false);
 }

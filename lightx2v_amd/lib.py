@@ -13,7 +13,7 @@ import math
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libx2v_hip.so")
+LIB_PATH = os.environ.get("X2V_LIB_PATH") or os.path.join(_HERE, "libx2v_hip.so")  # X2V_LIB_PATH: an alternative build of the same sources (tools/build_variant.sh, A/B runs)
 
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_SILU = 0, 1, 2, 3
 ROUND_FP32, ROUND_REF = 0, 1
@@ -343,7 +343,8 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
 
 
 def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False):
-    """1 = 128x128 kernel, 2 = 256x256 ping-pong kernel: what variant 0 launches for this shape (x2v_gemm_kernel_choice)."""
+    """1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (fp8), 3 = 256x256 single-stream kernel (bf16): what variant 0 launches for
+    this shape (x2v_gemm_kernel_choice)."""
     rc = _lib.x2v_gemm_kernel_choice(M, N, K, K if ldx is None else ldx, K if ldw is None else ldw, int(fp8))
     if rc < 0:
         raise X2VError(f"gemm_kernel_choice: bad shape M={M} N={N} K={K}")

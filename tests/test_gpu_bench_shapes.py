@@ -2,8 +2,8 @@
 
 The op-level tests in test_gpu_ops.py use small shapes, which the GEMM dispatcher sends to the 128x128 kernel and where attention
 runs a handful of key tiles.  Here the shapes are chosen so that
-  * `lib.gemm` / `lib.gemm_fp8` take the 256x256 ping-pong kernel BY THEIR OWN DISPATCH (asserted through x2v_gemm_kernel_choice, and by
-    bit-equality with the forced variant 2) — the Wan-14B projections 5120→5120, 5120→13824, 13824→5120, ragged M included,
+  * `lib.gemm` / `lib.gemm_fp8` take the 256x256 kernels (bf16: single-stream, fp8: ping-pong) BY THEIR OWN DISPATCH (asserted through
+    x2v_gemm_kernel_choice, and by bit-equality with the forced variant) — the Wan-14B projections 5120→5120, 5120→13824, 13824→5120, ragged M included,
     all four epilogues;
   * the ping-pong attention kernel on pre-transposed V with a pre-scaled q (what the fused block drivers launch) sees >= 8192 keys
     through strided fused-QKV views, against torch SDPA and exact fp32 attention;
@@ -47,7 +47,7 @@ WAN14B_GEMMS = [(4096, 5120, 5120), (4096, 5120, 13824), (4100, 13824, 5120), (4
 def test_gemm256_bf16_natural_dispatch_vs_oracle(lib, M, K, N):
     from oracle import wan_oracle as O
 
-    assert lib.gemm_kernel_choice(M, N, K) == 2, "shape must take the 256x256 kernel by the dispatcher's own rule"
+    assert lib.gemm_kernel_choice(M, N, K) == 3, "shape must take the 256x256 single-stream kernel by the dispatcher's own rule"
     gen = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=gen).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16)
@@ -56,7 +56,8 @@ def test_gemm256_bf16_natural_dispatch_vs_oracle(lib, M, K, N):
     ref = O.mm(x, w, b)
     got = lib.gemm(xd, wd_, bd)
     assert_bf16_close(got, ref, ulps=1, atol=2e-3, bad_frac=1e-3, name="gemm256")
-    assert torch.equal(got, lib.gemm(xd, wd_, bd, variant=2)), "variant 0 did not run the 256x256 kernel"
+    assert torch.equal(got, lib.gemm(xd, wd_, bd, variant=3)), "variant 0 did not run the 256x256 kernel"
+    assert torch.equal(got, lib.gemm(xd, wd_, bd, variant=2)), "the two 256x256 kernels must agree bit for bit"
     assert_bf16_close(lib.gemm(xd, wd_), O.mm(x, w), ulps=1, atol=2e-3, bad_frac=1e-3, name="gemm256 no bias")
     # fused epilogues against the reference's separate ops (transformer_infer.py:402,468,488-503; pre_infer.py:74-76)
     ref_g = torch.nn.functional.gelu(ref, approximate="tanh")
@@ -73,6 +74,29 @@ def test_gemm256_bf16_natural_dispatch_vs_oracle(lib, M, K, N):
         assert_bf16_close(r, ref_r, ulps=1, atol=6e-3, bad_frac=2e-3, name=f"gemm256+residual(gate={g is not None})")
     # the two tilings agree to summation-order effects (both compared with the oracle above; this catches a tile-local defect)
     assert_bf16_close(lib.gemm(xd, wd_, bd, variant=1), got.cpu(), ulps=1, atol=2e-3, bad_frac=1e-3, name="128^2 vs 256^2")
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 5120, 5120), (4100, 5120, 13824), (300, 64, 264), (257, 128, 520), (1000, 192, 256), (515, 320, 8), (2049, 1536, 1544)])
+def test_gemm256_single_stream_kernel_is_bit_equal_to_ping_pong(lib, M, K, N):
+    """The two 256x256 kernels (variant 2: two waves per SIMD in ping-pong, variant 3: one software-pipelined wave per SIMD) run the same
+    16x16x32 MFMA over the same k order, so every output must be EQUAL — all epilogues, ragged M and N, K loops of 1..216 tiles (the
+    single-stream kernel's prologue / tail paths), K-blocked x and N-blocked y (the Ulysses exchange buffers)."""
+    gen = torch.Generator().manual_seed(M * 7 + K + N)
+    x = dev(torch.randn(M, K, generator=gen).to(torch.bfloat16))
+    w = dev((torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16))
+    b = dev((torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16))
+    for epi in (lib.EPI_NONE, lib.EPI_GELU_TANH, lib.EPI_SILU):
+        a2, a3 = lib.gemm(x, w, b, epilogue=epi, variant=2), lib.gemm(x, w, b, epilogue=epi, variant=3)
+        assert torch.equal(a2, a3), f"epilogue {epi}: max |d| = {(a2.float() - a3.float()).abs().max().item():.3e}"
+    assert torch.equal(lib.gemm(x, w, None, variant=2), lib.gemm(x, w, None, variant=3))
+    res = dev(torch.randn(M, N, generator=gen).to(torch.bfloat16))
+    gate = dev((torch.randn(1, N, generator=gen) * 0.5).to(torch.bfloat16))
+    for g in (gate, None):
+        r2, r3 = res.clone(), res.clone()
+        lib.gemm(x, w, b, epilogue=lib.EPI_RESIDUAL, resid=r2, gate=g, variant=2)
+        lib.gemm(x, w, b, epilogue=lib.EPI_RESIDUAL, resid=r3, gate=g, variant=3)
+        assert torch.equal(r2, r3)
+    assert torch.isfinite(lib.gemm(x, w, b, variant=3).float()).all()
 
 
 @pytest.mark.parametrize("M,K,N", [(4096, 5120, 5120), (4100, 5120, 13824), (4096, 13824, 5120)])
@@ -195,7 +219,7 @@ def test_wan14b_block_vs_oracle(ref_rounding):
     dims = dict(synth.WAN_DIMS["wan2.1-14b"], num_layers=1)
     ts = (16, 5, 32, 64)  # (C, T, H, W) latent → 5 x 16 x 32 = 2560 tokens
     S = synth.seq_len_of(ts)
-    assert lib.gemm_kernel_choice(S, dims["dim"], dims["dim"]) == 2 and lib.gemm_kernel_choice(S, dims["ffn_dim"], dims["dim"]) == 2
+    assert lib.gemm_kernel_choice(S, dims["dim"], dims["dim"]) == 3 and lib.gemm_kernel_choice(S, dims["ffn_dim"], dims["dim"]) == 3
     wd = synth.synth_wan_weights(dims, seed=11)
     lat, ctx, _ = synth.synth_inputs(dims, ts)
     t = torch.tensor(777)
