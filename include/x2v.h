@@ -317,6 +317,12 @@ int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_strid
 int x2v_vae_prep_f16(const float* x, void* y, int T, int H, int W, int C, const float* gamma, const float* a, const float* b, int silu, int upsample,
                      int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, void* stream);
 
+/* x2v_vae_prep_f16 writing the hi/lo fp16 split of its result (x = hi + lo, hi = fp16(x), lo = fp16(x - hi): ~22 mantissa bits) as channels
+ * [hi | hi | lo] (3*C halves per pixel, y_px_stride >= 3*C).  With weights laid out [hi | lo | hi] along Cin, x2v_vae_conv_f16 accumulates
+ * xh.wh + xh.wl + xl.wh in fp32: the Wan VAE's fp32 convolutions (vae.py:794) at fp32-grade accuracy on the 16-bit matrix instruction. */
+int x2v_vae_prep_split_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a, const float* b, int silu, int upsample,
+                           int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, void* stream);
+
 /* x2v_vae_prep_ex_f32 writing fp16: fills the operand buffer of x2v_vae_conv_f16 (y strides in halves, C % 8 == 0). */
 int x2v_vae_prep_ex_f16(const float* x, void* y, int T, int H, int W, int C, const float* mul, const float* add, int silu, int clamp01, int up_hw, int up_t,
                         int64_t y_frame_stride, int64_t y_row_stride, void* stream);

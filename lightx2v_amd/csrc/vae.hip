@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void vae_conv16_kernel(const _Float16* __re
 template <int LPP, typename OT = float>
 __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__ x, OT* __restrict__ y, int64_t npix, int Hh, int Ww, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ a, const float* __restrict__ b,
-                                                       int silu, int up, int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride) {
+                                                       int silu, int up, int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, int split = 0) {
   constexpr int GPB = 256 / LPP;  // pixel groups per block
   const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
   const int nch = C / 4;
@@ -425,6 +425,19 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
         *reinterpret_cast<Out4*>(yb + y_px_stride + c4 * 4) = ov;
         *reinterpret_cast<Out4*>(yb + y_row_stride + c4 * 4) = ov;
         *reinterpret_cast<Out4*>(yb + y_row_stride + y_px_stride + c4 * 4) = ov;
+      }
+      if constexpr (sizeof(OT) == 2) {
+        if (split) {
+          // hi/lo operand split (x = hi + lo to ~22 mantissa bits): channels [hi | hi | lo], to meet weights laid out [hi | lo | hi] —
+          // the 16-bit convolution then accumulates xh.wh + xh.wl + xl.wh in fp32 (the xl.wl term is below fp32 resolution)
+          const Out4 lv = {{(OT)(o[0] - (float)ov.e[0]), (OT)(o[1] - (float)ov.e[1]), (OT)(o[2] - (float)ov.e[2]), (OT)(o[3] - (float)ov.e[3])}};
+#pragma unroll
+          for (int q = 0; q < (up ? 4 : 1); ++q) {
+            OT* yq = yb + (q & 1) * y_px_stride + (q >> 1) * y_row_stride;
+            *reinterpret_cast<Out4*>(yq + C + c4 * 4) = ov;
+            *reinterpret_cast<Out4*>(yq + 2 * C + c4 * 4) = lv;
+          }
+        }
       }
     }
   }
@@ -932,27 +945,40 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_ex_f32(const 
 }
 
 // x2v_vae_prep_f32 writing fp16 with an explicit pixel stride (channel axis padded to a multiple of 64 for x2v_vae_conv_f16); strides in halves
-extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a,
-                                                                       const float* b, int silu, int upsample, int64_t y_frame_stride, int64_t y_row_stride,
-                                                                       int64_t y_px_stride, void* stream) {
+static int vae_prep_f16_impl(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a, const float* b, int silu, int upsample,
+                             int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, int split, void* stream) {
   X2V_REQUIRE(x && y, X2V_E_ARG, "vae_prep_f16: null pointer");
   X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && C > 0 && C % 4 == 0 && C <= 1024, X2V_E_SHAPE, "vae_prep_f16: bad shape (C %% 4 == 0, C <= 1024)");
-  X2V_REQUIRE(y_frame_stride % 8 == 0 && y_row_stride % 8 == 0 && y_px_stride % 8 == 0 && y_px_stride >= C && aligned16(x) && aligned16(y) && aligned16(gamma) &&
-                  aligned16(a) && aligned16(b),
-              X2V_E_ALIGN, "vae_prep_f16: 16-byte alignment (strides multiples of 8 halves)");
+  X2V_REQUIRE(y_frame_stride % 8 == 0 && y_row_stride % 8 == 0 && y_px_stride % 8 == 0 && y_px_stride >= (split ? 3 : 1) * C && aligned16(x) && aligned16(y) &&
+                  aligned16(gamma) && aligned16(a) && aligned16(b),
+              X2V_E_ALIGN, "vae_prep_f16: 16-byte alignment (strides multiples of 8 halves, pixel stride >= the channels written)");
   const int64_t npix = (int64_t)T * Hh * Ww;
   hipStream_t st = (hipStream_t)stream;
   if (C <= 128) {
     const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
     hipLaunchKernelGGL((vae_prep_kernel<32, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
-                       y_frame_stride, y_row_stride, y_px_stride);
+                       y_frame_stride, y_row_stride, y_px_stride, split);
   } else {
     const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
     hipLaunchKernelGGL((vae_prep_kernel<64, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
-                       y_frame_stride, y_row_stride, y_px_stride);
+                       y_frame_stride, y_row_stride, y_px_stride, split);
   }
   X2V_LAUNCH_CHECK("vae_prep_f16 launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a,
+                                                                       const float* b, int silu, int upsample, int64_t y_frame_stride, int64_t y_row_stride,
+                                                                       int64_t y_px_stride, void* stream) {
+  return vae_prep_f16_impl(x, y, T, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride, y_px_stride, 0, stream);
+}
+
+// The same pass writing the hi/lo split of its result, channels [hi | hi | lo] (3 C halves per pixel): operand of x2v_vae_conv_f16 with weights
+// [hi | lo | hi] — fp32-grade convolution (~22 mantissa bits per operand) on the 16-bit matrix instruction
+extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_split_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a,
+                                                                             const float* b, int silu, int upsample, int64_t y_frame_stride, int64_t y_row_stride,
+                                                                             int64_t y_px_stride, void* stream) {
+  return vae_prep_f16_impl(x, y, T, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride, y_px_stride, 1, stream);
 }
 
 // fp32 in, fp16 out: the operand buffer of x2v_vae_conv_f16 (strides in halves)

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "x2v_softmax_rows_f32": [_c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
     "x2v_vae_conv_f16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "x2v_vae_prep_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _i64, _c_void_p],
+    "x2v_vae_prep_split_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _i64, _c_void_p],
     "x2v_vae_prep_ex_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_vae_prep_ex_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_vae_replicate_border_f32": [_c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
@@ -606,17 +607,20 @@ def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0
     return out
 
 
-def vae_prep(x, y_view, y_strides, gamma=None, a=None, b=None, silu=False, upsample=False):
-    """x [T,H,W,C] contiguous fp32 -> y_view (first element = destination of pixel (0,0,0)); y_strides = (frame, row) in floats."""
+def vae_prep(x, y_view, y_strides, gamma=None, a=None, b=None, silu=False, upsample=False, split=False):
+    """x [T,H,W,C] contiguous fp32 -> y_view (first element = destination of pixel (0,0,0)); y_strides = (frame, row) in floats.
+    split (fp16 y_view only): write the hi/lo split [hi | hi | lo] (3*C channels per pixel, x2v_vae_prep_split_f16)."""
     T, H, W, C = _f32dense(x, "vae_prep x", 4).shape
     for nm, t in (("gamma", gamma), ("a", a), ("b", b)):
         _f32dense(t, f"vae_prep {nm}", numel=C)
     _dev_view(y_view, "vae_prep y", (torch.float32, torch.float16))
     init()
     if y_view.dtype == torch.float16:  # operand buffer of the 16-bit convolution: channel axis possibly padded (pixel stride from the view)
-        _check(_lib.x2v_vae_prep_f16(_p(x), _p(y_view), T, H, W, C, _p(gamma), _p(a), _p(b), int(silu), int(upsample), y_strides[0], y_strides[1], y_view.stride(2), _stream()),
-               "vae_prep_f16")
+        fn = _lib.x2v_vae_prep_split_f16 if split else _lib.x2v_vae_prep_f16
+        _check(fn(_p(x), _p(y_view), T, H, W, C, _p(gamma), _p(a), _p(b), int(silu), int(upsample), y_strides[0], y_strides[1], y_view.stride(2), _stream()), "vae_prep_f16")
         return
+    if split:
+        raise X2VError("vae_prep: split needs an fp16 destination")
     _check(_lib.x2v_vae_prep_f32(_p(x), _p(y_view), T, H, W, C, _p(gamma), _p(a), _p(b), int(silu), int(upsample), y_strides[0], y_strides[1], _stream()), "vae_prep")
 
 

@@ -94,7 +94,7 @@ def test_vae_decode_matches_reference_fixture():
     gld = load_file(os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
     dim, seed = int(gld["dim"]), int(gld["seed"])
     sd = synth.synth_wan_vae_weights(dim=dim, seed=seed)
-    m = vae.WanVAE(sd, dim=dim)
+    m = vae.WanVAE(sd, dim=dim, conv16=False)  # the fp32 matrix instruction
     out = m.decode(gld["z"].cuda())
     assert out.shape == (1, 3, 9, 64, 64)
     _check(out[0], gld["decoded"], "WanVAE.decode vs reference fixture")
@@ -116,7 +116,7 @@ def test_vae_decode_frame_batched_is_bit_identical():
     dim, seed = int(gld["dim"]), int(gld["seed"])
     sd = synth.synth_wan_vae_weights(dim=dim, seed=seed)
     z = torch.randn(16, 6, 8, 8, generator=torch.Generator().manual_seed(5)).cuda()
-    for conv16 in (False, True):
+    for conv16 in (False, True, "split"):
         ref = vae.WanVAE(sd, dim=dim, conv16=conv16, chunk_frames=1).decode(z)
         assert ref.shape == (1, 3, 21, 64, 64) and torch.isfinite(ref).all()
         for g in (2, 3, 4, 5, 8):
@@ -124,9 +124,9 @@ def test_vae_decode_frame_batched_is_bit_identical():
             out = m.decode(z)
             assert torch.equal(out, ref), f"chunk_frames={g} conv16={conv16}: max |d| = {(out - ref).abs().max().item():.3e}"
             assert torch.equal(m.decode(z), ref)  # second decode on the grown buffers
-    # the committed fixture through the default chunking
+    # the committed fixture through the default construction (hi/lo split operands, two latent frames per pass)
     out = vae.WanVAE(sd, dim=dim).decode(gld["z"].cuda())
-    _check(out[0], gld["decoded"], "WanVAE.decode (chunk_frames=4) vs reference fixture")
+    _check(out[0], gld["decoded"], "WanVAE.decode (defaults) vs reference fixture")
 
 
 def test_vae_decode_fp16_operands_opt_in():
@@ -185,6 +185,54 @@ def test_vae_decode_fp16_operands_opt_in():
     _check(out96[0], ref96, "WanVAE.decode dim 96 (fp16 conv operands) vs oracle", atol=2e-2, rel=1e-2)
 
 
+def test_vae_decode_split_fp16_is_fp32_grade():
+    """WanVAE(conv16="split"): activations and weights of the 3x3(x3) convolutions as hi + lo fp16 pairs (~22 mantissa bits), three 16-bit
+    products per fp32 product, fp32 accumulation — held to the SAME tolerance as the all-fp32 decode (|d| <= 2e-3, relative L2 <= 1e-3;
+    the fp16-operand form needs 2e-2 / 1e-2), against the reference fixture and against the oracle at the released widths; the split of a
+    single convolution against fp32 conv3d of the unrounded operands; bit-identical across frame chunkings like the other forms."""
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import lib, synth, vae
+    from oracle import wan_vae_oracle as V
+
+    g = torch.Generator().manual_seed(7)
+    for (T, H, W, Cin, Cout, kt, kh, kw) in [(2, 9, 11, 96, 160, 3, 3, 3), (1, 17, 33, 64, 3, 3, 3, 3), (2, 8, 32, 128, 96, 1, 3, 3)]:
+        x = torch.randn(T, H, W, Cin, generator=g) * 3
+        w = torch.randn(Cout, Cin, kt, kh, kw, generator=g) / (kt * kh * kw * Cin) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        ph, pw = kh // 2, kw // 2
+        xin = F.pad(x.permute(3, 0, 1, 2), (pw, pw, ph, ph, kt - 1, 0))
+        ref = F.conv3d(xin.unsqueeze(0).double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+        cp = (3 * Cin + 63) // 64 * 64
+        buf = torch.zeros(kt - 1 + T, H + 2 * ph, W + 2 * pw, cp, dtype=torch.float16, device="cuda")
+        strides = ((H + 2 * ph) * (W + 2 * pw) * cp, (W + 2 * pw) * cp, cp)
+        lib.vae_prep(x.cuda(), buf[kt - 1 :, ph:, pw:], strides[:2], split=True)
+        hi = x.half()
+        assert torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, :Cin].cpu(), hi) and torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, Cin : 2 * Cin].cpu(), hi)
+        assert torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, 2 * Cin : 3 * Cin].cpu(), (x - hi.float()).half())
+        wcl = w.permute(0, 2, 3, 4, 1).contiguous()
+        whi = wcl.half()
+        w16 = torch.zeros(Cout, kt, kh, kw, cp, dtype=torch.float16)
+        w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, (wcl - whi.float()).half(), whi
+        out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
+        lib.vae_conv16(buf, strides, w16.cuda(), out, T, H, W, bias=b.cuda())
+        _check(out, ref, f"split conv {(kt, kh, kw)} Cin={Cin} Cout={Cout}", atol=2e-5, rel=2e-6)
+    gld = load_file(os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
+    dim, seed = int(gld["dim"]), int(gld["seed"])
+    sd_t = synth.synth_wan_vae_weights(dim=dim, seed=seed)
+    m = vae.WanVAE(sd_t, dim=dim, conv16="split")
+    out = m.decode(gld["z"].cuda())
+    assert m.model.decoder.w16, "no convolution took the 16-bit path"
+    _check(out[0], gld["decoded"], "WanVAE.decode (hi/lo split) vs reference fixture")
+    assert torch.equal(out, vae.WanVAE(sd_t, dim=dim, conv16="split", chunk_frames=1).decode(gld["z"].cuda()))
+    sd = synth.synth_wan_vae_weights(dim=96, seed=3)
+    z = torch.randn(16, 2, 6, 8, generator=torch.Generator().manual_seed(6))
+    mean, inv_std = torch.tensor(synth.WAN_VAE_MEAN), 1.0 / torch.tensor(synth.WAN_VAE_STD)
+    with torch.no_grad():
+        ref96 = V.wan_vae_decode(sd, z, mean, inv_std, dim=96)
+    _check(vae.WanVAE(sd, dim=96, conv16="split").decode(z.cuda())[0], ref96, "WanVAE.decode dim 96 (hi/lo split) vs oracle")
+
+
 def test_vae_decode_real_widths_vs_oracle():
     """dim = 96 (384/384/384/192/96 channels, the released Wan2.1 VAE widths) on a small latent; checker = CPU oracle."""
     from lightx2v_amd import synth, vae
@@ -196,6 +244,6 @@ def test_vae_decode_real_widths_vs_oracle():
     mean, inv_std = torch.tensor(synth.WAN_VAE_MEAN), 1.0 / torch.tensor(synth.WAN_VAE_STD)
     with torch.no_grad():
         ref = V.wan_vae_decode(sd, z, mean, inv_std, dim=96)
-    out = vae.WanVAE(sd, dim=96).decode(z.cuda())
+    out = vae.WanVAE(sd, dim=96, conv16=False).decode(z.cuda())
     assert out.shape == (1, 3, 5, 32, 64)
     _check(out[0], ref, "WanVAE.decode (dim 96) vs oracle")

@@ -14,10 +14,14 @@ run bench_default timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$O
 find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 run bench13 timeout 600 python bench.py --workload wan1.3b_480px49f --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench13.json" 2> "$OUT/bench13.err"; cat "$OUT/bench13.json" >> "$OUT/summary.txt"
 run bench_fp8_distill timeout 600 python bench.py --fp8 --distill --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench14_fp8_distill.json" 2> "$OUT/bench14_fp8_distill.err"; cat "$OUT/bench14_fp8_distill.json" >> "$OUT/summary.txt"
+run torch_step_cfg2 timeout 300 python tools/torch_step_baseline.py --workload wan1.3b_480px49f > "$OUT/torch_step_wan13b_480p.json" 2> "$OUT/torch_step.err"; cat "$OUT/torch_step_wan13b_480p.json" >> "$OUT/summary.txt"
+run gemm_vs_hipblaslt timeout 300 python tools/gemm_vs_hipblaslt.py > "$OUT/gemm_vs_hipblaslt.json" 2> "$OUT/gemm_cmp.err"; cat "$OUT/gemm_vs_hipblaslt.json" >> "$OUT/summary.txt"
 run hunyuan timeout 600 python tools/hunyuan_bench.py > "$OUT/hunyuan13b.json" 2> "$OUT/hunyuan13b.err"; cat "$OUT/hunyuan13b.json" >> "$OUT/summary.txt"
 run e2e_13b timeout 300 python tools/e2e.py --workload wan1.3b_480px49f --steps 50 > "$OUT/e2e_wan13b_480p.json" 2> "$OUT/e2e13.err"; cat "$OUT/e2e_wan13b_480p.json" >> "$OUT/summary.txt"
 run e2e_fp8_distill timeout 400 python tools/e2e.py --fp8 --distill > "$OUT/e2e_wan14b_fp8_distill.json" 2> "$OUT/e2e_fp8.err"; cat "$OUT/e2e_wan14b_fp8_distill.json" >> "$OUT/summary.txt"
-run vae_wan_fp32 timeout 300 python tools/vae_bench.py --latent 16,21,90,160 > "$OUT/vae_wan_720p81f_fp32.json" 2> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_fp32.json" >> "$OUT/summary.txt"
+run vae_wan_split timeout 300 python tools/vae_bench.py --latent 16,21,90,160 --split > "$OUT/vae_wan_720p81f_split.json" 2> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_split.json" >> "$OUT/summary.txt"
+run vae_wan_split4 timeout 300 python tools/vae_bench.py --latent 16,21,90,160 --split --chunk-frames 4 > "$OUT/vae_wan_720p81f_split_chunk4.json" 2>> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_split_chunk4.json" >> "$OUT/summary.txt"
+run vae_wan_fp32 timeout 300 python tools/vae_bench.py --latent 16,21,90,160 --chunk-frames 4 > "$OUT/vae_wan_720p81f_fp32.json" 2>> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_fp32.json" >> "$OUT/summary.txt"
 run vae_wan_fp16 timeout 300 python tools/vae_bench.py --latent 16,21,90,160 --conv16 > "$OUT/vae_wan_720p81f_fp16ops.json" 2>> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_fp16ops.json" >> "$OUT/summary.txt"
 run vae_hunyuan_tile timeout 300 python tools/hunyuan_vae_bench.py > "$OUT/vae_hunyuan_tile_fp16ops.json" 2> "$OUT/vae_hy.err"; cat "$OUT/vae_hunyuan_tile_fp16ops.json" >> "$OUT/summary.txt"
 run vae_hunyuan_full timeout 400 python tools/hunyuan_vae_bench.py --full > "$OUT/vae_hunyuan_720p129f_fp16ops.json" 2>> "$OUT/vae_hy.err"; cat "$OUT/vae_hunyuan_720p129f_fp16ops.json" >> "$OUT/summary.txt"
