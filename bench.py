@@ -156,15 +156,14 @@ def ulysses_self_check(dist, world, rank):
     path: RCCL all-to-alls on the blocked exchange buffers) and unsharded on every rank; the two noise predictions must agree to 5e-3
     relative L2 on every rank (same kernels on re-partitioned rows).  The result travels in the JSON line so that a scaling record
     proves N ranks really exchanged data."""
-    from lightx2v_amd import scheduler, synth, wan
+    from lightx2v_amd import scheduler, synth, ulysses, wan
 
     dims = dict(synth.WAN_DIMS["wan-tiny"], dim=256 * world, num_heads=2 * world, ffn_dim=1024, num_layers=2)
     ts = (16, 3, 8 * world, 12)  # tokens divisible by N
     wd = synth.synth_wan_weights(dims, seed=3, device="cuda", gen_device="cuda")
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
-    outs = []
-    for pat in (None, "ulysses"):
+    def one(pat):
         cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=pat)
         model = wan.WanModel(cfg, wd)
         sch = scheduler.WanScheduler(cfg, device="cuda")
@@ -172,14 +171,34 @@ def ulysses_self_check(dist, world, rank):
         model.set_scheduler(sch)
         sch.step_pre(0)
         model.infer(inputs)
-        outs.append(sch.noise_pred.float())
+        torch.cuda.synchronize()
+        return sch.noise_pred.float()
+
+    outs = [one(None)]
+    # The designed exchange path first; if this PyTorch/RCCL build rejects one of its collective forms (argument errors are raised on every
+    # rank alike, before anything is sent) the simpler forms are tried, and the one that ran is named in the JSON line.
+    path, errors = None, []
+    for name, blocked, halves in (("blocked buffers, head->seq in two overlapped halves", True, True), ("blocked buffers, one head->seq exchange", True, False),
+                                  ("row-major exchange (reference form, transposing copies)", False, False)):
+        wan.WanTransformerInfer.blocked_exchange = blocked
+        ulysses.UlyssesAttention.split_head2seq_default = halves
+        try:
+            outs.append(one("ulysses"))
+            path = name
+            break
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"{name}: {type(e).__name__}: {str(e)[:200]}")
+            if rank == 0:
+                print(f"bench: Ulysses exchange path '{name}' failed: {errors[-1]}", file=sys.stderr)
+    if path is None:
+        raise SystemExit("bench: no Ulysses exchange path works on this node: " + " | ".join(errors))
     rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).reshape(1)
     worst = rel.clone()
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     ok = bool(worst.item() < 5e-3)
     if not ok:
         raise SystemExit(f"bench: Ulysses self-check failed on rank {rank}: relative L2 {rel.item():.3e} (worst {worst.item():.3e})")
-    return {"ranks": world, "worst_rel_l2": worst.item(), "tolerance": 5e-3, "passed": ok}
+    return {"ranks": world, "worst_rel_l2": worst.item(), "tolerance": 5e-3, "passed": ok, "exchange_path": path, "rejected_paths": errors}
 
 
 def main():

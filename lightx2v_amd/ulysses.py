@@ -62,6 +62,9 @@ class UlyssesAttention:
         self.comm_stream = None
         self._buffers = {}
         self.copies = 0  # layout copies made by the row-major entry (the blocked entry makes none): asserted by the tests
+        self.split_head2seq = self.split_head2seq_default  # head->seq in two halves (all_to_all_single with split sizes) under the second half's attention
+
+    split_head2seq_default = True
 
     class _Pending:
         """An exchange already issued on the communication stream (result valid once the compute stream has joined it)."""
@@ -128,7 +131,7 @@ class UlyssesAttention:
         fast = self._default_attn and (variant & 0xFF) == lib.ATTN_FAST
         vt = lib.transpose_heads(vh, hl) if fast else None  # the ping-pong kernel reads V^T (1/N of the single-GPU transposition)
         # head->seq in two halves by destination rank: rows [0, split) of o go to ranks [0, N/2), the rest to ranks [N/2, N)
-        halves = [(0, n)] if n < 2 else [(0, n // 2), (n // 2, n)]
+        halves = [(0, n)] if n < 2 or not self.split_head2seq else [(0, n // 2), (n // 2, n)]
         for (j0, j1) in halves:
             rows = slice(j0 * s_local, j1 * s_local)
 
@@ -277,6 +280,7 @@ class UlyssesHunyuanAttention:
         self.comm_stream = None
         self._buffers = {}
         self.copies = 0  # image-row layout copies made by the row-major entry (the blocked entry makes none): asserted by the tests
+        self.split_head2seq = True
 
     # ---- the fused driver's path: exchange buffers are kernel operands ---------------------------------------------------
     def buffers(self, n_img, n_txt, hd, mlp, dtype, device):
@@ -354,7 +358,7 @@ class UlyssesHunyuanAttention:
                 lib.attention(jq[rows], jk[:nq], jv[:nq], hl, 128, out=o[rows], variant=variant)
 
         # head->seq of the image rows in two halves by destination rank: the first half's exchange runs under the second half's attention
-        halves = [(0, n)] if n < 2 else [(0, n // 2), (n // 2, n)]
+        halves = [(0, n)] if n < 2 or not self.split_head2seq else [(0, n // 2), (n // 2, n)]
         for hi, (j0, j1) in enumerate(halves):
             last = hi == len(halves) - 1
             attend(slice(j0 * n_img, nq if last else j1 * n_img))  # the valid text queries ride with the last half

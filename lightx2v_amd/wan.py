@@ -303,7 +303,7 @@ class WanTransformerInfer:
         variant = (lib.ATTN_FAST | lib.ATTN_Q_PRESCALED) if fast else 0
         rope_args = dict(s0=self.sp_rank * s_local, eps=weights.self_attn_norm_q.eps, round_mode=self.round_mode, q_out_scale=lib.ATTN_PRESCALE if fast else 1.0)
         pa = self.parallel_attention
-        if pa is not None and hasattr(pa, "attend_blocked") and x.is_cuda and self._blocked_ok(weights):
+        if pa is not None and hasattr(pa, "attend_blocked") and x.is_cuda and self.blocked_exchange and self._blocked_ok(weights):
             # Ulysses without layout copies: the exchange buffers [N, S/N, (H/N)d] are kernel operands (ulysses.py)
             b = pa.buffers(s_local, x.shape[1], x.dtype, x.device)
             weights.self_attn_v.apply(n1, out=b["sv"])  # v needs no norm / RoPE: projected first, straight into its send buffer,
@@ -327,6 +327,8 @@ class WanTransformerInfer:
         else:
             attn = pa(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)
         return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
+
+    blocked_exchange = True  # Ulysses: exchange buffers as kernel operands (False: the reference's row-major form with its transposing copies)
 
     @staticmethod
     def _blocked_ok(weights):
