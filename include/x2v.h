@@ -149,6 +149,11 @@ int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw
 int x2v_gemm_bf16_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kblock_stride, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy,
                           int y_nblock, int64_t y_nblock_stride, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
 
+/* v = x . W^T + bias written as V^T [N/128][ldvt/64][128][64] with tokens in [M, ldvt) zero-filled — x2v_gemm_bf16 followed by
+ * x2v_transpose_heads_bf16 in one kernel (same bits): the self-attention v projection (transformer_infer.py:345-347) handing its result to
+ * x2v_attn_fwd_bf16_vt without the transposing pass.  Only for shapes that x2v_gemm_kernel_choice maps to kernel 3 (else X2V_E_SHAPE). */
+int x2v_gemm_bf16_vt(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int K, void* stream);
+
 /* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape: 1 = the
  * 128x128 kernel, 2 = the 256x256 ping-pong kernel (fp8), 3 = the 256x256 single-stream kernel (bf16) (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it
  * compared with the oracle is the one the dispatcher takes for a model's shapes. */

@@ -260,6 +260,7 @@ int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, i
 // gemm256s.hip: the same tile as one software-pipelined wave per SIMD (bf16)
 int gemm256s_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
                       const void* resid, int64_t ldr, const void* gate, int gm_tiles, hipStream_t st, GemmBlocking gb);
+int gemm256s_vt_dispatch(const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int nk, hipStream_t st);
 }  // namespace x2v
 
 using namespace x2v;
@@ -421,6 +422,22 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8_variant(const
 extern "C" __attribute__((visibility("default"))) int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                             int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream) {
   return x2v_gemm_fp8_variant(xq, ldx, sx, wq, ldw, sw, bias, y, ldy, M, N, K, epilogue, resid, ldr, gate, 0, stream);
+}
+
+// v projection with V^T output (the operand of x2v_attn_fwd_bf16_vt) straight from the GEMM epilogue: only the single-stream 256x256 kernel
+// has this output mode, so shapes the dispatcher would give to another kernel are refused (X2V_E_SHAPE: run x2v_gemm_bf16 +
+// x2v_transpose_heads_bf16 instead; x2v_gemm_kernel_choice tells beforehand).
+extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16_vt(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt, int64_t ldvt, int64_t M,
+                                                                       int N, int K, void* stream) {
+  X2V_REQUIRE(x && w && vt, X2V_E_ARG, "gemm_bf16_vt: null pointer");
+  X2V_REQUIRE(K > 0 && K % GB_K == 0, X2V_E_SHAPE, "gemm_bf16_vt: K=%d must be a positive multiple of %d", K, GB_K);
+  X2V_REQUIRE(M > 0 && N > 0 && N % 128 == 0, X2V_E_SHAPE, "gemm_bf16_vt: N=%d must be whole heads of 128", N);
+  X2V_REQUIRE(ldvt % 64 == 0 && ldvt >= M, X2V_E_SHAPE, "gemm_bf16_vt: ldvt must be a multiple of 64 and >= M");
+  X2V_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && aligned16(x) && aligned16(w) && aligned16(vt) && (bias == nullptr || ((uintptr_t)bias % 2) == 0),
+              X2V_E_ALIGN, "gemm_bf16_vt: operand rows must be 16-byte aligned");
+  X2V_REQUIRE(choose_kernel(M, N, K / GB_K, ldx * 2, ldw * 2, false) == 3, X2V_E_SHAPE,
+              "gemm_bf16_vt: this shape is not dispatched to the single-stream 256x256 kernel (use x2v_gemm_bf16 + x2v_transpose_heads_bf16)");
+  return gemm256s_vt_dispatch(x, ldx * 2, w, ldw * 2, bias, vt, ldvt, M, N, K / GB_K, (hipStream_t)stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8) {

@@ -68,7 +68,11 @@ __device__ __forceinline__ float s_acc_read() {
   return x;
 }
 
-template <int EPI>
+// VT (epilogue NONE only): y is written TRANSPOSED per head and 64-token block — V^T [N/128][ldy/64][128][64], the operand layout of the
+// ping-pong attention kernel (x2v_transpose_heads_bf16's output), tokens in [M, ldy) zero-filled.  The MFMA operands swap roles, so a lane
+// owns four consecutive TOKENS of one output channel and the staging / store code stays 8- and 16-byte wide; every (m, n) sums the same
+// products in the same order as in the row-major form (bit-identical values).
+template <int EPI, bool VT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256s_kernel(
     const char* __restrict__ A, int64_t lda_bytes, const char* __restrict__ W, int64_t ldw_bytes, const unsigned short* __restrict__ bias,
     unsigned short* __restrict__ Y, int64_t ldy, int64_t M, int N, int nk, const unsigned short* __restrict__ resid, int64_t ldr,
@@ -179,7 +183,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned kw1 = (unsigned)(t + 1) * 128u, kw2 = (unsigned)(t + 2) * 128u;
     s_for<0, 128>([&](auto nc) {
       constexpr int n = decltype(nc)::value, ks = n >> 6, xb = (n >> 3) & 7, wb = n & 7;
-      s_mfma<xb * 8 + wb>(fw[ks][wb], fx[ks][xb]);
+      if constexpr (VT) s_mfma<xb * 8 + wb>(fx[ks][xb], fw[ks][wb]);
+      else s_mfma<xb * 8 + wb>(fw[ks][wb], fx[ks][xb]);
       if constexpr (n < 32 && (n & 1) == 0) S_READ(n >> 1, ST, 1)  // k-step 1 of this tile
       // the last 16 - S_EARLY pieces of tile t+1 (its stage was freed by the previous tile's first barrier)
       if constexpr (n >= S_LATE0 && (n - S_LATE0) % S_STEP == 0 && (n - S_LATE0) / S_STEP < 16 - S_EARLY) {
@@ -229,77 +234,119 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __builtin_amdgcn_s_barrier();                                 // every wave is past its last fragment read: LDS becomes the staging area
   S_SB();
 
-  // ---- epilogue phase 1: acc (+bias, activation) -> bf16 -> LDS [256][S_EPI_LD]
-  //      tile (xb, wb), register e: tile row wr*128 + xb*16 + r16, tile col wc*128 + wb*16 + 4*g16 + e
-  uint2 bv[8];
+  if constexpr (VT) {
+    static_assert(EPI == X2V_EPI_NONE, "V^T output: plain epilogue only");
+    // ---- phase 1: tile (xb, wb), register e: channel wc*128 + wb*16 + r16, token wr*128 + xb*16 + 4*g16 + e  ->  LDS [256 channels][S_EPI_LD]
+    float bvt[8];
 #pragma unroll
-  for (int wb = 0; wb < 8; ++wb) {
-    int gn = n0 + wc * 128 + wb * 16 + 4 * g16;
-    gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
-    bv[wb] = make_uint2(0u, 0u);
-    if (bias != nullptr) bv[wb] = *reinterpret_cast<const uint2*>(bias + gn);
-  }
-  s_for<0, 64>([&](auto ic) {
-    constexpr int I = decltype(ic)::value, xb = I >> 3, wb = I & 7;
-    const int ml = wr * 128 + xb * 16 + r16, nl = wc * 128 + wb * 16 + 4 * g16;
-    float vv[4] = {s_acc_read<4 * I + 0>(), s_acc_read<4 * I + 1>(), s_acc_read<4 * I + 2>(), s_acc_read<4 * I + 3>()};
-    vv[0] += bf_lo(bv[wb].x);
-    vv[1] += bf_hi(bv[wb].x);
-    vv[2] += bf_lo(bv[wb].y);
-    vv[3] += bf_hi(bv[wb].y);
-    if (EPI == X2V_EPI_GELU_TANH) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) vv[e] = gelu_tanh_f(rbf(vv[e]));
-    } else if (EPI == X2V_EPI_SILU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) vv[e] = silu_f(rbf(vv[e]));
+    for (int wb = 0; wb < 8; ++wb) {
+      const int gn = n0 + wc * 128 + wb * 16 + r16;
+      bvt[wb] = (bias != nullptr && gn < N) ? bf2f(bias[gn]) : 0.f;
     }
-    uint2 pk;
-    pk.x = pack_bf2(vv[0], vv[1]);
-    pk.y = pack_bf2(vv[2], vv[3]);
-    *reinterpret_cast<uint2*>(smem + ml * S_EPI_LD + nl * 2) = pk;
-  });
-  __syncthreads();
-  // ---- epilogue phase 2: 16-byte stores, 32 lanes per 512-byte output row
+    s_for<0, 64>([&](auto ic) {
+      constexpr int I = decltype(ic)::value, xb = I >> 3, wb = I & 7;
+      const int nl = wc * 128 + wb * 16 + r16, ml = wr * 128 + xb * 16 + 4 * g16;
+      uint2 pk;
+      pk.x = pack_bf2(s_acc_read<4 * I + 0>() + bvt[wb], s_acc_read<4 * I + 1>() + bvt[wb]);
+      pk.y = pack_bf2(s_acc_read<4 * I + 2>() + bvt[wb], s_acc_read<4 * I + 3>() + bvt[wb]);
+      *reinterpret_cast<uint2*>(smem + nl * S_EPI_LD + ml * 2) = pk;
+    });
+    __syncthreads();
+    // ---- phase 2: a channel's 256 tokens = four 128-byte runs of V^T; 16-byte stores, tokens past M zeroed, blocks past ldy skipped
 #pragma unroll 4
-  for (int it = 0; it < 32; ++it) {
-    const int id = it * 256 + tid;
-    const int row = id >> 5, cc = id & 31;
-    const int64_t gmr = m0 + row;
-    const int gn = n0 + cc * 8;
-    if (gmr < M && gn < N) {
-      const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
-      uint4 o = *reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16);
-      if (EPI == X2V_EPI_RESIDUAL) {
-        float yv[8], xv[8], ov[8];
-        unpack8(o, yv);
-        unpack8(*reinterpret_cast<const uint4*>(resid + gmr * ldr + gn), xv);
-        if (gate != nullptr) {
-          float gv[8];
-          unpack8(*reinterpret_cast<const uint4*>(gate + gn), gv);
+    for (int it = 0; it < 32; ++it) {
+      const int id = it * 256 + tid;
+      const int ch = id >> 5, cc = id & 31;  // channel within the tile, 8-token chunk
+      const int gn = n0 + ch;
+      const int64_t tok = m0 + cc * 8;
+      if (gn < N && tok < ldy) {
+        uint4 o = *reinterpret_cast<const uint4*>(smem + ch * S_EPI_LD + cc * 16);
+        if (tok + 8 > M) {
+          unsigned short h[8];
+          *reinterpret_cast<uint4*>(h) = o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = xv[e] + rbf(yv[e] * gv[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = xv[e] + yv[e];
+          for (int e = 0; e < 8; ++e)
+            if (tok + e >= M) h[e] = 0;
+          o = *reinterpret_cast<const uint4*>(h);
         }
-        o = pack8(ov);
+        const int64_t blocks = ldy >> 6;  // 64-token blocks per head
+        unsigned short* dst = Y + (((int64_t)(gn >> 7) * blocks + (tok >> 6)) * 128 + (gn & 127)) * 64 + (tok & 63);
+        *reinterpret_cast<uint4*>(dst) = o;
       }
-      *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = o;
     }
-  }
+  } else {
+  // ---- epilogue phase 1: acc (+bias, activation) -> bf16 -> LDS [256][S_EPI_LD]
+    //      tile (xb, wb), register e: tile row wr*128 + xb*16 + r16, tile col wc*128 + wb*16 + 4*g16 + e
+    uint2 bv[8];
+  #pragma unroll
+    for (int wb = 0; wb < 8; ++wb) {
+      int gn = n0 + wc * 128 + wb * 16 + 4 * g16;
+      gn = gn + 3 < N ? gn : (N >= 4 ? N - 4 : 0);
+      bv[wb] = make_uint2(0u, 0u);
+      if (bias != nullptr) bv[wb] = *reinterpret_cast<const uint2*>(bias + gn);
+    }
+    s_for<0, 64>([&](auto ic) {
+      constexpr int I = decltype(ic)::value, xb = I >> 3, wb = I & 7;
+      const int ml = wr * 128 + xb * 16 + r16, nl = wc * 128 + wb * 16 + 4 * g16;
+      float vv[4] = {s_acc_read<4 * I + 0>(), s_acc_read<4 * I + 1>(), s_acc_read<4 * I + 2>(), s_acc_read<4 * I + 3>()};
+      vv[0] += bf_lo(bv[wb].x);
+      vv[1] += bf_hi(bv[wb].x);
+      vv[2] += bf_lo(bv[wb].y);
+      vv[3] += bf_hi(bv[wb].y);
+      if (EPI == X2V_EPI_GELU_TANH) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = gelu_tanh_f(rbf(vv[e]));
+      } else if (EPI == X2V_EPI_SILU) {
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = silu_f(rbf(vv[e]));
+      }
+      uint2 pk;
+      pk.x = pack_bf2(vv[0], vv[1]);
+      pk.y = pack_bf2(vv[2], vv[3]);
+      *reinterpret_cast<uint2*>(smem + ml * S_EPI_LD + nl * 2) = pk;
+    });
+    __syncthreads();
+    // ---- epilogue phase 2: 16-byte stores, 32 lanes per 512-byte output row
+  #pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+      const int id = it * 256 + tid;
+      const int row = id >> 5, cc = id & 31;
+      const int64_t gmr = m0 + row;
+      const int gn = n0 + cc * 8;
+      if (gmr < M && gn < N) {
+        const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
+        uint4 o = *reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16);
+        if (EPI == X2V_EPI_RESIDUAL) {
+          float yv[8], xv[8], ov[8];
+          unpack8(o, yv);
+          unpack8(*reinterpret_cast<const uint4*>(resid + gmr * ldr + gn), xv);
+          if (gate != nullptr) {
+            float gv[8];
+            unpack8(*reinterpret_cast<const uint4*>(gate + gn), gv);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = xv[e] + rbf(yv[e] * gv[e]);
+          } else {
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = xv[e] + yv[e];
+          }
+          o = pack8(ov);
+        }
+        *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = o;
+      }
+    }
+}
 #undef S_SB
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool VT = false>
 static int launch_gemm256s(const void* x, int64_t ldx_bytes, const void* w, int64_t ldw_bytes, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
                            const void* resid, int64_t ldr, const void* gate, int gm_tiles, hipStream_t st, GemmBlocking gb) {
   if (gm_tiles <= 0) gm_tiles = 4;
   const int ntm = (int)((M + S_M - 1) / S_M), ntn = (N + S_N - 1) / S_N;
-  int rc = ensure_dynamic_lds((const void*)gemm256s_kernel<EPI>, S_LDS_BYTES, "gemm256s attr");
+  int rc = ensure_dynamic_lds((const void*)gemm256s_kernel<EPI, VT>, S_LDS_BYTES, "gemm256s attr");
   if (rc != X2V_OK) return rc;
-  hipLaunchKernelGGL((gemm256s_kernel<EPI>), dim3((unsigned)ntm * (unsigned)ntn), dim3(256), S_LDS_BYTES, st, (const char*)x, ldx_bytes, (const char*)w, ldw_bytes,
+  hipLaunchKernelGGL((gemm256s_kernel<EPI, VT>), dim3((unsigned)ntm * (unsigned)ntn), dim3(256), S_LDS_BYTES, st, (const char*)x, ldx_bytes, (const char*)w, ldw_bytes,
                      (const unsigned short*)bias, (unsigned short*)y, ldy, M, N, nk, (const unsigned short*)resid, ldr, (const unsigned short*)gate, ntm, ntn, gm_tiles, gb);
   X2V_LAUNCH_CHECK("gemm256s launch");
   return X2V_OK;
@@ -315,6 +362,11 @@ int gemm256s_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, 
     case X2V_EPI_RESIDUAL: return launch_gemm256s<X2V_EPI_RESIDUAL>(x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
     default: set_error("gemm: unknown epilogue %d", epilogue); return X2V_E_ARG;
   }
+}
+
+// V^T-producing form (x2v_gemm_bf16_vt): y = V^T [N/128][ldvt/64][128][64]; `ldvt` travels in the ldy argument
+int gemm256s_vt_dispatch(const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int nk, hipStream_t st) {
+  return launch_gemm256s<X2V_EPI_NONE, true>(x, ldxb, w, ldwb, bias, vt, ldvt, M, N, nk, nullptr, 0, nullptr, 0, st, GemmBlocking());
 }
 
 }  // namespace x2v

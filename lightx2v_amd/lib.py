@@ -32,6 +32,7 @@ PROTOTYPES = {
     "x2v_rmsnorm_rope_scaled_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _i32, _c_void_p],
     "x2v_rmsnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_rmsnorm_rope_scaled_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _c_void_p],
+    "x2v_gemm_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p],
     "x2v_headnorm_rope_blocked_bf16": [_c_void_p, _c_void_p, _i64, _i32, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _f32, _c_void_p],
     "x2v_headnorm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i32, _i64, _f32, _i32, _f32, _c_void_p],
     "x2v_gate_residual_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
@@ -343,6 +344,23 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
     return out2
 
 
+def gemm_vt(x, weight_nk, bias, num_heads):
+    """V^T [H, ceil(M/64), 128, 64] of v = x @ weight_nk.T + bias (what transpose_heads(gemm(...)) returns, same bits): one kernel when the
+    shape takes the single-stream 256x256 GEMM (x2v_gemm_bf16_vt), the two-kernel sequence otherwise."""
+    x2, w2 = _row2d(_bf16(x, "x"), "x"), _row2d(_bf16(weight_nk, "weight"), "weight")
+    M, K = x2.shape
+    N = w2.shape[0]
+    if w2.shape[1] != K or N != num_heads * 128:
+        raise X2VError(f"gemm_vt: x [M,{K}] vs weight [{N},{w2.shape[1]}] for {num_heads} heads of 128")
+    init()
+    if M == 0 or _lib.x2v_gemm_kernel_choice(M, N, K, x2.stride(0), w2.stride(0), 0) != 3:
+        return transpose_heads(gemm(x2, w2, bias), num_heads)
+    ldvt = (M + 63) // 64 * 64
+    vt = torch.empty((num_heads, ldvt // 64, 128, 64), dtype=torch.bfloat16, device=x.device)
+    _check(_lib.x2v_gemm_bf16_vt(_p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(_vec(bias, "gemm bias", N)), _p(vt), ldvt, M, N, K, _stream()), "gemm_bf16_vt")
+    return vt
+
+
 def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False):
     """1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (fp8), 3 = 256x256 single-stream kernel (bf16): what variant 0 launches for
     this shape (x2v_gemm_kernel_choice)."""
@@ -375,6 +393,10 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
             t = t.as_strided((t.shape[0], t.shape[1] * t.shape[2]), (t.stride(0), 1))
         return _row2d(_bf16(t, name), name)
 
+    if v is None:  # V^T only (gemm_vt): the pre-transposed-V kernel never reads row-major v
+        if vt is None or (variant & 0xFF) != ATTN_FAST:
+            raise X2VError("attention: v may be omitted only together with vt= and variant ATTN_FAST")
+        v = k
     q2, k2, v2 = as2d(q, "q"), as2d(k, "k"), as2d(v, "v")
     Sq, Sk = q2.shape[0], k2.shape[0]
     out2 = torch.empty((Sq, num_heads * head_dim), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(_bf16(out, "out"), "out")

@@ -82,6 +82,11 @@ class MMWeightHip(_Movable):
             w, b = w[row_slice], (None if b is None else b[row_slice])
         return lib.gemm(input_tensor, w, b, epilogue=epilogue, resid=resid, gate=gate, out=out)
 
+    def apply_vt(self, input_tensor, num_heads):
+        """The layer's output as V^T [H, ceil(M/64), 128, 64] (the attention kernel's operand) — from the GEMM epilogue when the shape takes
+        the single-stream kernel, else GEMM + transpose; same bits either way."""
+        return lib.gemm_vt(input_tensor, self.weight, self.bias, num_heads)
+
     def state_dict(self, destination=None):
         destination = {} if destination is None else destination
         destination[self.weight_name] = self.weight.cpu().detach().clone()

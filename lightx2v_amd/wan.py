@@ -315,14 +315,18 @@ class WanTransformerInfer:
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)  # K-blocked x
         # Ulysses, row-major form: v is projected first and its seq→head exchange runs on the communication stream under the q and k
         # projections and the norm+RoPE kernel
-        v = weights.self_attn_v.apply(n1, **mmkw)
+        if pa is None and fast and not mmkw and hasattr(weights.self_attn_v, "apply_vt"):
+            v, vt = None, weights.self_attn_v.apply_vt(n1, self.num_heads)  # V^T from the v projection's epilogue (the attention kernel's operand)
+        else:
+            v, vt = weights.self_attn_v.apply(n1, **mmkw), None
         v_pending = pa.begin_exchange(v) if hasattr(pa, "begin_exchange") else None
         q = weights.self_attn_q.apply(n1, **mmkw)
         k = weights.self_attn_k.apply(n1, **mmkw)
         lib.rmsnorm_rope_(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
         if pa is None:
             # the ping-pong kernel reads V^T; transposed outside the timed launch so the hook times the attention kernel alone
-            vt = lib.transpose_heads(v, self.num_heads) if fast else None
+            if vt is None and fast:
+                vt = lib.transpose_heads(v, self.num_heads)
             attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant, vt=vt))
         else:
             attn = pa(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)

@@ -99,6 +99,28 @@ def test_gemm256_single_stream_kernel_is_bit_equal_to_ping_pong(lib, M, K, N):
     assert torch.isfinite(lib.gemm(x, w, b, variant=3).float()).all()
 
 
+@pytest.mark.parametrize("M,K,H", [(4096, 5120, 40), (4100, 5120, 40), (3001, 1536, 12), (300, 512, 4)])
+def test_v_projection_with_vt_epilogue_equals_gemm_then_transpose(lib, M, K, H):
+    """x2v_gemm_bf16_vt (the v projection writing V^T [H, ceil(M/64), 128, 64] from the GEMM epilogue) against x2v_gemm_bf16 followed by
+    x2v_transpose_heads_bf16: EQUAL, including the zero fill of the tokens between M and the next multiple of 64 (ragged M) and the small
+    shape where the wrapper runs the two-kernel sequence; and the attention kernel fed by it equals the one fed by the transposed copy."""
+    N = H * 128
+    gen = torch.Generator().manual_seed(M + H)
+    x = dev(torch.randn(M, K, generator=gen).to(torch.bfloat16))
+    w = dev((torch.randn(N, K, generator=gen) / math.sqrt(K)).to(torch.bfloat16))
+    b = dev((torch.randn(N, generator=gen) * 0.1).to(torch.bfloat16))
+    v = lib.gemm(x, w, b)
+    ref = lib.transpose_heads(v, H)
+    got = lib.gemm_vt(x, w, b, H)
+    assert got.shape == ref.shape and torch.equal(got, ref), f"max |d| = {(got.float() - ref.float()).abs().max().item():.3e}"
+    assert torch.equal(lib.gemm_vt(x, w, None, H), lib.transpose_heads(lib.gemm(x, w), H))
+    if M <= 4096:
+        q, k = (dev(torch.randn(M, N, generator=gen).to(torch.bfloat16)) for _ in range(2))
+        a1 = lib.attention(q, k, v, H, variant=lib.ATTN_FAST, vt=ref)
+        a2 = lib.attention(q, k, None, H, variant=lib.ATTN_FAST, vt=got)
+        assert torch.equal(a1, a2)
+
+
 @pytest.mark.parametrize("M,K,N", [(4096, 5120, 5120), (4100, 5120, 13824), (4096, 13824, 5120)])
 def test_gemm256_fp8_natural_dispatch_vs_oracle(lib, M, K, N):
     """Per-token x per-channel w8a8 (mm_weight.py:236-245,310-318) on the 256x256 kernel's fp8 mode — the kernel config #4 runs."""
