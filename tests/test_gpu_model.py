@@ -238,7 +238,7 @@ def test_cross_kv_cache_is_transparent():
     if blk is not None and id(blk) in entry["kv"]:
         k_cached = entry["kv"][id(blk)][0]
         tr.cache_cross_kv = False
-        k_fresh, _ = tr._cross_kv(blk, entry["ctx"])
+        k_fresh, _, _ = tr._cross_kv(blk, entry["ctx"])
         tr.cache_cross_kv = True
         assert torch.equal(k_cached, k_fresh)
     # a different prompt (new tensors) is not served from the cache; an in-place edit of the same tensor is noticed too
