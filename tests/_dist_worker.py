@@ -141,6 +141,22 @@ def hunyuan_checks(r, n, ulysses, O):
     # attention is permutation-equivariant in the keys up to fp summation order: bf16-rounding agreement, not bits
     assert (out.float() - want.float()).abs().max() <= 2 ** -6, (out.float() - want.float()).abs().max()
 
+    # the fused driver's copy-free path over the same collectives (CPU tensors; on the GPU the buffers are written by the GEMM / norm kernels):
+    # head-blocked send buffers in, K-blocked projection inputs out — must equal the row-major entry bit for bit, both text-mask cases
+    hdn = H * d // n
+    for n_valid in (n_txt, n_txt - 3):
+        ref_out = torch.empty_like(q)
+        ua(q, k, v, n_img, (n_valid, n_txt), H, ref_out)
+        bufs = ua.buffers(n_img, n_txt, H * d, 4 * hdn, torch.bfloat16, "cpu")
+        for i, src in enumerate((q, k, v)):
+            bufs["snd"][i].copy_(src[:n_img].view(n_img, n, hdn).transpose(0, 1))
+        before = ua.copies
+        a_img, a_txt = ua.attend_blocked(bufs, (q[n_img:], k[n_img:], v[n_img:]), (n_valid, n_txt), H)
+        assert ua.copies == before
+        assert a_img.shape == (n + 4, n_img, hdn) and a_txt.shape == (n + 4, n_txt, hdn)
+        assert torch.equal(a_img[:n].transpose(0, 1).reshape(n_img, H * d), ref_out[:n_img]), "blocked Hunyuan exchange: image rows differ"
+        assert torch.equal(a_txt[:n].transpose(0, 1).reshape(n_txt, H * d), ref_out[n_img:]), "blocked Hunyuan exchange: text rows differ"
+
     # masked text: rows beyond n_valid attend among themselves only (two segments, as the single-GPU path)
     out2 = torch.empty_like(q)
     ua(q, k, v, n_img, (n_txt - 3, n_txt), H, out2)
