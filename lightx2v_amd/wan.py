@@ -362,7 +362,8 @@ class WanTransformerInfer:
         if not self.cache_cross_kv:
             k = weights.cross_attn_k.apply(context)
             lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
-            return k, weights.cross_attn_v.apply(context), None
+            v = weights.cross_attn_v.apply(context)
+            return k, v, (lib.transpose_heads(v, self.num_heads) if (self.round_mode == lib.ROUND_FP32 and v.is_cuda) else None)
         per_ctx = self._cross_kv_cache.get(id(context))
         if per_ctx is None or per_ctx["ctx"] is not context or per_ctx["version"] != context._version:
             while len(self._cross_kv_cache) >= 2:
