@@ -196,6 +196,13 @@ class Decoder3d:
         return self._conv_cached("head", "decoder.head.2", x, gamma=self.w["decoder.head.0.gamma"], silu=True, flags=lib.VCONV_CLAMP)
 
 
+def chunk_bounds(t, chunk_frames):
+    """[a, b) latent-frame ranges of the decoder passes: the first frame alone (the one chunk without temporal upsampling, Resample "Rep",
+    vae.py:113-115), then `chunk_frames` at a time."""
+    edges = [0, 1] + list(range(1 + chunk_frames, t, chunk_frames)) + ([t] if t > 1 else [])
+    return list(zip(edges[:-1], edges[1:]))
+
+
 class WanVAE_:
     """reference: vae.py:640-760 (decode side)."""
 
@@ -223,9 +230,7 @@ class WanVAE_:
         lib.vae_prep(zl, zn, (h * w * zc, w * zc), a=scale[1].float().contiguous(), b=scale[0].float().contiguous())
         x = torch.empty_like(zn)
         lib.vae_conv(zn, (h * w * zc, w * zc, zc), self.conv2_w, x, t, h, w, bias=self.conv2_b)
-        # the first latent frame goes alone: it is the one chunk without temporal upsampling (Resample "Rep", vae.py:113-115)
-        bounds = [0, 1] + list(range(1 + self.chunk_frames, t, self.chunk_frames)) + ([t] if t > 1 else [])
-        outs = [self.decoder.forward(x[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+        outs = [self.decoder.forward(x[a:b]) for a, b in chunk_bounds(t, self.chunk_frames)]
         self.decoder.clear_cache()
         video = torch.cat(outs, dim=0)  # [T_out, H, W, 3]
         return video.permute(3, 0, 1, 2).unsqueeze(0).contiguous()

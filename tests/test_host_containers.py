@@ -127,3 +127,17 @@ def test_load_from_disk_reaches_every_child_that_can():
     root.add_module("blocks", WeightModuleList([inner]))
     root.load_from_disk()
     assert log == [("disk", "a"), ("disk", "p"), ("disk", "a"), ("disk", "p")]
+
+
+def test_vae_chunk_bounds_cover_every_latent_frame_once():
+    """WanVAE_.decode's passes: frame 0 alone, then chunk_frames at a time, every frame exactly once and in order (the bit-identity of the
+    chunkings themselves is a GPU test: tests/test_gpu_vae.py::test_vae_decode_frame_batched_is_bit_identical)."""
+    from lightx2v_amd.vae import chunk_bounds
+
+    for t in (1, 2, 3, 5, 6, 21, 33):
+        for g in (1, 2, 3, 4, 8, 64):
+            ch = chunk_bounds(t, g)
+            assert ch[0] == (0, 1) and ch[-1][1] == t
+            assert all(a < b for a, b in ch) and all(ch[i][1] == ch[i + 1][0] for i in range(len(ch) - 1))
+            assert all(b - a <= g for a, b in ch[1:])
+    assert chunk_bounds(21, 4) == [(0, 1), (1, 5), (5, 9), (9, 13), (13, 17), (17, 21)]
