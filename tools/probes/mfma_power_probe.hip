@@ -114,6 +114,101 @@ void run(const uint4* src, float* out, const char* what) {
   if (hipGetLastError() != hipSuccess) printf("  (launch error)\n");
 }
 
+// fp8 (e4m3, unit block scales): SHAPE 0 = v_mfma_scale_f32_32x32x64_f8f6f4, 1 = v_mfma_scale_f32_16x16x128_f8f6f4; a fragment = 32 bytes per lane
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <int SHAPE, int NA, int NB, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k8(const uint4* __restrict__ src, float* __restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int i = threadIdx.x; i < 131072 / 16; i += NW * 64) reinterpret_cast<uint4*>(smem)[i] = src[i];
+  __syncthreads();
+  using acc_t = typename Acc<SHAPE>::type;
+  constexpr int KS = SHAPE == 0 ? 2 : 1;        // k-steps per 128-wide K tile (one 128-byte row)
+  constexpr int RB = SHAPE == 0 ? 4096 : 2048;
+  const int lane = threadIdx.x & 63;
+  int row, g;
+  if (SHAPE == 0) { row = lane & 31; g = lane >> 5; } else { row = lane & 15; g = lane >> 4; }
+  const int swz = (row >> 1) & 7;
+  int rd[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) rd[ks][h] = row * 128 + ((((SHAPE == 0 ? ks * 4 + g * 2 : g * 2) + h) ^ swz) << 4);
+  acc_t acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < (SHAPE == 0 ? 16 : 4); ++e) acc[i][j][e] = 0.f;
+  i32x8_t fa[2][NA], fb[2][NB];
+  auto rdf = [&](int base, int ks) {
+    const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(smem + base + rd[ks][0]), hi = *reinterpret_cast<const i32x4_t*>(smem + base + rd[ks][1]);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+#define RD8_A(BUF_, SLOT_, KS_) _Pragma("unroll") for (int i = 0; i < NA; ++i) fa[BUF_][i] = rdf((SLOT_) * 32768 + ((i * RB) & 16383), KS_);
+#define RD8_B(BUF_, SLOT_, KS_) _Pragma("unroll") for (int j = 0; j < NB; ++j) fb[BUF_][j] = rdf((SLOT_) * 32768 + 16384 + ((j * RB) & 16383), KS_);
+  RD8_A(0, 0, 0) RD8_B(0, 0, 0) RD8_A(1, 1, KS - 1) RD8_B(1, 1, KS - 1)
+  for (int it = 0; it < iters; ++it) {
+    const int slot = it & 3, nslot = (it + 1) & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cur = (KS == 1 ? it : ks) & 1, nxt = cur ^ 1;
+      if (MODE == 1) {
+        if (ks + 1 < KS) { RD8_A(nxt, slot, ks + 1) RD8_B(nxt, slot, ks + 1) } else { RD8_A(nxt, nslot, 0) RD8_B(nxt, nslot, 0) }
+      }
+      const int c = MODE == 1 ? cur : 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const i32x8_t av = fa[MODE == 1 ? c : ((i + ks) & 1)][MODE == 1 ? i : (i + ks) % NA];
+          const i32x8_t bv = fb[MODE == 1 ? c : ((j + ks) & 1)][MODE == 1 ? j : (j + ks) % NB];
+          if constexpr (SHAPE == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bv, av, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bv, av, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    }
+  }
+  float sacc = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) sacc += acc[i][j][0] + acc[i][j][3];
+  out[blockIdx.x * (NW * 64) + threadIdx.x] = sacc;
+}
+
+template <int SHAPE, int NA, int NB, int MODE, int NW>
+void run8(const uint4* src, float* out, const char* what) {
+  auto kern = k8<SHAPE, NA, NB, MODE, NW>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  constexpr int KS = SHAPE == 0 ? 2 : 1;
+  const double flop_per_iter = 256.0 * NW * KS * NA * NB * (SHAPE == 0 ? 32.0 * 32 * 64 : 16.0 * 16 * 128) * 2.0;
+  const int iters = (int)(4.0e13 / flop_per_iter) + 1;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  int n = 0;
+  for (int phase = 0; phase < 2; ++phase) {
+    const double budget = phase == 0 ? 1500.0 : 1000.0;
+    double spent = 0.0;
+    n = 0;
+    (void)hipEventRecord(e0, 0);
+    while (spent < budget) {
+      for (int r = 0; r < 8; ++r) kern<<<256, NW * 64, 131072, 0>>>(src, out, iters);
+      n += 8;
+      (void)hipEventRecord(e1, 0);
+      (void)hipEventSynchronize(e1);
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      spent = ms;
+    }
+  }
+  const double tf = flop_per_iter * iters * n / (ms * 1e-3) / 1e12;
+  printf("%-46s %s NA=%d NB=%d waves/CU=%d %s: %7.1f TFLOP/s  = busy x clock %.3f GHz\n", what, SHAPE == 0 ? "fp8 32x32x64 " : "fp8 16x16x128", NA, NB, NW,
+         MODE == 1 ? "fragments from LDS" : "operands in registers", tf, tf / 5000.0 * 2.4);
+  fflush(stdout);
+}
+
 int main() {
   uint4* src;
   float* out;
@@ -138,6 +233,12 @@ int main() {
   run<0, 2, 2, 2, 4>(src, out, "attention 64 rows per wave (0.5 per MFMA)");
   run<0, 2, 4, 2, 8>(src, out, "attention 64 rows, two waves per SIMD");
   run<0, 1, 2, 0, 8>(src, out, "  attention shape, operands in registers");
+  } else if (atoi(getenv("PROBE_SET")) == 2) {
+  run8<0, 4, 2, 1, 8>(src, out, "fp8 gemm256 today (wave tile 128x64)");
+  run8<1, 8, 4, 1, 8>(src, out, "fp8 MI16x16x128, wave tile 128x64");
+  run8<0, 4, 2, 0, 8>(src, out, "  32x32x64, operands in registers");
+  run8<1, 8, 4, 0, 8>(src, out, "  16x16x128, operands in registers");
+  run8<0, 4, 2, 1, 8>(src, out, "fp8 gemm256 today again (drift check)");
   } else {
   run<0, 4, 2, 1, 8>(src, out, "gemm256 today (wave tile 128x64)");
   run<1, 8, 4, 1, 8>(src, out, "MI16x16, wave tile 128x64, two waves per SIMD");
