@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=4.0, help="budget of the FLOP-scaled block sample (the config #1 leg runs in full)")
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
+    ap.add_argument("--no-cfg-pair", action="store_true", help="run the conditional and unconditional forwards of a step separately (default: one pass over both)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule of config #4 (no CFG, denoising_step_list 1000/750/500/250, shift 5)")
@@ -237,7 +238,7 @@ def main():
         extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
     cfg = wan.default_config(
         dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
-        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, **extra,
+        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=not args.no_cfg_pair, **extra,
     )
     if world > 1 and dims["num_heads"] % world != 0:
         raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
@@ -298,9 +299,11 @@ def main():
     flop_cross = 4.0 * s_local * dims["text_len"] * dims["num_heads"] * 128
     n_self, n_cross = timer.count("self"), timer.count("cross")
     ms_self, ms_cross = timer.total_ms("self"), timer.total_ms("cross")
-    # under Ulysses the self-attention of a layer is launched in two halves of the query rows (head->seq overlap, ulysses.py)
-    launches_per_attn = max(1, round(n_self / max(1, dims["num_layers"] * fwd * args.steps)))
-    flop_self /= launches_per_attn
+    # FLOPs per self-attention LAUNCH = the step's self-attention FLOPs / its launches: one launch covers both CFG forwards in pair mode
+    # (wan.WanModel._forward_pair), half a layer's query rows under Ulysses (head->seq overlap, ulysses.py), one forward's layer otherwise
+    launches_per_step = n_self / max(1, args.steps)
+    forwards_per_launch = dims["num_layers"] * fwd / max(launches_per_step, 1e-9)
+    flop_self *= forwards_per_launch
     # roofline object = the self-attention launches of the dominant kernel (x2v::attn_fwd_v8_kernel: 99 % of the attention
     # FLOPs, 72 % of the step's); cross-attention runs a different instantiation and is reported beside it
     attn_ms = ms_self / max(n_self, 1)
@@ -314,7 +317,9 @@ def main():
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         if pmc.get("tokens") == S and pmc.get("heads") == heads_local:
-            traffic, traffic_note = pmc["hbm_bytes_per_launch"], pmc["note"]
+            # the PMC passes profiled the launch of ONE forward's layer; a launch of this run covers `forwards_per_launch` of them
+            traffic = pmc["hbm_bytes_per_launch"] * forwards_per_launch
+            traffic_note = (f"{forwards_per_launch:g} x the per-forward launch that was profiled. " if abs(forwards_per_launch - 1.0) > 1e-6 else "") + pmc["note"]
     model_label = {"wan2.1-14b": "Wan2.1-14B", "wan2.1-1.3b": "Wan2.1-1.3B"}.get(wl["model"], wl["model"])
     res_label = {"wan14b_720px81f": "720p 81f", "wan1.3b_480px49f": "480p 49f", "wan1.3b_256x256x17f": "256x256 17f"}.get(args.workload, args.workload)
     fast_attn = not args.ref_rounding
@@ -349,7 +354,8 @@ def main():
             "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
         },
         "roofline": {
-            "kernel": ("x2v::attn_fwd_v8_kernel<8, 8, true, 1> (ping-pong, q prescaled; self-attention launches)" if fast_attn
+            "kernel": ("x2v::attn_fwd_v8_kernel<8, 8, true> (ping-pong, q prescaled; self-attention launches"
+                       + ("; one launch = both CFG forwards of a layer)" if abs(forwards_per_launch - 2.0) < 1e-6 else ")") if fast_attn
                        else "x2v::attn_fwd_pipe_kernel<8, 8> (reference-rounding mode; self-attention launches)"),
             "bound": "mfma",
             "achieved": achieved,
@@ -357,7 +363,8 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": 4.0 * S * heads_local * 128 * 2,
+            "algorithmic_bytes_per_launch": 4.0 * S * heads_local * 128 * 2 * forwards_per_launch,
+            "forwards_per_launch": forwards_per_launch,
             "launches_timed": n_self,
             "avg_launch_ms": attn_ms,
             "flop_per_launch": flop_launch,

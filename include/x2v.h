@@ -186,6 +186,15 @@ int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt,
 int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                          int H, int head_dim, float scale, int q_prescaled, void* stream);
 
+/* x2v_attn_fwd_bf16_vt over B independent sequences in ONE launch: sequence b uses q / k / V^T / o at b * {q,k,vt,o}_bstride elements from the
+ * base pointers (same Sq, Sk, H, strides).  The fused Wan driver runs the conditional and unconditional forwards of a CFG step
+ * (models/networks/wan/model.py:197-226) as one pass over both token sets; this is their self-attention — 2 x 11 840 workgroups fill the 256 CUs'
+ * last round better than two launches do.  V^T is one array [H][ldvt/64][128][64] over the stacked tokens of all sequences (each sequence padded to
+ * a multiple of 64 rows), so vt_bstride = rows_per_sequence * 128. */
+int x2v_attn_fwd_bf16_vt_batched(const void* q, int64_t ldq, int64_t q_bstride, const void* k, int64_t ldk, int64_t k_bstride, const void* vt, int64_t ldvt,
+                                 int64_t vt_bstride, void* o, int64_t ldo, int64_t o_bstride, int64_t Sq, int64_t Sk, int H, int B, int head_dim, float scale,
+                                 int q_prescaled, void* stream);
+
 /* Per-token dynamic fp8 quantisation: s[m] = amax(|x[m,:]|)/448, xq = e4m3fn(x / s) — replaces
  * vllm ops.scaled_fp8_quant(use_per_token_if_dynamic=True) / sgl_kernel.sgl_per_token_quant_fp8
  * (mm_weight.py:236-245).  xq [M,K] bytes (ld = ldq), scale fp32 [M]. */

@@ -320,14 +320,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //       into the vector half-step;
 //   (c) the tile loop is unrolled x2 so that both LDS buffer indices are compile-time: every fragment address is
 //       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
+struct AttnBatch {
+  int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
+};
+
 template <int NW, int RESCALE_THR, bool PRESCALED>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
                                                                    const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
                                                                    int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
-                                                                   unsigned v_bytes) {
+                                                                   unsigned v_bytes, AttnBatch bs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // blockIdx.z = independent sequence of a batch (the two CFG branches of a denoise step): element offsets of its q / k / V^T / o
+  Q += (int64_t)blockIdx.z * bs.q;
+  Kp += (int64_t)blockIdx.z * bs.k;
+  VTp += (int64_t)blockIdx.z * bs.vt;
+  O += (int64_t)blockIdx.z * bs.o;
   constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
   constexpr int DEPTH = 4;  // fragment prefetch depth (slots ahead of the consuming MFMA)
   const int tid = threadIdx.x;
@@ -629,15 +638,16 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
 
 template <int NW, int THR, bool PRESCALED>
 static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                          int H, float scale, hipStream_t st) {
-  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = (int64_t)AT_D * ldvt * 2;
+                          int H, float scale, hipStream_t st, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0}) {
+  // buffer ranges from a head's (and sequence's) first element: K rows of this sequence, the V^T blocks of its ceil(Sk/64) key tiles
+  const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = ((Sk + AT_KV - 1) / AT_KV) * (int64_t)AT_D * AT_KV * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
   auto kern = attn_fwd_v8_kernel<NW, THR, PRESCALED>;
   int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
   if (rc != X2V_OK) return rc;
-  dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H);
+  dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), 4 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
-                     (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb);
+                     (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb, bs);
   X2V_LAUNCH_CHECK("attn launch");
   return X2V_OK;
 }
@@ -667,6 +677,29 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
   hipStream_t st = (hipStream_t)stream;
   return (q_prescaled & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
                            : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
+}
+
+// B independent sequences in one launch (grid z): sequence b reads q / k / V^T and writes o at b * {q,k,vt,o}_bstride elements from the base
+// pointers; all share Sq, Sk, H and the strides.  With V^T laid out [H][ldvt/64][128][64] over the tokens of ALL sequences (x2v_gemm_bf16_vt on
+// the stacked rows), vt_bstride = rows_per_sequence * 128 and rows_per_sequence % 64 == 0.
+extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt_batched(const void* q, int64_t ldq, int64_t q_bstride, const void* k, int64_t ldk, int64_t k_bstride,
+                                                                                   const void* vt, int64_t ldvt, int64_t vt_bstride, void* o, int64_t ldo, int64_t o_bstride,
+                                                                                   int64_t Sq, int64_t Sk, int H, int B, int head_dim, float scale, int q_prescaled, void* stream) {
+  if (Sq == 0 && Sk > 0 && H > 0 && B > 0) return X2V_OK;
+  X2V_REQUIRE(q && k && vt && o, X2V_E_ARG, "attn_vt_batched: null pointer");
+  X2V_REQUIRE(head_dim == AT_D, X2V_E_SHAPE, "attn_vt_batched: head_dim=%d (only 128 is built)", head_dim);
+  X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535 && B > 0 && B <= 65535, X2V_E_SHAPE, "attn_vt_batched: bad shape Sq=%lld Sk=%lld H=%d B=%d", (long long)Sq, (long long)Sk, H, B);
+  X2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 64 == 0 && ldo % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(vt) && aligned16(o) && q_bstride % 8 == 0 &&
+                  k_bstride % 8 == 0 && vt_bstride % (64 * AT_D) == 0 && o_bstride % 8 == 0,
+              X2V_E_ALIGN, "attn_vt_batched: rows must be 16-byte aligned, ldvt a multiple of 64, vt_bstride whole 64-key blocks");
+  X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D && ldvt >= (B - 1) * (vt_bstride / AT_D) + Sk, X2V_E_SHAPE,
+              "attn_vt_batched: token stride smaller than H*128, or ldvt smaller than the stacked sequences");
+  X2V_REQUIRE((q_prescaled & ~1) == 0, X2V_E_ARG, "attn_vt_batched: q_prescaled must be 0 or 1");
+  if (scale <= 0.f) scale = 0.08838834764831845f;
+  const AttnBatch bs{q_bstride, k_bstride, vt_bstride, o_bstride};
+  hipStream_t st = (hipStream_t)stream;
+  return (q_prescaled & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, B, bs)
+                           : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, B, bs);
 }
 
 // variant: 0 = default (= 6); lazy-rescale threshold of the pipelined kernel: 4 = eager rescale (every tile), 5 = threshold 4, 6 = threshold 8

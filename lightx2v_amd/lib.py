@@ -47,6 +47,7 @@ PROTOTYPES = {
     "x2v_gemm_kernel_choice": [_i64, _i32, _i32, _i64, _i64, _i32],
     "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
     "x2v_transpose_heads_bf16": [_c_void_p, _i64, _c_void_p, _i64, _i64, _i32, _c_void_p],
+    "x2v_attn_fwd_bf16_vt_batched": [_c_void_p, _i64, _i64, _c_void_p, _i64, _i64, _c_void_p, _i64, _i64, _c_void_p, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
@@ -341,6 +342,29 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
         _lib.x2v_gemm_bf16_variant(_p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out2), out2.stride(0), M, N, K, epilogue, _p(r2), 0 if r2 is None else r2.stride(0), _p(gate), variant, _stream()),
         "gemm_bf16",
     )
+    return out2
+
+
+def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=None, prescaled=False, scale=0.0, all_rows_query=True):
+    """`batch` independent self-attentions in one launch (x2v_attn_fwd_bf16_vt_batched): q, k, out are [batch * rows_per_seq, H*128] row-major
+    (any token stride), sequence b in rows [b * rows_per_seq, b * rows_per_seq + seq_len); vt = V^T [H, batch * rows_per_seq / 64, 128, 64] over
+    the stacked rows (gemm_vt / transpose_heads of the stacked v; rows_per_seq % 64 == 0).  Keys are the first seq_len rows of a sequence's
+    slot; with all_rows_query (default) every row of the slot is a query, so every row of `out` is written (the padding rows of a stacked
+    activation buffer stay finite), else only the first seq_len."""
+    q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
+    rows = batch * rows_per_seq
+    if rows_per_seq % 64 or not 0 < seq_len <= rows_per_seq or q2.shape[0] != rows or k2.shape[0] != rows or min(q2.shape[1], k2.shape[1]) < num_heads * 128:
+        raise X2VError(f"attention_batched: q {tuple(q2.shape)} k {tuple(k2.shape)} do not hold {batch} sequences of {rows_per_seq} (multiple of 64) rows x {num_heads} heads")
+    if vt.dtype != torch.bfloat16 or not vt.is_cuda or not vt.is_contiguous() or tuple(vt.shape) != (num_heads, rows // 64, 128, 64):
+        raise X2VError(f"attention_batched: vt must be the contiguous bf16 [H, rows/64, 128, 64] tensor over the stacked rows, got {tuple(vt.shape)}")
+    out2 = torch.empty((rows, num_heads * 128), dtype=torch.bfloat16, device=q.device) if out is None else _row2d(_bf16(out, "out"), "out")
+    if out2.shape[0] != rows or out2.shape[1] < num_heads * 128:
+        raise X2VError(f"attention_batched: out is {tuple(out2.shape)}")
+    init()
+    _check(_lib.x2v_attn_fwd_bf16_vt_batched(_p(q2), q2.stride(0), rows_per_seq * q2.stride(0), _p(k2), k2.stride(0), rows_per_seq * k2.stride(0), _p(vt), rows, rows_per_seq * 128,
+                                             _p(out2), out2.stride(0), rows_per_seq * out2.stride(0), rows_per_seq if all_rows_query else seq_len, seq_len, num_heads, batch, 128,
+                                             scale, int(bool(prescaled)), _stream()),
+           "attn_fwd_vt_batched")
     return out2
 
 

@@ -261,6 +261,8 @@ class WanTransformerInfer:
         self.attn_time_hook = None  # bench.py: callable(kind) -> context manager timing the attention launch
         self.cache_cross_kv = bool(_cfg(config, "cache_cross_kv", True))
         self._cross_kv_cache = {}  # (id(block weights), id(context)) -> (context, version, k, v); see _cross_kv
+        # CFG pair mode (WanModel._forward_pair): x holds BOTH forwards of a step, [cond rows | pad | uncond rows | pad], (S, S_pad) here
+        self._pair = None
 
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler
@@ -315,6 +317,20 @@ class WanTransformerInfer:
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)  # K-blocked x
         # Ulysses, row-major form: v is projected first and its seq→head exchange runs on the communication stream under the q and k
         # projections and the norm+RoPE kernel
+        if self._pair is not None:
+            # both CFG forwards in one pass: projections and row kernels run on the stacked rows, the two self-attentions are one launch
+            S, Sp = self._pair
+            if not mmkw and hasattr(weights.self_attn_v, "apply_vt"):
+                vt = weights.self_attn_v.apply_vt(n1, self.num_heads)
+            else:
+                vt = lib.transpose_heads(weights.self_attn_v.apply(n1, **mmkw), self.num_heads)
+            q = weights.self_attn_q.apply(n1, **mmkw)
+            k = weights.self_attn_k.apply(n1, **mmkw)
+            for b in range(2):  # token b*Sp + i of either forward sits at grid position i
+                rows = slice(b * Sp, b * Sp + S)
+                lib.rmsnorm_rope_(q[rows], k[rows], weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
+            attn = self._timed("self", lambda: lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True))
+            return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
         if pa is None and fast and not mmkw and hasattr(weights.self_attn_v, "apply_vt"):
             v, vt = None, weights.self_attn_v.apply_vt(n1, self.num_heads)  # V^T from the v projection's epilogue (the attention kernel's operand)
         else:
@@ -344,6 +360,14 @@ class WanTransformerInfer:
         n3, mmkw = _ln_then_mm_input(weights.cross_attn_q, x, weights.norm3.weight, weights.norm3.bias, eps=weights.norm3.eps)
         q = weights.cross_attn_q.apply(n3, **mmkw)
         lib.rmsnorm(q, weights.cross_attn_norm_q.weight, weights.cross_attn_norm_q.eps, out=q, round_mode=self.round_mode)
+        if self._pair is not None:
+            S, Sp = self._pair
+            attn = torch.empty_like(q)
+            for b, ctx in enumerate(context):  # (conditional, unconditional) text contexts; every row of a forward's slot is a query
+                k, v, vt = self._cross_kv(weights, ctx)
+                rows = slice(b * Sp, (b + 1) * Sp)
+                self._timed("cross", lambda: lib.attention(q[rows], k, v, self.num_heads, self.head_dim, variant=lib.ATTN_FAST, vt=vt, out=attn[rows]))
+            return weights.cross_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=None)
         k, v, vt = self._cross_kv(weights, context)
         if vt is not None:
             attn = self._timed("cross", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=lib.ATTN_FAST, vt=vt))
@@ -469,11 +493,14 @@ class WanPostInfer:
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler
 
-    def infer(self, weights, x, e, grid_sizes):
+    def infer_rows(self, weights, x, e):
+        """LN + modulate + head Linear on token rows: [rows, D] -> [rows, 64] (post_infer.py:15-40)."""
         e = (weights.head_modulation.tensor + e.unsqueeze(1)).chunk(2, dim=1)  # [1,2,D] → shift, scale
         x = lib.layernorm(x, scale=e[1].squeeze(0), shift=e[0].squeeze(0), eps=weights.norm.eps)
-        x = weights.head.apply(x)
-        return [u.float() for u in self.unpatchify(x, grid_sizes)]
+        return weights.head.apply(x)
+
+    def infer(self, weights, x, e, grid_sizes):
+        return [u.float() for u in self.unpatchify(self.infer_rows(weights, x, e), grid_sizes)]
 
     def unpatchify(self, x, grid_sizes):
         c = self.out_dim
@@ -556,14 +583,48 @@ class WanModel:
         x = self.transformer_infer.infer(self.transformer_weights, grid_sizes, embed, *pre_infer_out)
         return self.post_infer.infer(self.post_weight, x, embed, grid_sizes)[0]
 
+    def _pair_ok(self, inputs):
+        """The two forwards of a CFG step as ONE pass over [cond tokens | uncond tokens] (config `cfg_pair`, default on): same latents, same
+        timestep, same weights — only the text context of the cross-attention differs — so every projection and row kernel runs on 2 S rows
+        (a 14B 720p projection fills 46.2 rounds of 256 CUs instead of 2 x 23.1 -> 2 x 24) and the two self-attentions are one launch
+        (92.5 rounds instead of 2 x 47).  Each output row is computed from the same operands in the same order as in the separate
+        forwards, so the result is bit-identical (tests/test_gpu_model.py).  Needs the plain single-GPU block driver in its fp32-statistics mode."""
+        tr = self.transformer_infer
+        return (bool(_cfg(self.config, "cfg_pair", True)) and type(tr) is WanTransformerInfer and tr.parallel_attention is None and tr.round_mode == lib.ROUND_FP32
+                and tr.attention_type == "hip_flash" and self.scheduler.latents.is_cuda)
+
+    def _forward_pair(self, inputs):
+        tr = self.transformer_infer
+        embed, grid_sizes, (x, embed0, seq_lens, freqs, ctx_c) = self.pre_infer.infer(self.pre_weight, inputs, positive=True)
+        S = x.shape[0]
+        if int(seq_lens[0]) != S:
+            return None  # token buffer padded beyond the grid: the separate forwards handle it
+        ctx_u = self.pre_infer._text_context(self.pre_weight, inputs["text_encoder_output"]["context_null"])
+        Sp = (S + 63) // 64 * 64  # a forward's slot: whole 64-token blocks of V^T
+        X = torch.empty((2 * Sp, x.shape[1]), dtype=x.dtype, device=x.device)
+        for b in range(2):
+            X[b * Sp : b * Sp + S].copy_(x)
+            X[b * Sp + S : (b + 1) * Sp].zero_()  # padding rows: zero in, finite throughout (every kernel writes all rows of its output)
+        tr._pair = (S, Sp)
+        try:
+            X = tr.infer(self.transformer_weights, grid_sizes, embed, X, embed0, seq_lens, freqs, (ctx_c, ctx_u))
+        finally:
+            tr._pair = None
+        rows = self.post_infer.infer_rows(self.post_weight, X, embed)
+        return tuple(self.post_infer.unpatchify(rows[b * Sp : b * Sp + S], grid_sizes)[0].float() for b in range(2))
+
     @torch.no_grad()
     def infer(self, inputs):
         """cond forward, uncond forward, fp32 CFG combine (model.py:197-226)."""
-        cond = self._forward(inputs, True)
-        if not self.config["enable_cfg"]:
-            self.scheduler.noise_pred = cond
-            return
-        uncond = self._forward(inputs, False)
+        pair = self._forward_pair(inputs) if (self.config["enable_cfg"] and self._pair_ok(inputs)) else None
+        if pair is not None:
+            cond, uncond = pair
+        else:
+            cond = self._forward(inputs, True)
+            if not self.config["enable_cfg"]:
+                self.scheduler.noise_pred = cond
+                return
+            uncond = self._forward(inputs, False)
         if hasattr(self.scheduler, "set_cfg_parts"):
             # our schedulers fold `uncond + guide * (cond - uncond)` (:218) into the fused step_post launch; reading
             # scheduler.noise_pred still yields the combined tensor

@@ -301,3 +301,23 @@ def test_hunyuan13b_width_blocks_vs_oracle(ref_rounding):
     tr = hy.HunyuanTransformerInfer(cfg)
     out, _ = tr.infer(tw, img.cuda(), txt.cuda(), vec.cuda(), cu, n_img + n_txt, (cos.cuda(), sin.cuda()))
     assert_rel(out, ref, 1e-2, f"Hunyuan-13B-width double+single block (ref_rounding={ref_rounding})")
+
+
+def test_batched_attention_equals_per_sequence_launches(lib):
+    """x2v_attn_fwd_bf16_vt_batched (grid z = sequence; the two CFG forwards of a step in one launch) against one x2v_attn_fwd_bf16_vt launch per
+    sequence: EQUAL on the valid rows, with a slot size that pads each sequence (2100 -> 2112 rows), V^T from the stacked v, strided q / k
+    views, and the padding rows of the output written (finite)."""
+    H, S, Sp, B = 3, 2100, 2112, 2
+    gen = torch.Generator().manual_seed(9)
+    qkv = dev(torch.randn(B * Sp, 3 * H * 128, generator=gen).to(torch.bfloat16))
+    q, k, v = qkv[:, : H * 128], qkv[:, H * 128 : 2 * H * 128], qkv[:, 2 * H * 128 :]
+    vt = lib.transpose_heads(v, H)  # over the stacked rows: [H, B*Sp/64, 128, 64]
+    out = torch.full((B * Sp, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lib.attention_batched(q, k, vt, H, B, Sp, S, out=out)
+    assert torch.isfinite(out.float()).all(), "padding rows of the output must be written"
+    for b in range(B):
+        rows = slice(b * Sp, b * Sp + S)
+        ref = lib.attention(q[rows], k[rows], v[rows], H, variant=lib.ATTN_FAST)
+        assert torch.equal(out[rows], ref), f"sequence {b}: max |d| = {(out[rows].float() - ref.float()).abs().max().item():.3e}"
+    o2 = lib.attention_batched(q, k, vt, H, B, Sp, S, all_rows_query=False)
+    assert torch.equal(o2[:S], out[:S]) and torch.equal(o2[Sp : Sp + S], out[Sp : Sp + S])

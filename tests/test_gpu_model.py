@@ -286,3 +286,39 @@ def test_baseline_config1_full_run_vs_oracle():
     assert len(got_steps) == len(ref_steps) == steps
     assert_rel(got_steps[0], ref_steps[0], 3e-2, "config #1: latents after step 1")
     assert_rel(got_steps[-1], ref, 5e-2, "config #1: final latents after 4 CFG steps")
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_cfg_pair_pass_is_bit_identical_to_separate_forwards(fp8):
+    """WanModel.infer runs the conditional and unconditional forwards of a CFG step as ONE pass over [cond tokens | uncond tokens]
+    (config `cfg_pair`, default on; wan/model.py:197-226 runs them one after the other): every output row is computed from the same operands
+    in the same order, so noise predictions and latents over a denoise loop must be EQUAL to the separate-forward path — token counts that
+    are / are not multiples of 64 (padding rows inside the stacked buffer), bf16 and fp8 operators."""
+    from lightx2v_amd import scheduler, synth, wan
+
+    dims = synth.WAN_DIMS["wan-tiny"]
+    wd = _to_dev(synth.synth_wan_weights(dims, seed=1))
+    extra = {"mm_config": {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}} if fp8 else {}
+    for ts, frames in (((16, 3, 12, 10), 9), ((16, 2, 16, 16), 5)):  # 90 tokens (pad to 128) / 128 tokens
+        lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+        inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+        outs = {}
+        for pair in (True, False):
+            cfg = wan.default_config(dims, target_shape=ts, target_video_length=frames, infer_steps=3, cfg_pair=pair, **extra)
+            model = wan.WanModel(cfg, wd)
+            sch = scheduler.WanScheduler(cfg, device="cuda")
+            sch.prepare(latents=lat)
+            model.set_scheduler(sch)
+            assert model._pair_ok(inputs) == pair
+            sch.step_pre(0)
+            model.infer(inputs)
+            pred = sch.noise_pred.float().clone()
+            sch.step_post()
+            for i in (1, 2):
+                sch.step_pre(i)
+                model.infer(inputs)
+                sch.step_post()
+            outs[pair] = (pred, sch.latents.float().clone())
+        assert torch.isfinite(outs[True][1]).all()
+        assert torch.equal(outs[True][0], outs[False][0]), f"noise prediction differs: max |d| = {(outs[True][0] - outs[False][0]).abs().max().item():.3e}"
+        assert torch.equal(outs[True][1], outs[False][1]), "latents after 3 steps differ"
