@@ -238,7 +238,7 @@ def main():
         extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
     cfg = wan.default_config(
         dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
-        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=not args.no_cfg_pair, **extra,
+        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=(False if args.no_cfg_pair else "auto"), **extra,
     )
     if world > 1 and dims["num_heads"] % world != 0:
         raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")

@@ -345,12 +345,16 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
     return out2
 
 
-def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=None, prescaled=False, scale=0.0, all_rows_query=True):
-    """`batch` independent self-attentions in one launch (x2v_attn_fwd_bf16_vt_batched): q, k, out are [batch * rows_per_seq, H*128] row-major
-    (any token stride), sequence b in rows [b * rows_per_seq, b * rows_per_seq + seq_len); vt = V^T [H, batch * rows_per_seq / 64, 128, 64] over
-    the stacked rows (gemm_vt / transpose_heads of the stacked v; rows_per_seq % 64 == 0).  Keys are the first seq_len rows of a sequence's
-    slot; with all_rows_query (default) every row of the slot is a query, so every row of `out` is written (the padding rows of a stacked
-    activation buffer stay finite), else only the first seq_len."""
+def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=None, prescaled=False, scale=0.0, all_rows_query=True, one_launch=None, timed=None):
+    """`batch` independent self-attentions over stacked rows (x2v_attn_fwd_bf16_vt_batched): q, k, out are [batch * rows_per_seq, H*128]
+    row-major (any token stride), sequence b in rows [b * rows_per_seq, b * rows_per_seq + seq_len); vt = V^T [H, batch * rows_per_seq / 64,
+    128, 64] over the stacked rows (gemm_vt / transpose_heads of the stacked v; rows_per_seq % 64 == 0).  Keys are the first seq_len rows of
+    a sequence's slot; with all_rows_query (default) every row of the slot is a query, so every row of `out` is written (the padding rows
+    of a stacked activation buffer stay finite), else only the first seq_len.
+    one_launch: True = all sequences in one launch (grid z), False = one launch per sequence, None = by size — measured on MI355X: one
+    launch wins when a sequence alone already fills the chip many times over (Wan-14B 720p, 11 840 workgroups each: -0.85 %), and loses
+    when it does not (Wan-1.3B 480p, 960 workgroups each: +2 %, the two sequences' K/V share the L2s).  Same results either way.
+    timed: optional callable(fn) that runs fn() — called once per kernel launch (bench.py's per-launch HIP-event timer)."""
     q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
     rows = batch * rows_per_seq
     if rows_per_seq % 64 or not 0 < seq_len <= rows_per_seq or q2.shape[0] != rows or k2.shape[0] != rows or min(q2.shape[1], k2.shape[1]) < num_heads * 128:
@@ -361,10 +365,17 @@ def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=Non
     if out2.shape[0] != rows or out2.shape[1] < num_heads * 128:
         raise X2VError(f"attention_batched: out is {tuple(out2.shape)}")
     init()
-    _check(_lib.x2v_attn_fwd_bf16_vt_batched(_p(q2), q2.stride(0), rows_per_seq * q2.stride(0), _p(k2), k2.stride(0), rows_per_seq * k2.stride(0), _p(vt), rows, rows_per_seq * 128,
-                                             _p(out2), out2.stride(0), rows_per_seq * out2.stride(0), rows_per_seq if all_rows_query else seq_len, seq_len, num_heads, batch, 128,
-                                             scale, int(bool(prescaled)), _stream()),
-           "attn_fwd_vt_batched")
+    sq = rows_per_seq if all_rows_query else seq_len
+    if one_launch is None:
+        one_launch = ((sq + 255) // 256) * num_heads >= 4096
+    qb, kb, ob, vb = rows_per_seq * q2.stride(0), rows_per_seq * k2.stride(0), rows_per_seq * out2.stride(0), rows_per_seq * 128
+    for b0, nb in ([(0, batch)] if one_launch else [(b, 1) for b in range(batch)]):
+        def launch(b0=b0, nb=nb):
+            _check(_lib.x2v_attn_fwd_bf16_vt_batched(q2.data_ptr() + 2 * b0 * qb, q2.stride(0), qb, k2.data_ptr() + 2 * b0 * kb, k2.stride(0), kb, vt.data_ptr() + 2 * b0 * vb, rows,
+                                                     vb, out2.data_ptr() + 2 * b0 * ob, out2.stride(0), ob, sq, seq_len, num_heads, nb, 128, scale, int(bool(prescaled)), _stream()),
+                   "attn_fwd_vt_batched")
+
+        timed(launch) if timed is not None else launch()
     return out2
 
 

@@ -329,7 +329,7 @@ class WanTransformerInfer:
             for b in range(2):  # token b*Sp + i of either forward sits at grid position i
                 rows = slice(b * Sp, b * Sp + S)
                 lib.rmsnorm_rope_(q[rows], k[rows], weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
-            attn = self._timed("self", lambda: lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True))
+            attn = lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True, timed=lambda fn: self._timed("self", fn))
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
         if pa is None and fast and not mmkw and hasattr(weights.self_attn_v, "apply_vt"):
             v, vt = None, weights.self_attn_v.apply_vt(n1, self.num_heads)  # V^T from the v projection's epilogue (the attention kernel's operand)
@@ -584,13 +584,18 @@ class WanModel:
         return self.post_infer.infer(self.post_weight, x, embed, grid_sizes)[0]
 
     def _pair_ok(self, inputs):
-        """The two forwards of a CFG step as ONE pass over [cond tokens | uncond tokens] (config `cfg_pair`, default on): same latents, same
+        """The two forwards of a CFG step as ONE pass over [cond tokens | uncond tokens] (config `cfg_pair`: True / False / "auto" = by size, the default): same latents, same
         timestep, same weights — only the text context of the cross-attention differs — so every projection and row kernel runs on 2 S rows
         (a 14B 720p projection fills 46.2 rounds of 256 CUs instead of 2 x 23.1 -> 2 x 24) and the two self-attentions are one launch
         (92.5 rounds instead of 2 x 47).  Each output row is computed from the same operands in the same order as in the separate
         forwards, so the result is bit-identical (tests/test_gpu_model.py).  Needs the plain single-GPU block driver in its fp32-statistics mode."""
         tr = self.transformer_infer
-        return (bool(_cfg(self.config, "cfg_pair", True)) and type(tr) is WanTransformerInfer and tr.parallel_attention is None and tr.round_mode == lib.ROUND_FP32
+        want = _cfg(self.config, "cfg_pair", "auto")
+        if want == "auto":
+            # measured on MI355X: -0.8 % of a Wan-14B 720p step (11 840 attention workgroups per forward), +1 % of a Wan-1.3B 480p step (960):
+            # pair only when one forward's self-attention already fills the chip many times over (lib.attention_batched's rule)
+            want = ((self.scheduler.seq_len + 255) // 256) * tr.num_heads >= 4096
+        return (bool(want) and type(tr) is WanTransformerInfer and tr.parallel_attention is None and tr.round_mode == lib.ROUND_FP32
                 and tr.attention_type == "hip_flash" and self.scheduler.latents.is_cuda)
 
     def _forward_pair(self, inputs):

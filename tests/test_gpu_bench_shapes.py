@@ -313,8 +313,10 @@ def test_batched_attention_equals_per_sequence_launches(lib):
     q, k, v = qkv[:, : H * 128], qkv[:, H * 128 : 2 * H * 128], qkv[:, 2 * H * 128 :]
     vt = lib.transpose_heads(v, H)  # over the stacked rows: [H, B*Sp/64, 128, 64]
     out = torch.full((B * Sp, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
-    lib.attention_batched(q, k, vt, H, B, Sp, S, out=out)
+    lib.attention_batched(q, k, vt, H, B, Sp, S, out=out, one_launch=True)
     assert torch.isfinite(out.float()).all(), "padding rows of the output must be written"
+    for mode in (False, None):  # one launch per sequence on the stacked buffers / the size rule: same bits
+        assert torch.equal(lib.attention_batched(q, k, vt, H, B, Sp, S, one_launch=mode), out)
     for b in range(B):
         rows = slice(b * Sp, b * Sp + S)
         ref = lib.attention(q[rows], k[rows], v[rows], H, variant=lib.ATTN_FAST)

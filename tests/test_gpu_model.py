@@ -309,7 +309,7 @@ def test_cfg_pair_pass_is_bit_identical_to_separate_forwards(fp8):
             sch = scheduler.WanScheduler(cfg, device="cuda")
             sch.prepare(latents=lat)
             model.set_scheduler(sch)
-            assert model._pair_ok(inputs) == pair
+            assert model._pair_ok(inputs) == pair  # forced either way here; the default ("auto") decides by size
             sch.step_pre(0)
             model.infer(inputs)
             pred = sch.noise_pred.float().clone()
