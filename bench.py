@@ -17,7 +17,7 @@ N > 1 shards the SAME video across ranks (strong scaling).
 Output: ONE JSON line on rank 0.  value = video frames/sec = frames / (infer_steps x step latency), denoise
 loop only (VAE decode excluded).  `roofline` is for the dominant kernel (self-attention forward:
 72 % of the step's FLOPs at 720p); `cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on this box's host cores:
-BASELINE config #1 in full (the reference's own CPU-runnable case), plus a FLOP-scaled estimate for the benched workload.
+one block of the BENCHED workload at its full sequence length on a bounded row sample (value), plus BASELINE config #1 end to end beside it.
 """
 import argparse
 import contextlib
@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--infer-steps", type=int, default=50, help="length of the full denoise schedule (frames/sec denominator)")
     ap.add_argument("--no-cfg", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=4.0, help="budget of the FLOP-scaled block sample (the config #1 leg runs in full)")
+    ap.add_argument("--cpu-baseline-rows", type=int, default=256, help="query rows of the benched block the CPU baseline evaluates (scaled by S / rows)")
+    ap.add_argument("--no-cpu-config1", action="store_true", help="skip the end-to-end CPU run of BASELINE config #1 beside the baseline (~80 s on 128 threads)")
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
     ap.add_argument("--no-cfg-pair", action="store_true", help="run the conditional and unconditional forwards of a step separately (default: one pass over both)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
@@ -90,16 +91,52 @@ class AttnTimer:
         return len(self.pairs[kind])
 
 
-def cpu_baseline(dims, S_full, text_len, frames, infer_steps, cfg_forwards, budget_s):
+def cpu_baseline(dims, S_full, ts, text_len, frames, infer_steps, cfg_forwards, n_rows, with_config1=True):
     """The reference's CPU path (oracle/wan_oracle.py: torch bf16 addmm + torch_sdpa + the UniPC scheduler, pinned bit-exactly to the
-    reference) timed on this box's host cores.  Primary leg = BASELINE config #1 IN FULL, end to end: Wan2.1-T2V-1.3B, 256x256x17f
-    (S = 1280 tokens), 30 layers, 4 steps with CFG (8 forwards) + scheduler — no extrapolation.  Second field = one block of the benched
-    architecture at S = 1024 for a few seconds, scaled to the benched step by algorithmic FLOPs (an UNDER-estimate: attention is
-    quadratic in S).  Baseline only — never the thing shipped."""
+    reference) timed on this box's host cores.
+
+    `value` = the BENCHED workload (same architecture, same token count): ONE block at the full sequence length evaluated on a bounded
+    row sample — the part of the block that needs all rows (norm1 + modulate, k / v projections, norm_k, RoPE(k): `all_rows_s`) runs
+    in full, everything row-wise (q, the attention of the sampled queries against ALL keys, cross-attention, projections, FFN) on
+    `n_rows` rows and is scaled by S / n_rows; step = layers x cfg forwards x block.  No FLOP-ratio extrapolation across sequence
+    lengths (attention is quadratic in S).  `config1_full_run` = BASELINE config #1 (the reference's own CPU-runnable case: Wan2.1-1.3B,
+    256x256x17f, 4 CFG steps) run end to end, reported beside it — a DIFFERENT workload, never to be divided into `value`.
+    Baseline only — never the thing shipped."""
     from lightx2v_amd import synth
     from oracle import wan_oracle as O
 
     threads = torch.get_num_threads()
+    dd = dict(dims, num_layers=1)
+    wd = synth.synth_wan_weights(dd, seed=1)
+    g = torch.Generator().manual_seed(0)
+    grid = (ts[1], ts[2] // 2, ts[3] // 2)
+    x = torch.randn(S_full, dims["dim"], generator=g).to(torch.bfloat16)
+    embed0 = (torch.randn(6, dims["dim"], generator=g) * 0.1).to(torch.bfloat16)
+    context = torch.randn(text_len, dims["dim"], generator=g).to(torch.bfloat16)
+    rows = torch.randperm(S_full, generator=g)[:n_rows]
+    freqs = O.rope_freqs_table(128)
+    tm = {}
+    t0 = time.perf_counter()
+    O.wan_block_rows(wd, 0, dd, grid, x, embed0, freqs, context, rows, timing=tm)
+    sample_s = time.perf_counter() - t0
+    block_s = tm["all_rows_s"] + tm["sampled_rows_s"] * S_full / n_rows
+    step_s = block_s * dims["num_layers"] * cfg_forwards
+    flop_step, _ = step_flops(dims, S_full, text_len, cfg_forwards, cross_kv_cached=False)
+    out = {
+        "value": frames / (infer_steps * step_s),
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "ms_per_step_est": step_s * 1e3,
+        "tflops_per_s": flop_step / step_s / 1e12,
+        "sample": f"oracle (reference CPU path restated, pinned bit-exactly to the reference; the unmodified reference is absent on this box): one "
+        f"{dims['dim']}d/{dims['num_heads']}h block at the benched S={S_full}: all-rows part (norm1, k/v projections, norm_k, RoPE) in full {tm['all_rows_s']:.1f} s + "
+        f"{n_rows} sampled rows of the row-wise part (q, self-attention vs all {S_full} keys, cross-attention, o, FFN) {tm['sampled_rows_s']:.1f} s x {S_full}/{n_rows}; "
+        f"step = {dims['num_layers']} layers x {cfg_forwards} forwards x {block_s:.0f} s; {sample_s:.0f} s of CPU work on {threads} threads",
+    }
+    del wd, x
+    if not with_config1:
+        return out
     d1 = synth.WAN_DIMS["wan2.1-1.3b"]
     wl1 = synth.WORKLOADS["wan1.3b_256x256x17f"]
     wd = synth.synth_wan_weights(d1, seed=0)
@@ -109,45 +146,13 @@ def cpu_baseline(dims, S_full, text_len, frames, infer_steps, cfg_forwards, budg
     O.denoise_loop(wd, d1, lat, ctx, ctx_null, 4, 8.0, 6.0, step_callback=lambda i, x: step_t.append(time.perf_counter()))
     total = time.perf_counter() - t0
     per_step = [b - a for a, b in zip([t0] + step_t[:-1], step_t)]
-    flop1, _ = step_flops(d1, synth.seq_len_of(wl1["target_shape"]), d1["text_len"], 2)
-    out = {
-        "value": wl1["frames"] / total,
-        "unit": "frames/s",
-        "cores": threads,
-        "kind": "port",
-        "workload": "BASELINE config #1: Wan2.1-T2V-1.3B bf16, 256x256x17f (1280 tokens), 4 steps, CFG",
+    flop1, _ = step_flops(d1, synth.seq_len_of(wl1["target_shape"]), d1["text_len"], 2, cross_kv_cached=False)
+    out["config1_full_run"] = {
+        "workload": "BASELINE config #1: Wan2.1-T2V-1.3B bf16, 256x256x17f (1280 tokens), 4 steps, CFG — a different workload than `value`",
+        "frames_per_s": wl1["frames"] / total,
         "total_s": total,
         "ms_per_step": [round(x * 1e3, 1) for x in per_step],
         "tflops_per_s": flop1 * 4 / total / 1e12,
-        "sample": f"oracle denoise_loop (reference CPU path restated, pinned bit-exactly: torch bf16 addmm + torch_sdpa + UniPC), config #1 in full: "
-        f"4 CFG steps of the 30-layer 1.3B model at S=1280 in {total:.1f} s on {threads} threads = {wl1['frames'] / total:.3f} frames/s",
-    }
-    del wd
-    # second field: one block of the benched architecture, scaled by FLOPs
-    dd = dict(dims, num_layers=1)
-    wd = synth.synth_wan_weights(dd, seed=1)
-    S_s, grid = 1024, (4, 16, 16)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(S_s, dims["dim"], generator=g).to(torch.bfloat16)
-    embed0 = (torch.randn(6, dims["dim"], generator=g) * 0.1).to(torch.bfloat16)
-    context = torch.randn(text_len, dims["dim"], generator=g).to(torch.bfloat16)
-    freqs = O.rope_freqs_table(128)
-    O.wan_block(wd, 0, dd, grid, x.clone(), embed0, freqs, context)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.wan_block(wd, 0, dd, grid, x.clone(), embed0, freqs, context)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 200:
-            break
-    flop_sample, _ = step_flops(dd, S_s, text_len, 1, cross_kv_cached=False)
-    flop_step, _ = step_flops(dims, S_full, text_len, cfg_forwards)
-    est = el / n * flop_step / flop_sample
-    out["benched_workload_estimate"] = {
-        "ms_per_step_est": est * 1e3,
-        "frames_per_s_est": frames / (infer_steps * est),
-        "sample": f"1 block of {dims['dim']}d/{dims['num_heads']}h at S={S_s}, {n} reps in {el:.1f} s ({el / n * 1e3:.0f} ms/block, {flop_sample / (el / n) / 1e12:.2f} TFLOP/s), "
-        f"scaled x{flop_step / flop_sample:.0f} by algorithmic FLOPs (under-estimates: attention is quadratic in S)",
     }
     return out
 
@@ -164,28 +169,33 @@ def ulysses_self_check(dist, world, rank):
     wd = synth.synth_wan_weights(dims, seed=3, device="cuda", gen_device="cuda")
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
-    def one(pat):
+    def one(pat, blocked=True, split=True):
         cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=pat)
         model = wan.WanModel(cfg, wd)
+        if pat is not None:  # per-INSTANCE settings (the timed model gets the same ones from main)
+            model.transformer_infer.blocked_exchange = blocked
+            model.transformer_infer.parallel_attention.split_head2seq = split
         sch = scheduler.WanScheduler(cfg, device="cuda")
         sch.prepare(latents=lat)
         model.set_scheduler(sch)
         sch.step_pre(0)
         model.infer(inputs)
         torch.cuda.synchronize()
-        return sch.noise_pred.float()
+        return sch.noise_pred.float(), (model.transformer_infer.parallel_attention.split_head2seq if pat is not None else None)
 
-    outs = [one(None)]
-    # The designed exchange path first; if this PyTorch/RCCL build rejects one of its collective forms (argument errors are raised on every
-    # rank alike, before anything is sent) the simpler forms are tried, and the one that ran is named in the JSON line.
-    path, errors = None, []
-    for name, blocked, halves in (("blocked buffers, head->seq in two overlapped halves", True, True), ("blocked buffers, one head->seq exchange", True, False),
+    outs = [one(None)[0]]
+    # The designed exchange path first (ulysses.py itself probes the split-size collective form once and falls back to a single head->seq
+    # exchange); should this PyTorch/RCCL build still reject a form (argument errors are raised on every rank alike, before anything is
+    # sent), the simpler paths are tried, and the one that ran is named in the JSON line and used for the timed model.
+    path, errors, settings = None, [], None
+    for name, blocked, halves in (("blocked buffers, head->seq in two overlapped pieces", True, True), ("blocked buffers, one head->seq exchange", True, False),
                                   ("row-major exchange (reference form, transposing copies)", False, False)):
-        wan.WanTransformerInfer.blocked_exchange = blocked
-        ulysses.UlyssesAttention.split_head2seq_default = halves
         try:
-            outs.append(one("ulysses"))
-            path = name
+            o, split_used = one("ulysses", blocked, halves)
+            outs.append(o)
+            if blocked and halves and not split_used:
+                name = "blocked buffers, one head->seq exchange (split-size collective form rejected by the probe)"
+            path, settings = name, {"blocked_exchange": blocked, "split_head2seq": bool(split_used) if blocked else False}
             break
         except Exception as e:  # noqa: BLE001
             errors.append(f"{name}: {type(e).__name__}: {str(e)[:200]}")
@@ -199,16 +209,15 @@ def ulysses_self_check(dist, world, rank):
     ok = bool(worst.item() < 5e-3)
     if not ok:
         raise SystemExit(f"bench: Ulysses self-check failed on rank {rank}: relative L2 {rel.item():.3e} (worst {worst.item():.3e})")
-    return {"ranks": world, "worst_rel_l2": worst.item(), "tolerance": 5e-3, "passed": ok, "exchange_path": path, "rejected_paths": errors}
+    return {"ranks": world, "worst_rel_l2": worst.item(), "tolerance": 5e-3, "passed": ok, "exchange_path": path, "rejected_paths": errors, "settings": settings}
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    from lightx2v_amd import launch
+
+    # bare `python bench.py --gpus N` re-runs itself as N ranks under torch.distributed.run (lightx2v_amd/launch.py)
+    world, rank, local_rank = launch.ranks(__file__, args.gpus)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -270,6 +279,8 @@ def main():
     sp_check = None
     if world > 1:
         sp_check = ulysses_self_check(dist, world, rank)
+        model.transformer_infer.blocked_exchange = sp_check["settings"]["blocked_exchange"]
+        model.transformer_infer.parallel_attention.split_head2seq = sp_check["settings"]["split_head2seq"]
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -375,7 +386,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, S, dims["text_len"], wl["frames"], args.infer_steps, fwd, args.cpu_baseline_seconds)
+            out["cpu_baseline"] = cpu_baseline(dims, S, ts, dims["text_len"], wl["frames"], args.infer_steps, fwd, args.cpu_baseline_rows, not args.no_cpu_config1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
 struct AttnBatch {
   int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
+  int xcd_remap;        // 1: XCD-aware (sequence, head, query block) -> workgroup mapping (see the kernel), 0: the grid as dispatched
 };
 
 template <int NW, int RESCALE_THR, bool PRESCALED>
@@ -332,19 +333,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
                                                                    unsigned v_bytes, AttnBatch bs) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // blockIdx.z = independent sequence of a batch (the two CFG branches of a denoise step): element offsets of its q / k / V^T / o
-  Q += (int64_t)blockIdx.z * bs.q;
-  Kp += (int64_t)blockIdx.z * bs.k;
-  VTp += (int64_t)blockIdx.z * bs.vt;
-  O += (int64_t)blockIdx.z * bs.o;
+  // Work mapping.  The launch grid is (query blocks, heads, sequences) and the dispatcher hands workgroup number
+  // L = x + gx (y + gy z) to XCD L % 8 (observed placement; a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch").  Taken
+  // as it comes, the 64 workgroups resident on an XCD (32 CUs x 2) belong to ~2 heads and every head's K / V^T stream (38.7 MB at 720p)
+  // is pulled through all eight 4 MiB L2s: rocprofv3 showed 99 GB of L2<->fabric traffic per launch against 3.1 GB algorithmic
+  // (profiles/r02_pmc_attn_*).  XCD-aware form: XCD c owns the contiguous range c of the (sequence, head, query block) list (bijective
+  // for any count), so its resident workgroups are consecutive query blocks of ONE head that walk the same K / V^T tiles at about the same
+  // time — a tile is filled into that L2 once per generation of workgroups instead of once per drifting pair of heads.
+  int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  if (bs.xcd_remap) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nwg = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = L & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    qblk = (int)(id % gx);
+    const unsigned hz = id / gx;
+    head = (int)(hz % gy);
+    seq = (int)(hz / gy);
+  }
+  // seq = independent sequence of a batch (the two CFG branches of a denoise step): element offsets of its q / k / V^T / o
+  Q += (int64_t)seq * bs.q;
+  Kp += (int64_t)seq * bs.k;
+  VTp += (int64_t)seq * bs.vt;
+  O += (int64_t)seq * bs.o;
   constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
   constexpr int DEPTH = 4;  // fragment prefetch depth (slots ahead of the consuming MFMA)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fl = lane & 31, hi = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t q0 = (int64_t)blockIdx.x * (NW * 32) + wid * 32;
+  const int64_t q0 = (int64_t)qblk * (NW * 32) + wid * 32;
   const unsigned short* Kh = Kp + (int64_t)head * AT_D;
   const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;
 
@@ -638,7 +657,7 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
 
 template <int NW, int THR, bool PRESCALED>
 static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                          int H, float scale, hipStream_t st, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0}) {
+                          int H, float scale, hipStream_t st, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0, 0}) {
   // buffer ranges from a head's (and sequence's) first element: K rows of this sequence, the V^T blocks of its ceil(Sk/64) key tiles
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = ((Sk + AT_KV - 1) / AT_KV) * (int64_t)AT_D * AT_KV * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
@@ -646,6 +665,10 @@ static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk
   int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
   if (rc != X2V_OK) return rc;
   dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
+  // XCD-aware mapping once every XCD has more than a residency's worth of workgroups (below that the plain grid spreads a head's few
+  // query blocks over all L2s, which is what a small launch wants); X2V_ATTN_XCD=0/1 forces it (A/B runs)
+  static const int xcd_env = [] { const char* e = getenv("X2V_ATTN_XCD"); return e ? atoi(e) : -1; }();
+  bs.xcd_remap = xcd_env >= 0 ? (xcd_env != 0) : ((uint64_t)grid.x * grid.y * grid.z >= 2048);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), 4 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
                      (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb, bs);
   X2V_LAUNCH_CHECK("attn launch");
@@ -696,7 +719,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt_batch
               "attn_vt_batched: token stride smaller than H*128, or ldvt smaller than the stacked sequences");
   X2V_REQUIRE((q_prescaled & ~1) == 0, X2V_E_ARG, "attn_vt_batched: q_prescaled must be 0 or 1");
   if (scale <= 0.f) scale = 0.08838834764831845f;
-  const AttnBatch bs{q_bstride, k_bstride, vt_bstride, o_bstride};
+  const AttnBatch bs{q_bstride, k_bstride, vt_bstride, o_bstride, 0};
   hipStream_t st = (hipStream_t)stream;
   return (q_prescaled & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, B, bs)
                            : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, B, bs);

@@ -261,25 +261,29 @@ class LNWeightHip(_Movable):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-_CU_CACHE = {}
+_CU_CACHE = {}  # id(tensor) -> (tensor, version, boundaries); entries PIN their tensor
 
 
 def _segments(cu):
-    """cu_seqlens (int tensor on any device, list, or None) → python list of boundaries.  A device tensor costs one host read; the
-    boundaries are cached per (data_ptr, version, length) because the block loop passes the same tensor to every layer."""
+    """cu_seqlens (int tensor on any device, list, or None) → python list of boundaries.  A device tensor costs one host read.  The fused
+    block loop hands the SAME tensor object to every layer, so the boundaries are cached per tensor object: an entry holds a reference to
+    its tensor (so neither its id nor its storage address can be recycled by the caching allocator while the entry lives) and is valid only
+    for that very object at the same version counter.  A caller that builds fresh cu tensors per call (the reference's op-by-op loop,
+    wan/infer/transformer_infer.py:73-77) always misses and pays the 8-byte read — never a stale hit.  At most 8 tensors are pinned."""
     if cu is None:
         return None
     if not torch.is_tensor(cu):
         return [int(c) for c in cu]
     if not cu.is_cuda:
         return cu.tolist()
-    key = (cu.data_ptr(), cu._version, cu.numel())
-    hit = _CU_CACHE.get(key)
-    if hit is None:
-        if len(_CU_CACHE) > 64:
-            _CU_CACHE.clear()
-        hit = _CU_CACHE[key] = cu.tolist()
-    return hit
+    hit = _CU_CACHE.get(id(cu))
+    if hit is not None and hit[0] is cu and hit[1] == cu._version:
+        return hit[2]
+    while len(_CU_CACHE) >= 8:
+        _CU_CACHE.pop(next(iter(_CU_CACHE)))
+    bounds = cu.tolist()
+    _CU_CACHE[id(cu)] = (cu, cu._version, bounds)
+    return bounds
 
 
 def hip_flash(q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, model_cls=None, variant=0):

@@ -51,6 +51,60 @@ def head2seq(x, group=None):
     return recv.transpose(0, 1).reshape(s // n, n * hdn)  # one gather-copy into token-major layout
 
 
+def _split_plan(n, r, rows_per_rank, split):
+    """head->seq pieces of an attention output o [N * rows_per_rank, hd/N] (row block j goes to rank j): a list of
+    (destination ranks [j0, j1), send row range, in_split, out_split, recv row range of the [N * rows_per_rank] receive view).
+    split False: one equal exchange.  True: two pieces by destination rank ([0, N/2) and [N/2, N)), the first flying under the attention
+    of the second piece's query rows; a rank outside a piece's destinations receives nothing in it (zero-row receive view).
+    "force" (tests, world size 1): the self-exchange cut in two row pieces, so that RCCL sees the split-size call signature of the
+    N-GPU run on a one-GPU box."""
+    S = n * rows_per_rank
+    if n == 1 and split == "force":
+        h = rows_per_rank // 2
+        return [((0, 1), slice(0, h), [h], [h], slice(0, h)), ((0, 1), slice(h, S), [S - h], [S - h], slice(h, S))]
+    if n < 2 or not split:
+        return [((0, n), slice(0, S), None, None, slice(0, S))]
+    plan = []
+    for j0, j1 in ((0, n // 2), (n // 2, n)):
+        mine = j0 <= r < j1
+        plan.append(((j0, j1), slice(j0 * rows_per_rank, j1 * rows_per_rank), [rows_per_rank if j0 <= j < j1 else 0 for j in range(n)],
+                     [rows_per_rank if mine else 0] * n, slice(0, S) if mine else slice(0, 0)))
+    return plan
+
+
+_SPLIT_PROBED = {}
+
+
+def split_form_ok(group, device):
+    """Does this PyTorch / RCCL build take the split-size `all_to_all_single` with a zero-row receive view (the two-piece head->seq
+    exchange)?  Probed ONCE per (group, device) on a few rows, every rank running the same calls; a rank-local failure (argument checks
+    raise before anything is sent) is agreed on with a MIN all-reduce so that all ranks take the same path afterwards.  X2V_ULYSSES_SPLIT=0/1
+    skips the probe.  ADVICE r2: the fallback lives here, next to the collective, not only in bench.py."""
+    import os
+
+    env = os.environ.get("X2V_ULYSSES_SPLIT")
+    if env is not None:
+        return env != "0"
+    key = (id(group), str(device))
+    if key not in _SPLIT_PROBED:
+        n, r = _world(group)
+        ok = 1
+        try:
+            o = torch.zeros((n * 4, 8), dtype=torch.bfloat16, device=device)
+            ro = torch.zeros_like(o)
+            for _, rows, in_split, out_split, rrows in _split_plan(n, r, 4, True if n > 1 else "force"):
+                dist.all_to_all_single(ro[rrows], o[rows], out_split, in_split, group=group)
+            if o.is_cuda:
+                torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"lightx2v_amd.ulysses: split-size all_to_all_single rejected on rank {r} ({type(e).__name__}: {str(e)[:160]}); using one head->seq exchange", flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        _SPLIT_PROBED[key] = bool(flag.item())
+    return _SPLIT_PROBED[key]
+
+
 class UlyssesAttention:
     """Callable injected as `transformer_infer.parallel_attention` (reference hook: transformer_infer.py:381-388)."""
 
@@ -130,10 +184,12 @@ class UlyssesAttention:
         o = bufs["o"].view(S, hdn)
         fast = self._default_attn and (variant & 0xFF) == lib.ATTN_FAST
         vt = lib.transpose_heads(vh, hl) if fast else None  # the ping-pong kernel reads V^T (1/N of the single-GPU transposition)
-        # head->seq in two halves by destination rank: rows [0, split) of o go to ranks [0, N/2), the rest to ranks [N/2, N)
-        halves = [(0, n)] if n < 2 or not self.split_head2seq else [(0, n // 2), (n // 2, n)]
-        for (j0, j1) in halves:
-            rows = slice(j0 * s_local, j1 * s_local)
+        # head->seq in two pieces by destination rank: rows of ranks [0, N/2) first, exchanged under the attention of the second piece
+        split = self.split_head2seq
+        if split is True and not split_form_ok(self.group, o.device):
+            split = self.split_head2seq = False
+        ro = bufs["ro"].view(S, hdn)
+        for _, rows, in_split, out_split, rrows in _split_plan(n, r, s_local, split):
 
             def fn(rows=rows):
                 if fast:
@@ -144,16 +200,12 @@ class UlyssesAttention:
                 return o[rows]
 
             timer("self", fn) if timer is not None else fn()
-            in_split = [s_local if j0 <= j < j1 else 0 for j in range(n)]
-            mine = j0 <= r < j1
-            out_split = [s_local if mine else 0] * n
-            recv = bufs["ro"].view(S, hdn) if mine else bufs["ro"].view(S, hdn)[:0]
             if use_streams:
                 cs.wait_stream(cur)
                 with torch.cuda.stream(cs):
-                    dist.all_to_all_single(recv, o[rows], out_split, in_split, group=self.group)
+                    dist.all_to_all_single(ro[rrows], o[rows], out_split, in_split, group=self.group)
             else:
-                dist.all_to_all_single(recv, o[rows], out_split, in_split, group=self.group)
+                dist.all_to_all_single(ro[rrows], o[rows], out_split, in_split, group=self.group)
         if use_streams:
             cur.wait_stream(cs)
         return bufs["ro"]
@@ -357,23 +409,22 @@ class UlyssesHunyuanAttention:
             else:
                 lib.attention(jq[rows], jk[:nq], jv[:nq], hl, 128, out=o[rows], variant=variant)
 
-        # head->seq of the image rows in two halves by destination rank: the first half's exchange runs under the second half's attention
-        halves = [(0, n)] if n < 2 or not self.split_head2seq else [(0, n // 2), (n // 2, n)]
-        for hi, (j0, j1) in enumerate(halves):
-            last = hi == len(halves) - 1
-            attend(slice(j0 * n_img, nq if last else j1 * n_img))  # the valid text queries ride with the last half
+        # head->seq of the image rows in two pieces by destination rank: the first piece's exchange runs under the second piece's attention
+        split = self.split_head2seq
+        if split is True and not split_form_ok(self.group, o.device):
+            split = self.split_head2seq = False
+        plan = _split_plan(n, r, n_img, split)
+        recv_all = a_img[:n].view(tot, hdn)
+        for pi, (_, rows, in_split, out_split, rrows) in enumerate(plan):
+            last = pi == len(plan) - 1
+            attend(slice(rows.start, nq if last else rows.stop))  # the valid text queries ride with the last piece
             if last and n_valid < n_txt:  # the padded text tokens attend among themselves (second cu_seqlens segment)
                 pad = slice(nq, tot + n_txt)
                 if self.attn_fn is not None:
                     self.attn_fn(jq[pad], jk[pad], jv[pad], hl, o[pad])
                 else:
                     lib.attention(jq[pad], jk[pad], jv[pad], hl, 128, out=o[pad], variant=variant)
-            in_split = [n_img if j0 <= j < j1 else 0 for j in range(n)]
-            mine = j0 <= r < j1
-            out_split = [n_img if mine else 0] * n
-            recv = a_img[:n].view(tot, hdn) if mine else a_img[:n].view(tot, hdn)[:0]
-            send = o[j0 * n_img : j1 * n_img]
-            on_comm(lambda recv=recv, send=send, out_split=out_split, in_split=in_split: dist.all_to_all_single(recv, send, out_split, in_split, group=self.group))
+            on_comm(lambda recv=recv_all[rrows], send=o[rows], out_split=out_split, in_split=in_split: dist.all_to_all_single(recv, send, out_split, in_split, group=self.group))
         # text rows: every rank holds all text tokens for its heads -> gather the head blocks (block j = rank j's heads)
         on_comm(lambda: dist.all_gather_into_tensor(a_txt[:n].view(n * n_txt, hdn), o[tot:], group=self.group))
         if use_streams:

@@ -1,7 +1,10 @@
 """world_size-1 worker for tests/test_gpu_dist.py: the process group is the real RCCL backend ("nccl" on ROCm) on the one GPU of
 the box, so the collectives ulysses.py issues (all_to_all_single / all_gather_into_tensor on bf16 device tensors, on the
 communication stream, joined by events) go through RCCL itself rather than the host-staged test shim of the world-2 workers.
-With one rank every exchange is the identity, so the Ulysses-wrapped forward must equal the plain forward bit for bit."""
+With one rank every exchange is the identity, so the Ulysses-wrapped forward must equal the plain forward bit for bit.
+The head->seq exchange is FORCED into its two-piece split-size form (`split_head2seq = "force"`: the self-exchange cut in two row
+pieces), so that RCCL sees the `all_to_all_single(recv_view, send_view, out_split, in_split)` call signature of the N-GPU run, on the
+communication stream, overlapped with the second piece's attention; the probe `split_form_ok` runs against RCCL as well."""
 import os
 import sys
 
@@ -30,10 +33,21 @@ def main():
     wd = synth.synth_wan_weights(dims, seed=3)
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    assert ulysses.split_form_ok(None, torch.device("cuda", 0)), "RCCL rejected the split-size all_to_all_single form"
     outs = {}
-    for mode in ("single", "ulysses"):
-        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type="ulysses" if mode == "ulysses" else None)
+    calls = []
+    real_a2a = dist.all_to_all_single
+
+    def spy(out, inp, out_split=None, in_split=None, **kw):
+        calls.append((tuple(out.shape), tuple(inp.shape), out_split, in_split))
+        return real_a2a(out, inp, out_split, in_split, **kw)
+
+    for mode in ("single", "ulysses", "ulysses-split"):
+        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=None if mode == "single" else "ulysses")
         model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+        if mode == "ulysses-split":
+            model.transformer_infer.parallel_attention.split_head2seq = "force"
+            dist.all_to_all_single = spy
         sch = scheduler.WanScheduler(cfg, device="cuda")
         sch.prepare(latents=lat)
         model.set_scheduler(sch)
@@ -42,8 +56,13 @@ def main():
             model.infer(inputs)
             sch.step_post()
         outs[mode] = sch.latents.float().cpu()
+    dist.all_to_all_single = real_a2a
     assert torch.isfinite(outs["single"]).all()
     assert torch.equal(outs["single"], outs["ulysses"]), "world-1 Ulysses over RCCL differs from the plain forward"
+    assert torch.equal(outs["single"], outs["ulysses-split"]), "world-1 Ulysses with the two-piece split-size head->seq exchange differs from the plain forward"
+    split_calls = [c for c in calls if c[2] is not None]
+    assert split_calls and all(len(c[2]) == 1 and c[2] == c[3] and c[0][0] == c[2][0] for c in split_calls), split_calls[:4]
+    assert len(split_calls) == 2 * 2 * 2 * dims["num_layers"], f"{len(split_calls)} split-size exchanges (2 pieces x 2 forwards x 2 steps x layers expected)"
     dist.barrier()
     torch.cuda.synchronize()
     print("DIST_GPU_RCCL1_OK")

@@ -47,11 +47,19 @@ def test_roofline_peak_is_the_dense_bf16_figure(bench):
 
 @pytest.mark.parametrize("script", ["bench.py", "tools/e2e.py", "tools/hunyuan_bench.py"])
 def test_multi_gpu_launch_contract(script):
-    """`--gpus N` must match the launcher's WORLD_SIZE (one process per GPU under torch.distributed.run); a mismatch stops before
-    any device work with a message that says how to launch."""
+    """`python <script> --gpus N` without a launcher environment starts N ranks of itself under torch.distributed.run (the
+    driver's own command form must not need a human for N > 1): on this GPU-less box both ranks come up with their RANK / LOCAL_RANK,
+    find no device and stop with a message; a launcher whose --nproc-per-node differs from --gpus is refused."""
     import subprocess
     import sys
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
-    assert p.returncode != 0 and "torch.distributed.run --nproc-per-node" in (p.stderr + p.stdout)
+    text = p.stderr + p.stdout
+    assert "no launcher environment, starting -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1" in text
+    import torch
+
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and "rank 0 needs cuda:0" in text and "rank 1 needs cuda:1" in text
+    p = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert p.returncode != 0 and "--nproc-per-node must equal --gpus" in (p.stderr + p.stdout)

@@ -44,6 +44,38 @@ def test_hip_flash_multi_segment_matches_varlen_oracle():
         ops.hip_flash(q.cuda(), k.cuda(), v.cuda(), [0, 10, total], [0, total])
 
 
+def test_hip_flash_fresh_cu_tensors_recycled_at_one_address():
+    """The reference's op-by-op loop builds fresh device cu_seqlens per attention call (wan/infer/transformer_infer.py:73-77
+    `_calculate_q_k_len`: cat + cumsum, version 0, two entries) and drops them, so the caching allocator hands the SAME address to the next
+    one with other contents: self-attention [0, S], cross-attention keys [0, 512], another request's S.  The boundary cache must never serve
+    one tensor's boundaries for another (a (data_ptr, version, numel) key did)."""
+    from lightx2v_amd import ops
+    from oracle import wan_oracle as O
+
+    gen = torch.Generator().manual_seed(2)
+    H = 2
+    q, k, v = (torch.randn(640, H, 128, generator=gen).to(torch.bfloat16) for _ in range(3))
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    seen = set()
+    for n_q, n_k in ((640, 640), (640, 96), (300, 300), (640, 33), (128, 640)):
+        def cu_of(n):  # as the reference: a fresh tensor each time, freed right after the call
+            return torch.cat([torch.zeros(1, dtype=torch.int32, device="cuda"), torch.tensor([n], dtype=torch.int32, device="cuda")]).cumsum(0, dtype=torch.int32)
+
+        cq, ck = cu_of(n_q), cu_of(n_k)
+        seen.add((cq.data_ptr(), ck.data_ptr()))
+        got = ops.hip_flash(qd[:n_q], kd[:n_k], vd[:n_k], cq, ck, max_seqlen_q=n_q, max_seqlen_kv=n_k)
+        del cq, ck
+        assert_bf16_close(got, O.sdpa(q[:n_q], k[:n_k], v[:n_k]), ulps=0.128, atol=4e-3, name=f"fresh cu ({n_q}, {n_k})")
+    assert len(ops._CU_CACHE) <= 8
+    # an in-place edit of a cached tensor is seen through its version counter
+    cu = torch.tensor([0, 640], dtype=torch.int32, device="cuda")
+    ops.hip_flash(qd, kd, vd, cu, cu)
+    cu[1] = 100
+    got = ops.hip_flash(qd, kd, vd, cu, cu, max_seqlen_q=640)
+    assert_bf16_close(got[:100], O.sdpa(q[:100], k[:100], v[:100]), ulps=0.128, atol=4e-3, name="edited cu")
+    assert not got[100:].any()
+
+
 def test_patch_embedding_returns_the_conv3d_layout():
     from lightx2v_amd import registry
 

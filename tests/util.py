@@ -22,3 +22,19 @@ def assert_rel(got, ref, tol, name=""):
     assert torch.isfinite(got.float()).all(), f"{name}: non-finite values"
     e = rel_l2(got, ref)
     assert e <= tol, f"{name}: relative L2 error {e:.3e} > {tol}"
+
+
+def record(name, **numbers):
+    """Append measured parity numbers to gpurun_out/parity_summary.jsonl (merged back from the GPU box; the round's summary under
+    profiles/ is assembled from it).  Never fails a test."""
+    import json
+    import os
+
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.environ.get("X2V_PARITY_LOG") or os.path.join(root, "gpurun_out", "parity_summary.jsonl")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps({"name": name, **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in numbers.items()}}) + "\n")
+    except OSError:
+        pass

@@ -30,9 +30,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
-    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    from lightx2v_amd import launch
+
+    world, rank, local_rank = launch.ranks(__file__, a.gpus)  # bare `--gpus N`: re-runs itself as N ranks under torch.distributed.run
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
