@@ -169,8 +169,8 @@ def ulysses_self_check(dist, world, rank):
     wd = synth.synth_wan_weights(dims, seed=3, device="cuda", gen_device="cuda")
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
-    def one(pat, blocked=True, split=True):
-        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=pat)
+    def one(pat, streams=True, blocked=True, split=True):
+        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=pat, cfg_branch_streams=streams)
         model = wan.WanModel(cfg, wd)
         if pat is not None:  # per-INSTANCE settings (the timed model gets the same ones from main)
             model.transformer_infer.blocked_exchange = blocked
@@ -184,23 +184,26 @@ def ulysses_self_check(dist, world, rank):
         return sch.noise_pred.float(), (model.transformer_infer.parallel_attention.split_head2seq if pat is not None else None)
 
     outs = [one(None)[0]]
-    # The designed exchange path first (ulysses.py itself probes the split-size collective form once and falls back to a single head->seq
-    # exchange); should this PyTorch/RCCL build still reject a form (argument errors are raised on every rank alike, before anything is
-    # sent), the simpler paths are tried, and the one that ran is named in the JSON line and used for the timed model.
+    # The designed path first: the two CFG branches on two compute streams, blocked exchange buffers, head->seq in two overlapped pieces
+    # (ulysses.py itself probes the split-size collective form once and falls back to a single head->seq exchange).  Should this
+    # PyTorch/RCCL build still reject a form (argument errors are raised on every rank alike, before anything is sent), the simpler paths
+    # are tried; the one that ran is named in the JSON line and used for the timed model.
     path, errors, settings = None, [], None
-    for name, blocked, halves in (("blocked buffers, head->seq in two overlapped pieces", True, True), ("blocked buffers, one head->seq exchange", True, False),
-                                  ("row-major exchange (reference form, transposing copies)", False, False)):
+    for name, streams, blocked, halves in (("CFG branches on two streams, blocked buffers, head->seq in two overlapped pieces", True, True, True),
+                                           ("sequential CFG branches, blocked buffers, head->seq in two overlapped pieces", False, True, True),
+                                           ("sequential CFG branches, blocked buffers, one head->seq exchange", False, True, False),
+                                           ("sequential CFG branches, row-major exchange (reference form, transposing copies)", False, False, False)):
         try:
-            o, split_used = one("ulysses", blocked, halves)
+            o, split_used = one("ulysses", streams, blocked, halves)
             outs.append(o)
             if blocked and halves and not split_used:
-                name = "blocked buffers, one head->seq exchange (split-size collective form rejected by the probe)"
-            path, settings = name, {"blocked_exchange": blocked, "split_head2seq": bool(split_used) if blocked else False}
+                name += " -> ONE head->seq exchange (split-size collective form rejected by the probe)"
+            path, settings = name, {"cfg_branch_streams": streams, "blocked_exchange": blocked, "split_head2seq": bool(split_used) if blocked else False}
             break
         except Exception as e:  # noqa: BLE001
             errors.append(f"{name}: {type(e).__name__}: {str(e)[:200]}")
             if rank == 0:
-                print(f"bench: Ulysses exchange path '{name}' failed: {errors[-1]}", file=sys.stderr)
+                print(f"bench: Ulysses path '{name}' failed: {errors[-1]}", file=sys.stderr)
     if path is None:
         raise SystemExit("bench: no Ulysses exchange path works on this node: " + " | ".join(errors))
     rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).reshape(1)
@@ -279,6 +282,7 @@ def main():
     sp_check = None
     if world > 1:
         sp_check = ulysses_self_check(dist, world, rank)
+        model.config["cfg_branch_streams"] = sp_check["settings"]["cfg_branch_streams"]
         model.transformer_infer.blocked_exchange = sp_check["settings"]["blocked_exchange"]
         model.transformer_infer.parallel_attention.split_head2seq = sp_check["settings"]["split_head2seq"]
     for i in range(args.warmup):

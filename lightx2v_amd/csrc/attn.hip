@@ -320,12 +320,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //       into the vector half-step;
 //   (c) the tile loop is unrolled x2 so that both LDS buffer indices are compile-time: every fragment address is
 //       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
+#ifndef AT_DEFAULT_GEN
+#define AT_DEFAULT_GEN 8
+#endif
+#ifndef AT_DEFAULT_MAP
+#define AT_DEFAULT_MAP 0
+#endif
+#ifndef AT_DEFAULT_ROT
+#define AT_DEFAULT_ROT 0
+#endif
 struct AttnBatch {
   int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
-  int xcd_remap;        // 1: XCD-aware (sequence, head, query block) -> workgroup mapping (see the kernel), 0: the grid as dispatched
+  int xcd_remap;        // bits 0-7: work mapping (0 the grid as dispatched, 1 XCD-aware head-major, 2 XCD-aware with two heads in flight); bits 8-15: key-walk rotation mode
 };
 
-template <int NW, int RESCALE_THR, bool PRESCALED>
+template <int NW, int RESCALE_THR, bool PRESCALED, bool ROT>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
                                                                    const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
@@ -341,12 +350,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   // for any count), so its resident workgroups are consecutive query blocks of ONE head that walk the same K / V^T tiles at about the same
   // time — a tile is filled into that L2 once per generation of workgroups instead of once per drifting pair of heads.
   int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
-  if (bs.xcd_remap) {
+  const int map_mode = bs.xcd_remap & 0xff;
+  if (map_mode) {
     const unsigned gx = gridDim.x, gy = gridDim.y;
     const unsigned nwg = gx * gy * gridDim.z;
     const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const unsigned xcd = L & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
-    const unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    if (map_mode == 2 && (gy & 1u) == 0 && r8 == 0 && ((gy * gridDim.z) & 15u) == 0) {
+      // two heads in flight per XCD: consecutive workgroups alternate between the heads of a pair
+      const unsigned pair = id / (2 * gx), w = id % (2 * gx);
+      id = (2 * pair + (w & 1u)) * gx + (w >> 1);
+    }
     qblk = (int)(id % gx);
     const unsigned hz = id / gx;
     head = (int)(hz % gy);
@@ -400,12 +415,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   const int krow_w = wl * 4 + (lane >> 4), vrow_w = wl * 8 + (lane >> 3);
   const unsigned k_voff = (unsigned)(krow_w * ldk * 2) + (unsigned)(((lane & 15) ^ (krow_w & 15)) << 4);
   const unsigned v_voff = (unsigned)(vrow_w * 128) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
-#define A8_DMA_K(T_, BUF_)                                                                                   \
+#define A8_DMA_K(SOFF_, BUF_)                                                                                  \
   _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, k_voff, (unsigned)(T_) * k_tile_bytes + j * k_piece_bytes, 0, 0);
-#define A8_DMA_V(T_, BUF_)                                                                                   \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, k_voff, (SOFF_) + j * k_piece_bytes, 0, 0);
+#define A8_DMA_V(SOFF_, BUF_)                                                                                  \
   _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (unsigned)(T_) * AT_K_BYTES + j * v_piece_bytes, 0, 0);
+      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (SOFF_) + j * v_piece_bytes, 0, 0);
 
   // fragment offsets: K rows read through the bit-2/bit-3 swap so a half-wave's P registers are 8 consecutive keys
   int kaddr[8], vaddr[4];
@@ -427,6 +442,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   bool force = true;  // first tile: adopt its row max in either direction
   unsigned pw[16];
   const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+  // Key-tile walk: logical tile t of this workgroup is physical tile (t + rot) mod nt.  The online softmax does not care where the walk
+  // starts; what does is the L2: with the XCD-aware mapping the 64 workgroups resident on an XCD start together and ask for the SAME K / V^T
+  // lines at the same instant — every tile is a cold miss that all of them wait out together.  A start offset that depends on the query
+  // block de-phases them: one workgroup of a phase group takes the miss, its followers hit.  rot is a function of (qblk, nt) only, so a
+  // query row's result does not depend on how the launch was batched or mapped (it does depend on the rotation mode: another summation order).
+  const int rot_mode = ROT ? (bs.xcd_remap >> 8) & 0xff : 0;  // ROT = false: the instantiation without any of the wrap arithmetic
+  int rot = 0;
+  if (rot_mode == 1) rot = (qblk & 7);                       // stagger: up to 7 tiles apart
+  else if (rot_mode == 2) rot = (qblk & 3) * (nt >> 2);      // four phase groups a quarter of the walk apart
+  else if (rot_mode == 3) rot = (qblk & 1) * (nt >> 1);      // two phase groups
+  else if (rot_mode == 4) rot = (qblk & 7) * (nt >> 3);      // eight phase groups
+  else if (rot_mode == 5) rot = (qblk & 3) * 2;              // stagger 0 / 2 / 4 / 6 tiles
+  if (rot >= nt - 1) rot = 0;
+  rot = __builtin_amdgcn_readfirstlane(rot);
+  // the walk as running byte offsets of the next K / V^T tile to fetch.  Only the first nt - 1 (full) tiles rotate — logical tile t < nt - 1 is
+  // physical tile (t + rot) mod (nt - 1) — and the physical last tile, the one that may hold fewer than 64 keys, stays last, so the key mask
+  // lives in the final softmax only (a mask test in every tile's softmax costs 37 spilled SGPRs in this kernel).
+  const unsigned k_last = (unsigned)(nt - 1) * k_tile_bytes, v_last = (unsigned)(nt - 1) * AT_K_BYTES;
+  unsigned kso = (unsigned)rot * k_tile_bytes, vso = (unsigned)rot * AT_K_BYTES;
+#define A8_NEXT_K() if constexpr (ROT) { kso += k_tile_bytes; kso = kso == k_last ? 0u : kso; }
+#define A8_NEXT_V() if constexpr (ROT) { vso += AT_K_BYTES; vso = vso == v_last ? 0u : vso; }
+#define A8_KOFF(T_) (ROT ? ((T_) == nt - 1 ? k_last : kso) : (unsigned)(T_) * k_tile_bytes)
+#define A8_VOFF(T_) (ROT ? ((T_) == nt - 1 ? v_last : vso) : (unsigned)(T_) * AT_K_BYTES)
 
 #define A8_SB() __builtin_amdgcn_sched_barrier(0)
   // matrix half-step: unified stream of fragment slots n = 0..15 (K: key block n&1, head-dim step n>>1) and 16..31 (V^T: dv block
@@ -505,7 +543,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
 
   // ---- prologue: K(0)
   if (wid >= NW / 2) {
-    A8_DMA_K(0, 0)
+    A8_DMA_K(A8_KOFF(0), 0)
+    A8_NEXT_K()
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -518,10 +557,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
   int t = 0;
 #define A8_ISSUE(TG_) /* even half-step g = 2 TG_ */ \
   if ((TG_) + 1 < nt) {                               \
-    A8_DMA_K((TG_) + 1, ((TG_) + 1) & 1)              \
+    A8_DMA_K(A8_KOFF((TG_) + 1), ((TG_) + 1) & 1)     \
+    A8_NEXT_K()                                       \
   }                                                   \
   if ((TG_) < nt) {                                   \
-    A8_DMA_V((TG_), (TG_) & 1)                        \
+    A8_DMA_V(A8_VOFF(TG_), (TG_) & 1)                 \
+    A8_NEXT_V()                                       \
   }                                                   \
   A8_SB();
   // the data issued in an even half-step is awaited at the end of the following odd one: two half-steps of flight
@@ -575,6 +616,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
     A8_BAR_ODD()
   }
 #undef A8_ISSUE
+#undef A8_NEXT_K
+#undef A8_NEXT_V
+#undef A8_KOFF
+#undef A8_VOFF
 #undef A8_BAR_EVEN
 #undef A8_BAR_ODD
 #undef A8_SOFTMAX
@@ -600,6 +645,331 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
         pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(op + dv) = pk;
       }
+  }
+#endif
+}
+
+// "v9": the ping-pong kernel on v_mfma_f32_16x16x32_bf16.  Same workgroup (8 waves x 32 query rows), same LDS-DMA double buffering, same
+// half-step protocol and roles as v8; what changes is the register geometry.  At the board's power limit the 16x16x32 shape delivers more
+// FLOP per joule than 32x32x16 (tools/probes/mfma_power_probe: 1582 vs 1529-1540 TFLOP/s with attention's fragment traffic at 32 rows per
+// wave), the same effect that moved the GEMMs (gemm256.hip).
+//   * a wave's 32 query rows are two groups g of 16; lane = (c = lane & 15, qd = lane >> 4).
+//   * S^T = K . Q^T per 16-key sub-tile kt (4 per tile): A = K fragment (row = key kappa(kt, c), k-slot 8 qd + e <-> d = 32 ks + 8 qd + e),
+//     B = Q fragment (col = query 16 g + c, same k-slots): 4 kt x 2 g x 4 ks = 32 MFMAs; a K fragment read feeds both groups.
+//     The output lane (c, qd) holds rows 4 qd + r of sub-tile kt, i.e. keys kappa(kt, 4 qd + r).
+//   * kappa(2 j + b, i) = 32 j + 8 (i >> 2) + 4 b + (i & 3): lane (c, qd) then owns, over the sub-tile pair (2 j, 2 j + 1), the 8 CONSECUTIVE keys
+//     32 j + 8 qd + e — exactly the k-slots of a 16-byte V^T fragment (row dv, keys 32 j + 8 qd ..), so P stays in registers as the B operand
+//     of O^T += V^T . P: 8 dv tiles x 2 g x 2 j = 32 MFMAs, a V^T fragment read feeds both groups.  64 half-size MFMAs per tile for the
+//     32 of v8, the same 32 ds_read_b128.
+//   * K's LDS image keeps [64 keys][256 B] but its 16-byte chunk index is XORed with h(key) = (key & 3) | ((key >> 1) & 12): the 16 rows a
+//     16-lane group reads are kappa(kt, 0..15), whose h values are exactly 0..15 (h(kappa(kt, c)) = c) — conflict-free; (key & 15), v8's
+//     hash, would collide two-fold.  The DMA pieces of a wave are chosen so that h is the same for all of them (one voffset register).
+//   * a query's 64 scores of a tile sit in 4 lanes (the 4 qd of its column): row maxima of both groups cross lanes with 3 swaps
+//     (permlane16_swap, permlane32_swap, permlane16_swap) and 2 max.
+template <int NW, int RESCALE_THR, bool PRESCALED, bool ROT>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
+                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                                   const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
+                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
+                                                                   unsigned v_bytes, AttnBatch bs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(NW == 8, "DMA piece assignment below is written for 4 issuing waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+  const int map_mode = bs.xcd_remap & 0xff;
+  if (map_mode) {  // XCD-aware work mapping: see attn_fwd_v8_kernel
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nwg = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = L & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+    unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    if (map_mode == 2 && (gy & 1u) == 0 && r8 == 0 && ((gy * gridDim.z) & 15u) == 0) {
+      const unsigned pair = id / (2 * gx), w = id % (2 * gx);
+      id = (2 * pair + (w & 1u)) * gx + (w >> 1);
+    }
+    qblk = (int)(id % gx);
+    const unsigned hz = id / gx;
+    head = (int)(hz % gy);
+    seq = (int)(hz / gy);
+  }
+  Q += (int64_t)seq * bs.q;
+  Kp += (int64_t)seq * bs.k;
+  VTp += (int64_t)seq * bs.vt;
+  O += (int64_t)seq * bs.o;
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
+  constexpr int DEPTH = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, qd = lane >> 4;
+  const int64_t q0 = (int64_t)qblk * (NW * 32) + wid * 32;
+  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
+  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;
+
+  bf16x8_t qf[2][4];  // [query group][k-step of 32 head-dim values]
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    int64_t qr = q0 + 16 * g + c16;
+    qr = qr < Sq ? qr : Sq - 1;
+    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + qd * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+      if constexpr (!PRESCALED) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
+      }
+      qf[g][ks] = v;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[g][ks]));
+
+  // LDS-DMA, 1 KiB pieces (4 K rows / 8 V^T rows), issued by the upper half of the waves during their vector half-step (as v8).  K piece pc
+  // holds rows 4 pc .. 4 pc + 3; wave wl takes pc = 2 wl + b0 + 8 b3 (b0, b3 in {0,1}): for all of them h(row) = (row & 3) | (wl << 2), so ONE
+  // per-lane offset serves its four pieces; the piece's rows travel in the scalar offset.
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
+  constexpr int NDW = NW / 2;
+  constexpr int NPC = 16 / NDW;
+  const int wl = wid & (NW / 2 - 1);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_row_bytes = (unsigned)(ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * 128);
+  const int krr = lane >> 4, vrow_w = wl * 8 + (lane >> 3);
+  const unsigned k_voff = (unsigned)((8 * wl + krr) * ldk * 2) + (unsigned)(((lane & 15) ^ (krr | (wl << 2))) << 4);
+  const unsigned v_voff = (unsigned)(vrow_w * 128) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
+#define A9_DMA_K(SOFF_, BUF_)                                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                                            \
+      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + ((wl << 1) | (j & 1) | ((j >> 1) << 3)) * 1024), 16, k_voff,              \
+      (SOFF_) + (unsigned)(4 * (j & 1) + 32 * (j >> 1)) * k_row_bytes, 0, 0);
+#define A9_DMA_V(SOFF_, BUF_)                                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                                            \
+      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (SOFF_) + j * v_piece_bytes, 0, 0);
+
+  // fragment offsets.  K: row kappa(kt, c) = 8 (c >> 2) + (c & 3) [+ 32 j + 4 b as an immediate], chunk (4 ks + qd) ^ c.  V^T: row 16 T + c
+  // [16 T rows as an immediate], chunk (4 j + qd) ^ ((c >> 1) & 7).
+  int kbase[4], vbase[2];
+  const int krow_rd = 8 * (c16 >> 2) + (c16 & 3);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kbase[ks] = krow_rd * 256 + ((((ks << 2) | qd) ^ c16) << 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) vbase[j] = c16 * 128 + ((((j << 2) | qd) ^ ((c16 >> 1) & 7)) << 4);
+
+  f32x4_t oacc[8][2], sc[4][2], negm[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      negm[g][e] = 0.f;
+#pragma unroll
+      for (int T = 0; T < 8; ++T) oacc[T][g][e] = 0.f;
+    }
+  float m_run[2] = {0.f, 0.f};
+  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  bool force = true;  // first tile: adopt its row max in either direction
+  unsigned pw[2][2][4];  // [key group j][query group g]: 8 bf16 probabilities = the B operand of a PV MFMA
+  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
+  const int rot_mode = ROT ? (bs.xcd_remap >> 8) & 0xff : 0;
+  int rot = 0;
+  if (rot_mode == 1) rot = (qblk & 7);
+  else if (rot_mode == 2) rot = (qblk & 3) * (nt >> 2);
+  else if (rot_mode == 3) rot = (qblk & 1) * (nt >> 1);
+  else if (rot_mode == 4) rot = (qblk & 7) * (nt >> 3);
+  else if (rot_mode == 5) rot = (qblk & 3) * 2;
+  if (rot >= nt - 1) rot = 0;
+  rot = __builtin_amdgcn_readfirstlane(rot);
+  const unsigned k_last = (unsigned)(nt - 1) * k_tile_bytes, v_last = (unsigned)(nt - 1) * AT_K_BYTES;
+  unsigned kso = (unsigned)rot * k_tile_bytes, vso = (unsigned)rot * AT_K_BYTES;
+#define A9_NEXT_K() if constexpr (ROT) { kso += k_tile_bytes; kso = kso == k_last ? 0u : kso; }
+#define A9_NEXT_V() if constexpr (ROT) { vso += AT_K_BYTES; vso = vso == v_last ? 0u : vso; }
+#define A9_KOFF(T_) (ROT ? ((T_) == nt - 1 ? k_last : kso) : (unsigned)(T_) * k_tile_bytes)
+#define A9_VOFF(T_) (ROT ? ((T_) == nt - 1 ? v_last : vso) : (unsigned)(T_) * AT_K_BYTES)
+
+#define A9_SB() __builtin_amdgcn_sched_barrier(0)
+  // matrix half-step: fragment slots n = 0..15 (K: k-step n >> 2, sub-tile n & 3) and 16..31 (V^T: key group (n - 16) >> 3, dv tile (n - 16) & 7),
+  // each fragment read DEPTH slots ahead and consumed by the two MFMAs of its slot (query groups 0 and 1).
+#define A9_FRAG(N_)                                                                                                      \
+  ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + (((N_) & 3) >> 1) * 8192 + ((N_) & 1) * 1024 + kbase[(N_) >> 2]) \
+             : *reinterpret_cast<const bf16x8_t*>(vb + (((N_) - 16) & 7) * 2048 + vbase[((N_) - 16) >> 3]))
+#define A9_MATRIX(N0_, N1_, VB_, KB_)                                                                                    \
+  {                                                                                                                      \
+    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                                  \
+    const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    bf16x8_t fr[DEPTH];                                                                                                  \
+    _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                        \
+    _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                              \
+      const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                                       \
+      if (n < 16) {                                                                                                      \
+        const int ks = n >> 2, kt = n & 3;                                                                               \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                  \
+          if (ks == 0) /* D early-clobber: the -m tuple stays a pure input */                                            \
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(sc[kt][g]) : "v"(f_), "v"(qf[g][0]), "v"(negm[g])); \
+          else                                                                                                           \
+            sc[kt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f_, qf[g][ks], sc[kt][g], 0, 0, 0);                       \
+        }                                                                                                                \
+      } else {                                                                                                           \
+        const int T = (n - 16) & 7, j = (n - 16) >> 3;                                                                   \
+        _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                  \
+          i32x4_t pq = {(int)pw[j][g][0], (int)pw[j][g][1], (int)pw[j][g][2], (int)pw[j][g][3]};                         \
+          oacc[T][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f_, __builtin_bit_cast(bf16x8_t, pq), oacc[T][g], 0, 0, 0); \
+        }                                                                                                                \
+      }                                                                                                                  \
+      if (n + DEPTH < (N1_)) fr[(n - (N0_)) % DEPTH] = A9_FRAG(n + DEPTH);                                               \
+      A9_SB();                                                                                                           \
+    }                                                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+  }
+  // vector half-step: softmax of the tile in sc -> packed bf16 P in pw.  Register r of sc[kt][g] is key 32 (kt >> 1) + 8 qd + 4 (kt & 1) + r.
+#define A9_SOFTMAX(LAST_)                                                                                                \
+  {                                                                                                                      \
+    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                                      \
+      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                                   \
+      _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) _Pragma("unroll") for (int r = 0; r < 4; ++r)                     \
+        if (32 * (kt >> 1) + 8 * qd + 4 * (kt & 1) + r >= left) { sc[kt][0][r] = -1e30f; sc[kt][1][r] = -1e30f; }        \
+    }                                                                                                                    \
+    float mg[2];                                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                      \
+      const float a_ = vmax3(sc[0][g][0], sc[0][g][1], sc[0][g][2]), b_ = vmax3(sc[0][g][3], sc[1][g][0], sc[1][g][1]);   \
+      const float c_ = vmax3(sc[1][g][2], sc[1][g][3], sc[2][g][0]), d_ = vmax3(sc[2][g][1], sc[2][g][2], sc[2][g][3]);   \
+      const float e_ = vmax3(sc[3][g][0], sc[3][g][1], sc[3][g][2]);                                                     \
+      mg[g] = vmax3(vmax3(a_, b_, c_), vmax3(d_, e_, sc[3][g][3]), -3.0e38f);                                            \
+    }                                                                                                                    \
+    { /* across the four lanes (qd) of a query column, both groups at once: rows {A01, B01, A23, B23} -> {A, B, A, B} -> A | B */ \
+      auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mg[0]), __float_as_uint(mg[1]), false, false);         \
+      const float c1 = vmax2(__uint_as_float(s1[0]), __uint_as_float(s1[1]));                                            \
+      auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c1), __float_as_uint(c1), false, false);               \
+      const float c2 = vmax2(__uint_as_float(s2[0]), __uint_as_float(s2[1]));                                            \
+      auto s3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(c2), __float_as_uint(c2), false, false);               \
+      mg[0] = __uint_as_float(s3[0]);                                                                                    \
+      mg[1] = __uint_as_float(s3[1]);                                                                                    \
+    }                                                                                                                    \
+    if (force || __any(vmax2(mg[0], mg[1]) > (float)RESCALE_THR)) { /* cold: some row's max grew by more than THR (or first tile) */ \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                    \
+        const float d = force ? mg[g] : fmaxf(mg[g], 0.f);                                                               \
+        m_run[g] += d;                                                                                                   \
+        if (!force) {                                                                                                    \
+          const float al = __builtin_amdgcn_exp2f(-d);                                                                   \
+          lsum[g][0] *= al;                                                                                              \
+          lsum[g][1] *= al;                                                                                              \
+          _Pragma("unroll") for (int T = 0; T < 8; ++T) _Pragma("unroll") for (int e = 0; e < 4; ++e) oacc[T][g][e] *= al; \
+        }                                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) negm[g][e] = -m_run[g];                                            \
+        _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) _Pragma("unroll") for (int e = 0; e < 4; ++e) sc[kt][g][e] -= d; \
+      }                                                                                                                  \
+      force = false;                                                                                                     \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) _Pragma("unroll") for (int e = 0; e < 4; e += 2) { \
+      const float p0 = __builtin_amdgcn_exp2f(sc[kt][g][e]), p1 = __builtin_amdgcn_exp2f(sc[kt][g][e + 1]);             \
+      lsum[g][0] += p0;                                                                                                  \
+      lsum[g][1] += p1;                                                                                                  \
+      pw[kt >> 1][g][2 * (kt & 1) + (e >> 1)] = pack_bf2(p0, p1);                                                        \
+    }                                                                                                                    \
+    { /* the row sums belong to THIS half-step */                                                                        \
+      asm volatile("" : "+v"(lsum[0][0]), "+v"(lsum[0][1]), "+v"(lsum[1][0]), "+v"(lsum[1][1]));                         \
+      A9_SB();                                                                                                           \
+    }                                                                                                                    \
+  }
+
+  // ---- prologue: K(0)
+  if (wid >= NW / 2) {
+    A9_DMA_K(A9_KOFF(0), 0)
+    A9_NEXT_K()
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int t = 0;
+#define A9_ISSUE(TG_) /* even half-step g = 2 TG_ */  \
+  if ((TG_) + 1 < nt) {                               \
+    A9_DMA_K(A9_KOFF((TG_) + 1), ((TG_) + 1) & 1)     \
+    A9_NEXT_K()                                       \
+  }                                                   \
+  if ((TG_) < nt) {                                   \
+    A9_DMA_V(A9_VOFF(TG_), (TG_) & 1)                 \
+    A9_NEXT_V()                                       \
+  }                                                   \
+  A9_SB();
+#define A9_BAR_EVEN() __syncthreads();
+#define A9_BAR_ODD()                                   \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+  __syncthreads();
+  if (wid < NW / 2) {
+    A9_MATRIX(0, 16, 0, 0)
+    A9_BAR_EVEN()
+    while (t < nt - 1) {
+      A9_SOFTMAX(false)
+      A9_BAR_ODD()
+      A9_MATRIX(0, 32, 0, 1)
+      A9_BAR_EVEN()
+      if (++t >= nt - 1) break;
+      A9_SOFTMAX(false)
+      A9_BAR_ODD()
+      A9_MATRIX(0, 32, 1, 0)
+      A9_BAR_EVEN()
+      ++t;
+    }
+    A9_SOFTMAX(true)
+    A9_BAR_ODD()
+    A9_MATRIX(16, 32, t & 1, 0)
+    A9_BAR_EVEN()
+    A9_BAR_ODD()
+  } else {
+    A9_ISSUE(0)
+    A9_BAR_EVEN()
+    A9_MATRIX(0, 16, 0, 0)
+    A9_BAR_ODD()
+    while (t < nt - 1) {
+      A9_ISSUE(t + 1)
+      A9_SOFTMAX(false)
+      A9_BAR_EVEN()
+      A9_MATRIX(0, 32, 0, 1)
+      A9_BAR_ODD()
+      if (++t >= nt - 1) break;
+      A9_ISSUE(t + 1)
+      A9_SOFTMAX(false)
+      A9_BAR_EVEN()
+      A9_MATRIX(0, 32, 1, 0)
+      A9_BAR_ODD()
+      ++t;
+    }
+    A9_SOFTMAX(true)
+    A9_BAR_EVEN()
+    A9_MATRIX(16, 32, t & 1, 0)
+    A9_BAR_ODD()
+  }
+#undef A9_ISSUE
+#undef A9_NEXT_K
+#undef A9_NEXT_V
+#undef A9_KOFF
+#undef A9_VOFF
+#undef A9_BAR_EVEN
+#undef A9_BAR_ODD
+#undef A9_SOFTMAX
+#undef A9_MATRIX
+#undef A9_FRAG
+#undef A9_SB
+#undef A9_DMA_K
+#undef A9_DMA_V
+
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float l_run = lsum[g][0] + lsum[g][1];
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    const int64_t qrow = q0 + 16 * g + c16;
+    if (qrow < Sq) {
+      unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D + 4 * qd;
+#pragma unroll
+      for (int T = 0; T < 8; ++T) {
+        uint2 pk;
+        pk.x = pack_bf2(oacc[T][g][0] * inv, oacc[T][g][1] * inv);
+        pk.y = pack_bf2(oacc[T][g][2] * inv, oacc[T][g][3] * inv);
+        *reinterpret_cast<uint2*>(op + 16 * T) = pk;
+      }
+    }
   }
 #endif
 }
@@ -661,14 +1031,19 @@ static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk
   // buffer ranges from a head's (and sequence's) first element: K rows of this sequence, the V^T blocks of its ceil(Sk/64) key tiles
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = ((Sk + AT_KV - 1) / AT_KV) * (int64_t)AT_D * AT_KV * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
-  auto kern = attn_fwd_v8_kernel<NW, THR, PRESCALED>;
+  dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
+  // work mapping / key-walk rotation (see the kernel): defaults apply once every XCD has more than a residency's worth of workgroups (below that
+  // the plain grid spreads a head's few query blocks over all L2s, which is what a small launch wants); X2V_ATTN_MAP / X2V_ATTN_ROT force a mode (A/B runs)
+  static const int map_env = [] { const char* e = getenv("X2V_ATTN_MAP"); return e ? atoi(e) : -1; }();
+  static const int rot_env = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
+  const bool big = (uint64_t)grid.x * grid.y * grid.z >= 2048;
+  const int map_mode = map_env >= 0 ? map_env : (big ? AT_DEFAULT_MAP : 0), rot_mode = rot_env >= 0 ? rot_env : (big ? AT_DEFAULT_ROT : 0);
+  bs.xcd_remap = (map_mode & 0xff) | ((rot_mode & 0xff) << 8);
+  static const int gen_env = [] { const char* e = getenv("X2V_ATTN_GEN"); return e ? atoi(e) : AT_DEFAULT_GEN; }();  // 8: 32x32x16 MFMA, 9: 16x16x32
+  auto kern = gen_env == 9 ? (rot_mode ? attn_fwd_v9_kernel<NW, THR, PRESCALED, true> : attn_fwd_v9_kernel<NW, THR, PRESCALED, false>)
+                           : (rot_mode ? attn_fwd_v8_kernel<NW, THR, PRESCALED, true> : attn_fwd_v8_kernel<NW, THR, PRESCALED, false>);
   int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
   if (rc != X2V_OK) return rc;
-  dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
-  // XCD-aware mapping once every XCD has more than a residency's worth of workgroups (below that the plain grid spreads a head's few
-  // query blocks over all L2s, which is what a small launch wants); X2V_ATTN_XCD=0/1 forces it (A/B runs)
-  static const int xcd_env = [] { const char* e = getenv("X2V_ATTN_XCD"); return e ? atoi(e) : -1; }();
-  bs.xcd_remap = xcd_env >= 0 ? (xcd_env != 0) : ((uint64_t)grid.x * grid.y * grid.z >= 2048);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), 4 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
                      (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, Sk, scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb, bs);
   X2V_LAUNCH_CHECK("attn launch");

@@ -286,8 +286,17 @@ static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t 
 #ifndef X2V_GEMM256_BF16_KERNEL
 #define X2V_GEMM256_BF16_KERNEL 3
 #endif
-static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb, bool fp8) {
-  const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
+// The 256x256 kernels address an operand tile through a 32-bit buffer descriptor from the tile's first row: 255 rows + the K span of one row
+// (K-blocked x: (K blocks - 1) block strides + one block) must stay below 4 GiB, else the range check would wrap and valid elements read as
+// zero.  Such shapes take the 128x128 kernel (64-bit addressing).
+static bool spans_fit_256(int nk, int64_t ldxb, int64_t ldwb, const GemmBlocking& gb) {
+  const int64_t a_kpb = gb.a_kpb > 0 && gb.a_kpb < nk ? gb.a_kpb : nk;
+  const int64_t a_span = a_kpb < nk ? ((nk - 1) / a_kpb) * (int64_t)gb.a_cbs + a_kpb * 128 : (int64_t)nk * 128;
+  return ldxb < (1 << 24) && ldwb < (1 << 24) && 255 * ldxb + a_span < (1ll << 32) && 255 * ldwb + (int64_t)nk * 128 < (1ll << 32);
+}
+
+static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb, bool fp8, const GemmBlocking& gb = GemmBlocking()) {
+  const bool fits256 = spans_fit_256(nk, ldxb, ldwb, gb);
   const int64_t tiles256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
   return (fits256 && tiles256 >= 192 && nk >= 8) ? (fp8 ? 2 : X2V_GEMM256_BF16_KERNEL) : 1;
 }
@@ -300,16 +309,16 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
                         GemmBlocking gb = GemmBlocking()) {
   const int kind = variant & 0xff;
   const int gm_tiles = (variant >> 8) & 0xff;
-  const bool fits256 = ldxb < (1 << 24) && ldwb < (1 << 24);
+  const bool fits256 = spans_fit_256(nk, ldxb, ldwb, gb);
   if ((kind == 2 || kind == 3) && !fits256) {
-    set_error("gemm: leading dimension too large for the 256x256 kernels");
+    set_error("gemm: leading dimension / K-block span too large for the 256x256 kernels (32-bit tile addressing)");
     return X2V_E_SHAPE;
   }
   if (kind == 3 && FP8) {
     set_error("gemm: the single-stream 256x256 kernel is bf16 only");
     return X2V_E_ARG;
   }
-  const int chosen = kind == 0 ? choose_kernel(M, N, nk, ldxb, ldwb, FP8) : kind;
+  const int chosen = kind == 0 ? choose_kernel(M, N, nk, ldxb, ldwb, FP8, gb) : kind;
   if constexpr (!FP8) {
     if (chosen == 3) return gemm256s_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
   }

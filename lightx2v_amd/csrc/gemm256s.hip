@@ -275,6 +275,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   } else {
+  // ---- epilogue phase 0 (residual epilogue): this thread's 32 residual chunks (the rows / columns it will store in phase 2) are requested NOW,
+    //      into the registers the fragments no longer need, so that ONE memory latency runs under the accumulator -> LDS pass instead of eight
+    //      dependent round trips inside the store loop (the residual variant ran 8 % below the plain one per FLOP: ~10 us of a 117 us tile).
+    uint4 rres[32];
+    if constexpr (EPI == X2V_EPI_RESIDUAL) {
+  #pragma unroll
+      for (int it = 0; it < 32; ++it) {
+        const int id = it * 256 + tid;
+        const int row = id >> 5, cc = id & 31;
+        const int64_t gmr = m0 + row;
+        const int gn = n0 + cc * 8;
+        rres[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (gmr < M && gn < N) rres[it] = *reinterpret_cast<const uint4*>(resid + gmr * ldr + gn);
+      }
+    }
   // ---- epilogue phase 1: acc (+bias, activation) -> bf16 -> LDS [256][S_EPI_LD]
     //      tile (xb, wb), register e: tile row wr*128 + xb*16 + r16, tile col wc*128 + wb*16 + 4*g16 + e
     uint2 bv[8];
@@ -307,31 +322,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
     __syncthreads();
     // ---- epilogue phase 2: 16-byte stores, 32 lanes per 512-byte output row
-  #pragma unroll 4
-    for (int it = 0; it < 32; ++it) {
-      const int id = it * 256 + tid;
-      const int row = id >> 5, cc = id & 31;
-      const int64_t gmr = m0 + row;
-      const int gn = n0 + cc * 8;
-      if (gmr < M && gn < N) {
-        const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
-        uint4 o = *reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16);
-        if (EPI == X2V_EPI_RESIDUAL) {
+    if constexpr (EPI == X2V_EPI_RESIDUAL) {
+      // per-column gate chunk: the same 8 columns in every iteration of this thread (cc = tid & 31)
+      float gv[8];
+      {
+        const int gn = n0 + (tid & 31) * 8;
+        uint4 g4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (gate != nullptr && gn < N) g4 = *reinterpret_cast<const uint4*>(gate + gn);
+        unpack8(g4, gv);
+      }
+  #pragma unroll
+      for (int it = 0; it < 32; ++it) {
+        const int id = it * 256 + tid;
+        const int row = id >> 5, cc = id & 31;
+        const int64_t gmr = m0 + row;
+        const int gn = n0 + cc * 8;
+        if (gmr < M && gn < N) {
+          const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
           float yv[8], xv[8], ov[8];
-          unpack8(o, yv);
-          unpack8(*reinterpret_cast<const uint4*>(resid + gmr * ldr + gn), xv);
+          unpack8(*reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16), yv);
+          unpack8(rres[it], xv);
           if (gate != nullptr) {
-            float gv[8];
-            unpack8(*reinterpret_cast<const uint4*>(gate + gn), gv);
   #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = xv[e] + rbf(yv[e] * gv[e]);
           } else {
   #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = xv[e] + yv[e];
           }
-          o = pack8(ov);
+          *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = pack8(ov);
         }
-        *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = o;
+      }
+    } else {
+  #pragma unroll 4
+      for (int it = 0; it < 32; ++it) {
+        const int id = it * 256 + tid;
+        const int row = id >> 5, cc = id & 31;
+        const int64_t gmr = m0 + row;
+        const int gn = n0 + cc * 8;
+        if (gmr < M && gn < N) {
+          const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
+          *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = *reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16);
+        }
       }
     }
 }

@@ -275,7 +275,9 @@ def post_process(x, group=None):
 
 
 def parallelize_wan(wan_model, group=None, attn_fn=None):
-    """reference: ulysses/wrap.py:53-71 — swap the attention, shard x around the block stack."""
+    """reference: ulysses/wrap.py:53-71 — swap the attention, shard x around the block stack.  Beyond the reference: with CFG the two
+    forwards of a step are driven block by block on two compute streams (`cfg_branch_streams`) so that one branch's kernels run
+    while the other waits for an exchange."""
     tr = wan_model.transformer_infer
     n, r = _world(group)
     tr.parallel_attention = UlyssesAttention(group, attn_fn)
@@ -288,7 +290,87 @@ def parallelize_wan(wan_model, group=None, attn_fn=None):
         return post_process(x, group)
 
     tr.infer = new_infer
+    wan_model._cfg_interleave = CfgBranchStreams(wan_model, group, attn_fn)
     return wan_model
+
+
+class CfgBranchStreams:
+    """The conditional and unconditional forwards of a CFG step under Ulysses, interleaved block by block on two compute streams.
+
+    Sequentially (the reference: wan/model.py:197-226 runs one forward after the other, each block waiting for its all-to-alls with
+    torch.cuda.synchronize(), ulysses/attn.py:48,85) every exchange a block cannot hide behind its own kernels is dead time on the GPU: the q / k
+    seq->head exchange in front of the attention, the last head->seq piece behind it.  The two forwards share latents, timestep and weights
+    and are independent until the CFG combine, so here block i of the unconditional branch is enqueued on a second stream right behind
+    block i of the conditional one: whenever one branch's stream waits for its communication stream, the other's GEMMs / attention own
+    the CUs — including the FFN-up GEMM of one branch under the head->seq exchange of the other.  Each branch has its own UlyssesAttention
+    (exchange buffers, communication stream) and, over RCCL, its own process group (= its own communicator, so the two branches' collectives
+    do not queue behind each other).  Every kernel sees the same operands as in the sequential order: results are bit-identical
+    (tests/_dist_gpu_worker.py).  Host-side order of the collectives is the same on every rank (branch A's block i, then branch B's)."""
+
+    def __init__(self, wan_model, group=None, attn_fn=None):
+        self.model, self.group, self.attn_fn = wan_model, group, attn_fn
+        self.enabled = True
+        self._pa_b = None
+        self._streams = None
+        self._group_b = None
+
+    def usable(self, inputs):
+        m = self.model
+        tr = m.transformer_infer
+        return (self.enabled and m.config["enable_cfg"] and m.scheduler.latents.is_cuda and type(tr).__name__ == "WanTransformerInfer"
+                and hasattr(tr.parallel_attention, "attend_blocked"))
+
+    def _setup(self):
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            if dist.get_backend(self.group) == "nccl" and _world(self.group)[0] > 1:
+                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
+                self._group_b = dist.new_group(ranks=ranks, backend="nccl")  # collective call: every rank of the group gets here in its first step
+            else:
+                self._group_b = self.group
+            self._pa_b = UlyssesAttention(self._group_b, self.attn_fn)
+            self._pa_b.split_head2seq = self.model.transformer_infer.parallel_attention.split_head2seq
+        return self._streams
+
+    def forward_pair(self, inputs):
+        """Returns (cond, uncond) noise predictions, each a list-less fp32 tensor as WanModel._forward returns."""
+        m = self.model
+        tr = m.transformer_infer
+        sa, sb = self._setup()
+        pa_a, pa_b = tr.parallel_attention, self._pa_b
+        pa_b.split_head2seq = pa_a.split_head2seq
+        cur = torch.cuda.current_stream()
+        embed, grid_sizes, (x, embed0, seq_lens, freqs, ctx_c) = m.pre_infer.infer(m.pre_weight, inputs, positive=True)
+        ctx_u = m.pre_infer._text_context(m.pre_weight, inputs["text_encoder_output"]["context_null"])
+        xa = pre_process(x, self.group)
+        xb = xa.clone()
+        sa.wait_stream(cur)
+        sb.wait_stream(cur)
+        blocks = m.transformer_weights.blocks
+        try:
+            for i in range(tr.blocks_num):
+                with torch.cuda.stream(sa):
+                    tr.parallel_attention = pa_a
+                    xa = tr.infer_block(blocks[i], grid_sizes, embed, xa, embed0, seq_lens, freqs, ctx_c)
+                with torch.cuda.stream(sb):
+                    tr.parallel_attention = pa_b
+                    xb = tr.infer_block(blocks[i], grid_sizes, embed, xb, embed0, seq_lens, freqs, ctx_u)
+        finally:
+            tr.parallel_attention = pa_a
+        outs = []
+        for st, xs, grp in ((sa, xa, self.group), (sb, xb, self._group_b)):
+            with torch.cuda.stream(st):
+                full = post_process(xs, grp)
+                outs.append(m.post_infer.infer(m.post_weight, full, embed, grid_sizes)[0])
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
+        # allocator bookkeeping: xa / xb were allocated under `cur` and used under a branch stream, the outputs the other way round (the joins
+        # above already order every later use behind both branches)
+        xa.record_stream(sa)
+        xb.record_stream(sb)
+        for t in outs:
+            t.record_stream(cur)
+        return outs[0], outs[1]
 
 
 # ------------------------------------------------------------------------------------------------ HunyuanVideo

@@ -622,6 +622,9 @@ class WanModel:
     def infer(self, inputs):
         """cond forward, uncond forward, fp32 CFG combine (model.py:197-226)."""
         pair = self._forward_pair(inputs) if (self.config["enable_cfg"] and self._pair_ok(inputs)) else None
+        il = getattr(self, "_cfg_interleave", None)
+        if pair is None and il is not None and _cfg(self.config, "cfg_branch_streams", True) and il.usable(inputs):
+            pair = il.forward_pair(inputs)  # Ulysses: the two CFG branches block by block on two compute streams (ulysses.CfgBranchStreams)
         if pair is not None:
             cond, uncond = pair
         else:

@@ -43,8 +43,9 @@ def main():
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
     outs = {}
-    for mode in ("single", "ulysses"):
-        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type="ulysses" if mode == "ulysses" else None)
+    for mode in ("single", "ulysses", "ulysses-sequential"):
+        cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=None if mode == "single" else "ulysses",
+                                 cfg_branch_streams=(mode == "ulysses"))
         model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
         sch = scheduler.WanScheduler(cfg, device="cuda")
         sch.prepare(latents=lat)
@@ -52,11 +53,15 @@ def main():
         sch.step_pre(0)
         model.infer(inputs)
         outs[mode] = sch.noise_pred.float().cpu()
-        if mode == "ulysses":
+        if mode.startswith("ulysses"):
             pa = model.transformer_infer.parallel_attention
             assert pa.copies == 0 and pa._buffers, "the fused driver must take the copy-free blocked exchange path"
+            il = model._cfg_interleave
+            assert (il._pa_b is not None and il._pa_b._buffers and il._pa_b.copies == 0) == (mode == "ulysses"), "CFG-branch interleave: wrong path taken"
         sch.step_post()
         assert torch.isfinite(sch.latents).all()
+    # the two CFG branches interleaved on two compute streams (the default) against the sequential order: same kernels on the same operands
+    assert torch.equal(outs["ulysses"], outs["ulysses-sequential"]), "CFG-branch interleave changed the result"
     from oracle import wan_oracle as O
 
     ref = O.wan_model_infer(wd, dims, lat.to(torch.bfloat16), sch.timesteps[0].cpu(), ctx, ctx_null, cfg["sample_guide_scale"])

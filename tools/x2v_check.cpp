@@ -1070,6 +1070,54 @@ static void run_hbm() {
   }
 }
 
+
+// layout diagnosis of the pre-transposed-V attention kernels (`x2v_check dattn`): query r is aimed at key perm(r) (k = 4 q, every other score
+// ~N(0,1)), V encodes first the key index, then the dv index — the printed tables show which key / which dv column really arrived where.
+static void run_dattn() {
+  Rng rng(5);
+  const int H = 1;
+  for (int64_t S : {64, 128, 200}) {
+    auto q = rand_bf((size_t)S * 128, rng, 1.0f);
+    std::vector<uint16_t> k(q.size()), v1(q.size()), v2(q.size());
+    for (int64_t j = 0; j < S; ++j) {
+      const int64_t r = (j * 37 + 11) % S;  // key j is the target of query r
+      for (int e = 0; e < 128; ++e) {
+        k[j * 128 + e] = f2bf(4.0f * bf2f(q[r * 128 + e]));
+        v1[j * 128 + e] = f2bf((float)(j % 256));
+        v2[j * 128 + e] = f2bf((float)e);
+      }
+    }
+    DevBuf<uint16_t> dq(q), dk(k), dv1(v1), dv2(v2), dout((size_t)S * 128);
+    for (int pass = 0; pass < 2; ++pass) {
+      AttnVt vt;
+      vt.prepare(pass ? dv2.p : dv1.p, 128, S, H);
+      HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
+      attn_any(12, vt, dq.p, dk.p, nullptr, dout.p, S, S, H);
+      HIP_OK(hipDeviceSynchronize());
+      auto o = to_f(dout.host());
+      int bad = 0;
+      for (int64_t r = 0; r < S; ++r) {
+        int64_t jt = -1;
+        for (int64_t j = 0; j < S; ++j)
+          if ((j * 37 + 11) % S == r) jt = j;
+        for (int e = 0; e < 128; ++e) {
+          const float want = pass ? (float)e : (float)(jt % 256), got = o[r * 128 + e];
+          if (fabsf(got - want) > 0.51f && bad < 24) {
+            printf("  dattn S=%lld pass=%d: o[%lld][%d] = %g, want %g (target key %lld)\n", (long long)S, pass, (long long)r, e, got, want, (long long)jt);
+            ++bad;
+          } else if (fabsf(got - want) > 0.51f) ++bad;
+        }
+      }
+      char name[96];
+      snprintf(name, sizeof name, "dattn S=%lld %s", (long long)S, pass ? "dv routing" : "key routing");
+      ErrStat e;
+      e.n = o.size();
+      e.bad = bad;
+      report(name, e);
+    }
+  }
+}
+
 // single-kernel loops for rocprofv3 --pmc passes: `x2v_check pattn <variant> <S> <H> [iters]`, `x2v_check pgemm <M> <N> <K> [iters]`
 static void run_single(int argc, char** argv) {
   Rng rng(31);
@@ -1119,6 +1167,7 @@ int main(int argc, char** argv) {
   if (mode == "rope" || mode == "all") run_rope();
   if (mode == "gemm" || mode == "all") run_gemm();
   if (mode == "attn" || mode == "all") run_attn();
+  if (mode == "dattn") run_dattn();
   if (mode == "fp8" || mode == "all") run_fp8();
   if (mode == "conv" || mode == "all") run_conv();
   if (mode == "hbm") run_hbm();
