@@ -181,10 +181,15 @@ int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt,
 
 /* x2v_attn_fwd_bf16 on a pre-transposed V (x2v_transpose_heads_bf16) — the "ping-pong" kernel the fused block drivers launch for
  * self-attention (transformer_infer.py:369-379): V^T is staged by LDS-DMA and read as plain 16-byte fragments, the softmax scale * log2(e)
- * lives in q.  q_prescaled = 1: q already carries scale*log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16 folded it into
- * q's one rounding); 0: the kernel multiplies and re-rounds q itself. */
+ * lives in q.  flags: X2V_ATTN_VT_PRESCALED — q already carries scale*log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16 folded it
+ * into q's one rounding; without it the kernel multiplies and re-rounds q itself); X2V_ATTN_VT_STAGGER — query block b starts its walk over the
+ * key tiles (b mod 8) tiles in (the online softmax does not care where the walk starts; the L2 does: +1.3 % at Wan-14B 720p).  The result of a
+ * query row then depends on which 256-row block of the launch it sits in (another fp32 summation order, same tolerance): callers that compare
+ * bits across differently partitioned launches (the Ulysses driver) leave it off. */
+#define X2V_ATTN_VT_PRESCALED 1
+#define X2V_ATTN_VT_STAGGER 2
 int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                         int H, int head_dim, float scale, int q_prescaled, void* stream);
+                         int H, int head_dim, float scale, int flags, void* stream);
 
 /* x2v_attn_fwd_bf16_vt over B independent sequences in ONE launch: sequence b uses q / k / V^T / o at b * {q,k,vt,o}_bstride elements from the
  * base pointers (same Sq, Sk, H, strides).  The fused Wan driver runs the conditional and unconditional forwards of a CFG step
@@ -193,7 +198,7 @@ int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk,
  * a multiple of 64 rows), so vt_bstride = rows_per_sequence * 128. */
 int x2v_attn_fwd_bf16_vt_batched(const void* q, int64_t ldq, int64_t q_bstride, const void* k, int64_t ldk, int64_t k_bstride, const void* vt, int64_t ldvt,
                                  int64_t vt_bstride, void* o, int64_t ldo, int64_t o_bstride, int64_t Sq, int64_t Sk, int H, int B, int head_dim, float scale,
-                                 int q_prescaled, void* stream);
+                                 int flags, void* stream);
 
 /* Per-token dynamic fp8 quantisation: s[m] = amax(|x[m,:]|)/448, xq = e4m3fn(x / s) — replaces
  * vllm ops.scaled_fp8_quant(use_per_token_if_dynamic=True) / sgl_kernel.sgl_per_token_quant_fp8

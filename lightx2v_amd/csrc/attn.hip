@@ -321,13 +321,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //   (c) the tile loop is unrolled x2 so that both LDS buffer indices are compile-time: every fragment address is
 //       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
 #ifndef AT_DEFAULT_GEN
-#define AT_DEFAULT_GEN 8
-#endif
-#ifndef AT_DEFAULT_MAP
-#define AT_DEFAULT_MAP 0
-#endif
-#ifndef AT_DEFAULT_ROT
-#define AT_DEFAULT_ROT 0
+#define AT_DEFAULT_GEN 9
 #endif
 struct AttnBatch {
   int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
@@ -1027,17 +1021,26 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
 
 template <int NW, int THR, bool PRESCALED>
 static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                          int H, float scale, hipStream_t st, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0, 0}) {
+                          int H, float scale, hipStream_t st, bool stagger, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0, 0}) {
   // buffer ranges from a head's (and sequence's) first element: K rows of this sequence, the V^T blocks of its ceil(Sk/64) key tiles
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = ((Sk + AT_KV - 1) / AT_KV) * (int64_t)AT_D * AT_KV * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
   dim3 grid((unsigned)((Sq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
-  // work mapping / key-walk rotation (see the kernel): defaults apply once every XCD has more than a residency's worth of workgroups (below that
-  // the plain grid spreads a head's few query blocks over all L2s, which is what a small launch wants); X2V_ATTN_MAP / X2V_ATTN_ROT force a mode (A/B runs)
+  // Work mapping and key-walk rotation (see the kernels), measured on MI355X (profiles/r03_attn_v9_map_rot_matrix_and_pmc.txt):
+  //   * the XCD-aware head-major mapping lifts the L2 hit rate from 73-79 % to 96 % and cuts the L2<->fabric traffic 6-8x at every shape, but it
+  //     only PAYS while the K / V^T streams of the 8 heads then in flight fit the 256 MB Infinity Cache (Ulysses rank of Wan-14B 720p, 5 heads:
+  //     +4 %; Wan-1.3B 480p: +1.5 %); with 40 heads at 720p (8 x 38.7 MB in flight) it is 4-8 % SLOWER than the plain grid, whatever the
+  //     rotation — there the plain grid, which keeps all XCDs on the same ~2 heads, stays.
+  //   * the stagger of the walk (rot mode 1) is worth +1.3 % on the plain grid; it changes the summation order per query block, so it is
+  //     opt-in per call (flag X2V_ATTN_VT_STAGGER) and the drivers that promise partition-independent bits (Ulysses) do not set it.
+  // X2V_ATTN_MAP / X2V_ATTN_ROT force a mode (A/B runs).
   static const int map_env = [] { const char* e = getenv("X2V_ATTN_MAP"); return e ? atoi(e) : -1; }();
   static const int rot_env = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
-  const bool big = (uint64_t)grid.x * grid.y * grid.z >= 2048;
-  const int map_mode = map_env >= 0 ? map_env : (big ? AT_DEFAULT_MAP : 0), rot_mode = rot_env >= 0 ? rot_env : (big ? AT_DEFAULT_ROT : 0);
+  const uint64_t nwg = (uint64_t)grid.x * grid.y * grid.z;
+  const int64_t heads_in_flight = (int64_t)H * B < 8 ? (int64_t)H * B : 8;
+  const bool mall_resident = heads_in_flight * Sk * (2 * AT_D * 2) <= (224ll << 20);
+  const int map_mode = map_env >= 0 ? map_env : ((nwg >= 512 && mall_resident) ? 1 : 0);
+  const int rot_mode = rot_env >= 0 ? rot_env : ((stagger && Sk >= 16 * AT_KV) ? 1 : 0);
   bs.xcd_remap = (map_mode & 0xff) | ((rot_mode & 0xff) << 8);
   static const int gen_env = [] { const char* e = getenv("X2V_ATTN_GEN"); return e ? atoi(e) : AT_DEFAULT_GEN; }();  // 8: 32x32x16 MFMA, 9: 16x16x32
   auto kern = gen_env == 9 ? (rot_mode ? attn_fwd_v9_kernel<NW, THR, PRESCALED, true> : attn_fwd_v9_kernel<NW, THR, PRESCALED, false>)
@@ -1062,7 +1065,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_transpose_heads_bf16(c
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo,
-                                                                           int64_t Sq, int64_t Sk, int H, int head_dim, float scale, int q_prescaled, void* stream) {
+                                                                           int64_t Sq, int64_t Sk, int H, int head_dim, float scale, int flags, void* stream) {
   if (Sq == 0 && Sk > 0 && H > 0) return X2V_OK;  // no query rows: nothing to write (empty shard)
   X2V_REQUIRE(q && k && vt && o, X2V_E_ARG, "attn_vt: null pointer");
   X2V_REQUIRE(head_dim == AT_D, X2V_E_SHAPE, "attn_vt: head_dim=%d (only 128 is built)", head_dim);
@@ -1071,10 +1074,11 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
               "attn_vt: rows must be 16-byte aligned, ldvt a multiple of 64");
   X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D, X2V_E_SHAPE, "attn_vt: token stride smaller than H*128");
   if (scale <= 0.f) scale = 0.08838834764831845f;
-  X2V_REQUIRE((q_prescaled & ~1) == 0, X2V_E_ARG, "attn_vt: q_prescaled must be 0 or 1");
+  X2V_REQUIRE((flags & ~3) == 0, X2V_E_ARG, "attn_vt: flags = X2V_ATTN_VT_PRESCALED | X2V_ATTN_VT_STAGGER");
   hipStream_t st = (hipStream_t)stream;
-  return (q_prescaled & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st)
-                           : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st);
+  const bool stagger = (flags & 2) != 0;
+  return (flags & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger)
+                     : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger);
 }
 
 // B independent sequences in one launch (grid z): sequence b reads q / k / V^T and writes o at b * {q,k,vt,o}_bstride elements from the base
@@ -1082,7 +1086,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
 // the stacked rows), vt_bstride = rows_per_sequence * 128 and rows_per_sequence % 64 == 0.
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt_batched(const void* q, int64_t ldq, int64_t q_bstride, const void* k, int64_t ldk, int64_t k_bstride,
                                                                                    const void* vt, int64_t ldvt, int64_t vt_bstride, void* o, int64_t ldo, int64_t o_bstride,
-                                                                                   int64_t Sq, int64_t Sk, int H, int B, int head_dim, float scale, int q_prescaled, void* stream) {
+                                                                                   int64_t Sq, int64_t Sk, int H, int B, int head_dim, float scale, int flags, void* stream) {
   if (Sq == 0 && Sk > 0 && H > 0 && B > 0) return X2V_OK;
   X2V_REQUIRE(q && k && vt && o, X2V_E_ARG, "attn_vt_batched: null pointer");
   X2V_REQUIRE(head_dim == AT_D, X2V_E_SHAPE, "attn_vt_batched: head_dim=%d (only 128 is built)", head_dim);
@@ -1092,12 +1096,13 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt_batch
               X2V_E_ALIGN, "attn_vt_batched: rows must be 16-byte aligned, ldvt a multiple of 64, vt_bstride whole 64-key blocks");
   X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D && ldvt >= (B - 1) * (vt_bstride / AT_D) + Sk, X2V_E_SHAPE,
               "attn_vt_batched: token stride smaller than H*128, or ldvt smaller than the stacked sequences");
-  X2V_REQUIRE((q_prescaled & ~1) == 0, X2V_E_ARG, "attn_vt_batched: q_prescaled must be 0 or 1");
+  X2V_REQUIRE((flags & ~3) == 0, X2V_E_ARG, "attn_vt_batched: flags = X2V_ATTN_VT_PRESCALED | X2V_ATTN_VT_STAGGER");
   if (scale <= 0.f) scale = 0.08838834764831845f;
   const AttnBatch bs{q_bstride, k_bstride, vt_bstride, o_bstride, 0};
   hipStream_t st = (hipStream_t)stream;
-  return (q_prescaled & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, B, bs)
-                           : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, B, bs);
+  const bool stagger = (flags & 2) != 0;
+  return (flags & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger, B, bs)
+                     : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger, B, bs);
 }
 
 // variant: 0 = default (= 6); lazy-rescale threshold of the pipelined kernel: 4 = eager rescale (every tile), 5 = threshold 4, 6 = threshold 8

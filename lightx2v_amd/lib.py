@@ -187,6 +187,7 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
 
 
 ATTN_Q_PRESCALED = 0x100
+ATTN_STAGGER = 0x200  # x2v.h X2V_ATTN_VT_STAGGER: query block b starts its key walk (b mod 8) tiles in (single-GPU self-attention of the fused drivers)
 ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
 #                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
@@ -345,7 +346,7 @@ def gemm(x, weight_nk, bias=None, epilogue=EPI_NONE, resid=None, gate=None, out=
     return out2
 
 
-def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=None, prescaled=False, scale=0.0, all_rows_query=True, one_launch=None, timed=None):
+def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=None, prescaled=False, scale=0.0, all_rows_query=True, one_launch=None, timed=None, stagger=False):
     """`batch` independent self-attentions over stacked rows (x2v_attn_fwd_bf16_vt_batched): q, k, out are [batch * rows_per_seq, H*128]
     row-major (any token stride), sequence b in rows [b * rows_per_seq, b * rows_per_seq + seq_len); vt = V^T [H, batch * rows_per_seq / 64,
     128, 64] over the stacked rows (gemm_vt / transpose_heads of the stacked v; rows_per_seq % 64 == 0).  Keys are the first seq_len rows of
@@ -354,7 +355,8 @@ def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=Non
     one_launch: True = all sequences in one launch (grid z), False = one launch per sequence, None = by size — measured on MI355X: one
     launch wins when a sequence alone already fills the chip many times over (Wan-14B 720p, 11 840 workgroups each: -0.85 %), and loses
     when it does not (Wan-1.3B 480p, 960 workgroups each: +2 %, the two sequences' K/V share the L2s).  Same results either way.
-    timed: optional callable(fn) that runs fn() — called once per kernel launch (bench.py's per-launch HIP-event timer)."""
+    timed: optional callable(fn) that runs fn() — called once per kernel launch (bench.py's per-launch HIP-event timer).
+    stagger: X2V_ATTN_VT_STAGGER (see x2v.h): same for every launch form here, since a row's query block index does not depend on it."""
     q2, k2 = _row2d(_bf16(q, "q"), "q"), _row2d(_bf16(k, "k"), "k")
     rows = batch * rows_per_seq
     if rows_per_seq % 64 or not 0 < seq_len <= rows_per_seq or q2.shape[0] != rows or k2.shape[0] != rows or min(q2.shape[1], k2.shape[1]) < num_heads * 128:
@@ -372,7 +374,7 @@ def attention_batched(q, k, vt, num_heads, batch, rows_per_seq, seq_len, out=Non
     for b0, nb in ([(0, batch)] if one_launch else [(b, 1) for b in range(batch)]):
         def launch(b0=b0, nb=nb):
             _check(_lib.x2v_attn_fwd_bf16_vt_batched(q2.data_ptr() + 2 * b0 * qb, q2.stride(0), qb, k2.data_ptr() + 2 * b0 * kb, k2.stride(0), kb, vt.data_ptr() + 2 * b0 * vb, rows,
-                                                     vb, out2.data_ptr() + 2 * b0 * ob, out2.stride(0), ob, sq, seq_len, num_heads, nb, 128, scale, int(bool(prescaled)), _stream()),
+                                                     vb, out2.data_ptr() + 2 * b0 * ob, out2.stride(0), ob, sq, seq_len, num_heads, nb, 128, scale, int(bool(prescaled)) | (2 if stagger else 0), _stream()),
                    "attn_fwd_vt_batched")
 
         timed(launch) if timed is not None else launch()
@@ -449,7 +451,7 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
             raise X2VError(f"attention: vt must be the contiguous bf16 [H, ceil(Sk/64), 128, 64] tensor of transpose_heads, got {tuple(vt.shape)}")
         _check(
             _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[1] * 64, _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
-                                      1 if (variant & ATTN_Q_PRESCALED) else 0, _stream()),
+                                      (1 if (variant & ATTN_Q_PRESCALED) else 0) | (2 if (variant & ATTN_STAGGER) else 0), _stream()),
             "attn_fwd_vt",
         )
         return out2

@@ -329,7 +329,7 @@ class WanTransformerInfer:
             for b in range(2):  # token b*Sp + i of either forward sits at grid position i
                 rows = slice(b * Sp, b * Sp + S)
                 lib.rmsnorm_rope_(q[rows], k[rows], weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
-            attn = lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True, timed=lambda fn: self._timed("self", fn))
+            attn = lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True, stagger=True, timed=lambda fn: self._timed("self", fn))
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
         if pa is None and fast and not mmkw and hasattr(weights.self_attn_v, "apply_vt"):
             v, vt = None, weights.self_attn_v.apply_vt(n1, self.num_heads)  # V^T from the v projection's epilogue (the attention kernel's operand)
@@ -343,7 +343,8 @@ class WanTransformerInfer:
             # the ping-pong kernel reads V^T; transposed outside the timed launch so the hook times the attention kernel alone
             if vt is None and fast:
                 vt = lib.transpose_heads(v, self.num_heads)
-            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant, vt=vt))
+            # single GPU: the staggered key walk (x2v.h X2V_ATTN_VT_STAGGER); the pair pass sets it too, so the two stay bit-identical
+            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant | (lib.ATTN_STAGGER if fast else 0), vt=vt))
         else:
             attn = pa(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)
         return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)

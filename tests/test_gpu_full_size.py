@@ -114,13 +114,19 @@ def test_attention_wan14b_720p_full_size(lib):
     _plant(q32, k, 0, S, PLANTS)
     q_pre = (q32 * lib.ATTN_PRESCALE).to(torch.bfloat16)
     vt = lib.transpose_heads(v, H)
-    out = lib.attention(q_pre, k, None, H, variant=lib.ATTN_FAST | lib.ATTN_Q_PRESCALED, vt=vt)
+    var = lib.ATTN_FAST | lib.ATTN_Q_PRESCALED | lib.ATTN_STAGGER  # exactly what WanTransformerInfer.infer_self_attn passes on one GPU
+    out = lib.attention(q_pre, k, None, H, variant=var, vt=vt)
     assert torch.isfinite(out.float()).all()
     rows = sample_rows(S, 192, must=[r for r, _ in PLANTS])
     k_cpu, v_cpu = k.cpu(), v.cpu()
     _check_attention_rows(lib, out[rows.cuda()], q32[rows.cuda()].cpu(), k_cpu, v_cpu, H, "attn 14B 720p S=75600 H=40")
     for r, j in PLANTS:  # key-index mapping pinned independently of the oracle
         assert (out[r, :128].float() - v[j, :128].float()).abs().max().item() <= 2 ** -6, (r, j)
+    # the walk without the stagger (what the Ulysses driver launches): same values up to the fp32 summation order
+    out0 = lib.attention(q_pre, k, None, H, variant=lib.ATTN_FAST | lib.ATTN_Q_PRESCALED, vt=vt)
+    assert torch.equal(out0[:256], out[:256]), "query block 0 starts at tile 0 either way"
+    assert rel_l2(out0, out) <= 5e-3 and not torch.equal(out0, out)
+    del out0
     # the kernel folding the scale itself, and the general entry on row-major V, on a few query blocks of the same problem
     blk = torch.cat([torch.arange(0, 256), torch.arange(S - 80, S)]).cuda()
     qb = q32.to(torch.bfloat16)
@@ -147,7 +153,7 @@ def test_attention_cfg_pair_launch_full_size(lib):
         _plant(q32, k, b * Sp, S, PLANTS[b::2])
     q_pre = (q32 * lib.ATTN_PRESCALE).to(torch.bfloat16)
     vt = lib.transpose_heads(v, H)
-    out = lib.attention_batched(q_pre, k, vt, H, B, Sp, S, prescaled=True)
+    out = lib.attention_batched(q_pre, k, vt, H, B, Sp, S, prescaled=True, stagger=True)
     assert torch.isfinite(out.float()).all(), "padding rows must be written"
     for b in range(B):
         rows = sample_rows(S, 96, seed=10 + b, must=[r for r, _ in PLANTS[b::2]])
@@ -174,7 +180,7 @@ def test_attention_hunyuan_720p_129f_full_size(lib):
     for r, j in plants:
         k[j, :128] = (q32[r, :128] * 3.0).to(torch.bfloat16)
     out = torch.zeros(L, D, dtype=torch.bfloat16, device="cuda")
-    var = lib.ATTN_FAST | lib.ATTN_Q_PRESCALED
+    var = lib.ATTN_FAST | lib.ATTN_Q_PRESCALED | lib.ATTN_STAGGER
     lib.attention(q[:S], k[:S], v[:S], H, 128, out=out[:S], variant=var)
     lib.attention(q[S:], k[S:], v[S:], H, 128, out=out[S:], variant=var)
     assert torch.isfinite(out.float()).all()

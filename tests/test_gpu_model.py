@@ -289,8 +289,9 @@ def test_baseline_config1_full_run_vs_oracle():
     # the tolerances above anchored: the SAME loop evaluated in fp32 with no bf16 rounding points is the truth; the HIP
     # path may be at most 1.5 x as far from it as the reference's own bf16 CPU path is (both are bf16 realisations of that graph)
     tru_steps = []
-    with O.truth_precision(torch.float32):
-        O.denoise_loop(O.upcast(wd), dims, lat, O.upcast(ctx), O.upcast(ctx_null), steps, shift, guide, step_callback=lambda i, x: tru_steps.append(x.clone()))
+    with O.truth_precision(torch.float32, device="cuda"):  # the oracle's statements in fp32 through plain PyTorch on the GPU (the scheduler stays on the host)
+        O.denoise_loop(O.upcast(wd, device="cuda"), dims, lat, O.upcast(ctx, device="cuda"), O.upcast(ctx_null, device="cuda"), steps, shift, guide,
+                       step_callback=lambda i, x: tru_steps.append(x.clone()))
     for i in (0, steps - 1):
         e_hip, e_ref = rel_l2(got_steps[i], tru_steps[i]), rel_l2(ref_steps[i], tru_steps[i])
         record(f"config #1 loop, latents after step {i + 1}", err_hip_vs_fp32=e_hip, err_oracle_vs_fp32=e_ref, hip_vs_oracle=rel_l2(got_steps[i], ref_steps[i]))
@@ -310,14 +311,15 @@ def test_wan13b_block_and_forward_errors_are_anchored_to_fp32_truth():
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     t = torch.tensor(640)
     latb = lat.to(torch.bfloat16)
-    wd32, ctx32 = O.upcast(wd), O.upcast(ctx)
+    wd32, ctx32 = O.upcast(wd, device="cuda"), O.upcast(ctx, device="cuda")
     embed_o, grid, x_o, embed0_o, _, context_o = O.wan_pre_infer(wd, dims, latb, t, ctx)
     freqs = O.rope_freqs_table(128)
     ref_blk = O.wan_block(wd, 0, dims, grid, x_o.clone(), embed0_o, freqs, context_o)
     ref_fwd = O.wan_forward(wd, dims, latb, t, ctx)
-    with O.truth_precision(torch.float32):
-        tru_blk = O.wan_block(wd32, 0, dims, grid, x_o.float(), embed0_o.float(), freqs, context_o.float())
-        tru_fwd = O.wan_forward(wd32, dims, latb.float(), t, ctx32)
+    with O.truth_precision(torch.float32, device="cuda"):  # plain PyTorch fp32 on the GPU
+        tru_blk = O.wan_block(wd32, 0, dims, grid, x_o.float().cuda(), embed0_o.float().cuda(), freqs.cuda(), context_o.float().cuda()).cpu()
+        tru_fwd = O.wan_forward(wd32, dims, latb.float().cuda(), t, ctx32).cpu()
+    del wd32
     cfg = wan.default_config(dims, target_shape=ts, target_video_length=17, infer_steps=4)
     model = wan.WanModel(cfg, _to_dev(wd))
     sch = scheduler.WanScheduler(cfg, device="cuda")

@@ -1144,9 +1144,36 @@ static void run_single(int argc, char** argv) {
     fill_random(w, rng, 0.02f);
     fill_random(b, rng, 0.02f);
     const int variant = argc > 6 ? atoi(argv[6]) : 0;
-    double ms = time_ms(iters, [&] { X2V_OKAY(x2v_gemm_bf16_variant(x.p, K, w.p, K, b.p, y.p, N, M, N, K, X2V_EPI_NONE, nullptr, 0, nullptr, variant, nullptr)); });
-    printf("pgemm variant=%d M=%lld N=%d K=%d: %.3f ms %.1f TFLOP/s\n", variant, (long long)M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
+    const int epi = argc > 7 ? atoi(argv[7]) : X2V_EPI_NONE;  // 2 = gate-residual (y doubles as resid), 1 = GELU
+    DevBuf<uint16_t> gate(N);
+    fill_random(gate, rng, 0.5f);
+    if (epi == X2V_EPI_RESIDUAL) fill_random(y, rng, 1.f);
+    double ms = time_ms(iters, [&] {
+      X2V_OKAY(x2v_gemm_bf16_variant(x.p, K, w.p, K, b.p, y.p, N, M, N, K, epi, epi == X2V_EPI_RESIDUAL ? y.p : nullptr, N, epi == X2V_EPI_RESIDUAL ? gate.p : nullptr, variant, nullptr));
+    });
+    printf("pgemm variant=%d epi=%d M=%lld N=%d K=%d: %.3f ms %.1f TFLOP/s\n", variant, epi, (long long)M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
   }
+}
+
+// `x2v_check pattnb <S> <H> [iters]`: the self-attention launch with K stored HEAD-BLOCKED [H][S][128] (a head's keys contiguous: row stride 256 B
+// instead of H * 256 B), expressed through the batched entry (one "sequence" per head, H = 1 inside) — an experiment on whether the strided K
+// rows are what the XCD-aware mapping stumbles over.
+static void run_pattnb(int argc, char** argv) {
+  Rng rng(31);
+  const int64_t S = atoll(argv[2]);
+  const int H = atoi(argv[3]);
+  const int iters = argc > 4 ? atoi(argv[4]) : 3;
+  const int64_t Sp = (S + 63) / 64 * 64;
+  DevBuf<uint16_t> q((size_t)S * H * 128), kb((size_t)H * S * 128), v((size_t)S * H * 128), o((size_t)S * H * 128);
+  fill_random(q, rng, 1.f);
+  fill_random(kb, rng, 1.f);
+  fill_random(v, rng, 1.f);
+  AttnVt vt;
+  vt.prepare(v.p, H * 128, S, H);
+  double ms = time_ms(iters, [&] {
+    X2V_OKAY(x2v_attn_fwd_bf16_vt_batched(q.p, H * 128, 128, kb.p, 128, S * 128, vt.vt->p, (int64_t)H * Sp, Sp * 128, o.p, H * 128, 128, S, S, 1, H, 128, 0.f, 0, nullptr));
+  });
+  printf("pattnb (K head-blocked) S=%lld H=%d: %.3f ms %.1f TFLOP/s\n", (long long)S, H, ms, 4.0 * S * S * H * 128 / ms / 1e9);
 }
 
 int main(int argc, char** argv) {
@@ -1154,6 +1181,11 @@ int main(int argc, char** argv) {
   if (mode == "pattn" || mode == "pgemm") {
     X2V_OKAY(x2v_init(0));
     run_single(argc, argv);
+    return 0;
+  }
+  if (mode == "pattnb") {
+    X2V_OKAY(x2v_init(0));
+    run_pattnb(argc, argv);
     return 0;
   }
   X2V_OKAY(x2v_init(0));
