@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--cpu-baseline-rows", type=int, default=256, help="query rows of the benched block the CPU baseline evaluates (scaled by S / rows)")
     ap.add_argument("--no-cpu-config1", action="store_true", help="skip the end-to-end CPU run of BASELINE config #1 beside the baseline (~80 s on 128 threads)")
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
-    ap.add_argument("--no-cfg-pair", action="store_true", help="run the conditional and unconditional forwards of a step separately (default: one pass over both)")
+    ap.add_argument("--no-cfg-pair", action="store_true", help="run the conditional and unconditional forwards of a step separately (default: by size)")
+    ap.add_argument("--cfg-pair", action="store_true", help="force the one-pass form of the two CFG forwards (default: by size — on for 14B 720p, off for 1.3B 480p)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule of config #4 (no CFG, denoising_step_list 1000/750/500/250, shift 5)")
@@ -250,7 +251,7 @@ def main():
         extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
     cfg = wan.default_config(
         dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
-        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=(False if args.no_cfg_pair else "auto"), **extra,
+        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=(False if args.no_cfg_pair else True if args.cfg_pair else "auto"), **extra,
     )
     if world > 1 and dims["num_heads"] % world != 0:
         raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
@@ -325,16 +326,15 @@ def main():
     flop_launch = flop_self
     achieved = flop_launch / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
     traffic, traffic_note = None, "no PMC summary for this shape under profiles/"
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_attn_traffic.json")
-    if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_attn_traffic.json")
+    # PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py: this very command under --pmc FETCH_SIZE / WRITE_SIZE, the rows of this
+    # kernel instantiation averaged per launch); the summary they wrote for THIS launch form is reported, never one of another form
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_attn_traffic.json")
     if world == 1 and os.path.exists(pmc_path):
         with open(pmc_path) as fh:
             pmc = json.load(fh)
-        if pmc.get("tokens") == S and pmc.get("heads") == heads_local:
-            # the PMC passes profiled the launch of ONE forward's layer; a launch of this run covers `forwards_per_launch` of them
-            traffic = pmc["hbm_bytes_per_launch"] * forwards_per_launch
-            traffic_note = (f"{forwards_per_launch:g} x the per-forward launch that was profiled. " if abs(forwards_per_launch - 1.0) > 1e-6 else "") + pmc["note"]
+        if pmc.get("tokens") == S and pmc.get("heads") == heads_local and abs(pmc.get("forwards_per_launch", 0) - forwards_per_launch) < 1e-6:
+            traffic = pmc["hbm_bytes_per_launch"]
+            traffic_note = pmc["note"]
     model_label = {"wan2.1-14b": "Wan2.1-14B", "wan2.1-1.3b": "Wan2.1-1.3B"}.get(wl["model"], wl["model"])
     res_label = {"wan14b_720px81f": "720p 81f", "wan1.3b_480px49f": "480p 49f", "wan1.3b_256x256x17f": "256x256 17f"}.get(args.workload, args.workload)
     fast_attn = not args.ref_rounding
@@ -369,7 +369,7 @@ def main():
             "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
         },
         "roofline": {
-            "kernel": ("x2v::attn_fwd_v8_kernel<8, 8, true> (ping-pong, q prescaled; self-attention launches"
+            "kernel": ("x2v::attn_fwd_v9_kernel<8, 8, true, true> (ping-pong on 16x16x32 MFMA, q prescaled, staggered key walk; self-attention launches"
                        + ("; one launch = both CFG forwards of a layer)" if abs(forwards_per_launch - 2.0) < 1e-6 else ")") if fast_attn
                        else "x2v::attn_fwd_pipe_kernel<8, 8> (reference-rounding mode; self-attention launches)"),
             "bound": "mfma",

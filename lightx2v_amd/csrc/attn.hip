@@ -6,22 +6,20 @@
 // git history; DESIGN.md §4.1 keeps their measurements):
 //   * attn_fwd_pipe_kernel ("v2"): the general entry on row-major q/k/v (x2v_attn_fwd_bf16): what cross-attention, the text refiner and
 //     the reference-rounding mode launch.  Per-wave software pipeline, K by LDS-DMA, V^T fragments by ds_read_b64_tr_b16.
-//   * attn_fwd_v8_kernel ("ping-pong"): what the fused block drivers launch for self-attention (x2v_attn_fwd_bf16_vt) on a
+//   * attn_fwd_v9_kernel ("ping-pong"): what the fused block drivers launch for self-attention (x2v_attn_fwd_bf16_vt) on a
 //     pre-transposed V and a q that already carries scale*log2(e).
 // Common structure:
 //   * one workgroup = 8 waves x 32 query rows of ONE head; K/V tiles of 64 keys are staged once per workgroup in LDS and shared
 //     by all waves; double buffered.
-//   * "swapped" QK^T: S^T = K . Q^T with v_mfma_f32_32x32x16_bf16, K fragment as the A operand.  Each lane
-//     then owns ONE query column (lane&31) and 32 of the tile's 64 keys, so the whole online softmax
-//     (max, exp2, row sum, rescale of O) is lane-local; the two half-waves exchange one max per tile (v_permlane32_swap).
-//   * P never leaves registers: the accumulator layout of S^T (per lane: keys {0-3,8-11,..}+4*half) IS a valid
-//     B-operand layout for the PV MFMA as long as the V^T fragment enumerates keys in the same order — the
-//     reduction index of an MFMA may be permuted freely if both operands agree.
-//   * O^T accumulates as 4 MFMA tiles of [32 dv][32 queries] per wave (64 accumulator registers).
-//   * LDS image of K: [64 keys][256 B] with the 16-byte chunk index XORed by (key & 15) (conflict-free
-//     ds_read_b128 over its 16-lane service groups); the swizzle is applied on the per-lane DMA SOURCE address.
-//   * q-block-fastest grid: co-resident workgroups walk the same head's K/V stream in near lock-step, so
-//     each XCD's L2 serves a K/V tile to its 32 CUs from one fill.
+//   * "swapped" QK^T: S^T = K . Q^T, K fragment as the MFMA's A operand (v2: 32x32x16, a lane owns ONE query column and 32 of the tile's
+//     64 keys; ping-pong: 16x16x32, a lane owns one query column in each of two groups and 16 of the 64 keys), so max, exp2, row sum and the
+//     rescale of O are lane-local up to one (v2) / three (ping-pong) cross-lane swaps of the row maxima per tile.
+//   * P never leaves registers: the accumulator layout of S^T IS a valid B-operand layout for the PV MFMA as long as the V^T fragment
+//     enumerates keys in the same order — the reduction index of an MFMA may be permuted freely if both operands agree.
+//   * LDS image of K: [64 keys][256 B] with the 16-byte chunk index XORed by a hash of the key (conflict-free ds_read_b128 over its 16-lane
+//     service groups); the swizzle is applied on the per-lane DMA SOURCE address.
+//   * q-block-fastest grid: co-resident workgroups walk the same head's K/V stream close together, so an XCD's L2 serves a K/V tile to
+//     several of its CUs from one fill (launch_attn_vt has the measured story of the XCD-aware alternative).
 #include "x2v_common.h"
 
 namespace x2v {
@@ -297,356 +295,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 #undef AT_TILE
 
 // ------------------------------------------------------------------------------------------------
-// "ping-pong" (v8): every wave alternates a pure matrix half-step {QK^T(t) then PV(t-1): 32 MFMAs + their LDS fragment reads} with a
-// pure vector half-step {softmax(t): row max, exp2, row sum, bf16 pack}, and the two waves of a SIMD (wid and wid + NW/2) run half a
-// step apart — while one occupies the matrix pipe the other occupies the VALU port.  In phase (v2) both waves want the VALU during
-// the softmax (exp2 is quarter rate) and both want the matrix pipe during PV; the measured decomposition showed the parts
-// adding up rather than overlapping.
-//   * V is consumed pre-transposed (x2v_transpose_heads_bf16: V^T [H][S/64][128 dv][64 keys]), so both operand tiles arrive by LDS-DMA
-//     into [rows][128 B]-swizzled images and both fragments are plain ds_read_b128 (K rows are read through a bit-2/bit-3 swap so
-//     that a half-wave's P registers are 8 consecutive keys = the k-order of a 16-byte V^T fragment);
-//   * one barrier per half-step; data movement is by global half-step g, identical for all waves: even g = 2t issues
-//     K(t+1) and V^T(t) (both double buffered), the odd half-step that follows ends with s_waitcnt vmcnt(0).  Only the waves in
-//     their vector half-step issue the DMA (an LDS-DMA issue costs ~60 cycles between bare MFMAs, about half in VALU-only gaps);
-//   * scores leave the MFMA already relative to the running max (C = -m_run, known before QK^T(t) starts because softmax(t-1)
-//     is the same wave's previous half-step), q carries scale*log2(e) (PRESCALED: folded in by the producer), so P = exp2(S') with
-//     no per-score FMA; rescale stays lazy (cold branch, threshold RESCALE_THR in base-2 units);
-//   * one score buffer: nothing spills at 2 waves per SIMD.
-// Round 2 (what the .s of the round-1 body showed in the matrix half-step; +3.9 %, profiles/r02_attn_pingpong_tune_ab.log):
-//   (a) hipcc computed the second score chain IN the registers of the -m tuple and copied it out afterwards (s_nop 8 + 8 v_mov_b64
-//       between QK^T and PV, and 8 more v_mov_b64 per tile to restore -m): the first MFMA of each chain now goes through an asm
-//       statement whose output is early-clobber, so -m stays a pure input and nothing is copied;
-//   (b) the 19 row-sum adds had been sunk behind the last PV MFMA (inside the matrix half-step, at raised priority): they are pinned
-//       into the vector half-step;
-//   (c) the tile loop is unrolled x2 so that both LDS buffer indices are compile-time: every fragment address is
-//       register + immediate (12 v_add_u32 per tile gone from the matrix half-step).
-#ifndef AT_DEFAULT_GEN
-#define AT_DEFAULT_GEN 9
-#endif
-struct AttnBatch {
-  int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
-  int xcd_remap;        // bits 0-7: work mapping (0 the grid as dispatched, 1 XCD-aware head-major, 2 XCD-aware with two heads in flight); bits 8-15: key-walk rotation mode
-};
-
-template <int NW, int RESCALE_THR, bool PRESCALED, bool ROT>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
-                                                                   const unsigned short* __restrict__ Kp, int64_t ldk,
-                                                                   const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O,
-                                                                   int64_t ldo, int64_t Sq, int64_t Sk, float scale_log2e, unsigned k_bytes,
-                                                                   unsigned v_bytes, AttnBatch bs) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Work mapping.  The launch grid is (query blocks, heads, sequences) and the dispatcher hands workgroup number
-  // L = x + gx (y + gy z) to XCD L % 8 (observed placement; a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch").  Taken
-  // as it comes, the 64 workgroups resident on an XCD (32 CUs x 2) belong to ~2 heads and every head's K / V^T stream (38.7 MB at 720p)
-  // is pulled through all eight 4 MiB L2s: rocprofv3 showed 99 GB of L2<->fabric traffic per launch against 3.1 GB algorithmic
-  // (profiles/r02_pmc_attn_*).  XCD-aware form: XCD c owns the contiguous range c of the (sequence, head, query block) list (bijective
-  // for any count), so its resident workgroups are consecutive query blocks of ONE head that walk the same K / V^T tiles at about the same
-  // time — a tile is filled into that L2 once per generation of workgroups instead of once per drifting pair of heads.
-  int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
-  const int map_mode = bs.xcd_remap & 0xff;
-  if (map_mode) {
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned nwg = gx * gy * gridDim.z;
-    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned xcd = L & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
-    unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
-    if (map_mode == 2 && (gy & 1u) == 0 && r8 == 0 && ((gy * gridDim.z) & 15u) == 0) {
-      // two heads in flight per XCD: consecutive workgroups alternate between the heads of a pair
-      const unsigned pair = id / (2 * gx), w = id % (2 * gx);
-      id = (2 * pair + (w & 1u)) * gx + (w >> 1);
-    }
-    qblk = (int)(id % gx);
-    const unsigned hz = id / gx;
-    head = (int)(hz % gy);
-    seq = (int)(hz / gy);
-  }
-  // seq = independent sequence of a batch (the two CFG branches of a denoise step): element offsets of its q / k / V^T / o
-  Q += (int64_t)seq * bs.q;
-  Kp += (int64_t)seq * bs.k;
-  VTp += (int64_t)seq * bs.vt;
-  O += (int64_t)seq * bs.o;
-  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
-  constexpr int DEPTH = 4;  // fragment prefetch depth (slots ahead of the consuming MFMA)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fl = lane & 31, hi = lane >> 5;
-  const int64_t q0 = (int64_t)qblk * (NW * 32) + wid * 32;
-  const unsigned short* Kh = Kp + (int64_t)head * AT_D;
-  const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;
-
-  bf16x8_t qf[8];
-  {
-    int64_t qr = q0 + fl;
-    qr = qr < Sq ? qr : Sq - 1;
-    const unsigned short* qp = Q + qr * ldq + (int64_t)head * AT_D + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-    if constexpr (!PRESCALED) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        bf16x8_t v = qf[ks];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
-        qf[ks] = v;
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
-  // LDS-DMA of K [64 keys][256 B] and V^T [128 dv][128 B] tiles, 1 KiB pieces (4 K rows / 8 V^T rows).  Only the upper half of the
-  // waves moves data (all 16 pieces per operand, during their vector half-step); their pieces are wl + (NW/2) j: the rows of a wave's
-  // pieces differ by a multiple of 16, so the swizzled source chunk is the same and ONE per-lane offset register per operand serves
-  // all pieces (the piece stride travels in the scalar offset with the tile offset).
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, k_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, v_bytes, 0x00020000);
-  constexpr int NDW = NW / 2;     // waves that issue
-  constexpr int NPC = 16 / NDW;   // pieces per issuing wave and operand
-  const int wl = wid & (NW / 2 - 1);
-  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_piece_bytes = (unsigned)(4 * NDW * ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * 128);
-  const int krow_w = wl * 4 + (lane >> 4), vrow_w = wl * 8 + (lane >> 3);
-  const unsigned k_voff = (unsigned)(krow_w * ldk * 2) + (unsigned)(((lane & 15) ^ (krow_w & 15)) << 4);
-  const unsigned v_voff = (unsigned)(vrow_w * 128) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
-#define A8_DMA_K(SOFF_, BUF_)                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rk, (at_lds_ptr_t)(smem + K_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, k_voff, (SOFF_) + j * k_piece_bytes, 0, 0);
-#define A8_DMA_V(SOFF_, BUF_)                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < NPC; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                  \
-      rv, (at_lds_ptr_t)(smem + V_OFF + (BUF_) * AT_K_BYTES + (wl + NDW * j) * 1024), 16, v_voff, (SOFF_) + j * v_piece_bytes, 0, 0);
-
-  // fragment offsets: K rows read through the bit-2/bit-3 swap so a half-wave's P registers are 8 consecutive keys
-  int kaddr[8], vaddr[4];
-  const int krow_rd = (fl & 0x13) | ((fl & 4) << 1) | ((fl & 8) >> 1);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = krow_rd * 256 + (((hi ^ (krow_rd & 15)) << 4) ^ (ks << 5));
-#pragma unroll
-  for (int g = 0; g < 4; ++g) vaddr[g] = fl * 128 + ((((g << 1) | hi) ^ ((fl >> 1) & 7)) << 4);
-
-  f32x16_t oacc[4], sc[2], negm;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    negm[e] = 0.f;
-#pragma unroll
-    for (int T = 0; T < 4; ++T) oacc[T][e] = 0.f;
-  }
-  float m_run = 0.f;
-  float lsum[4] = {0.f, 0.f, 0.f, 0.f};
-  bool force = true;  // first tile: adopt its row max in either direction
-  unsigned pw[16];
-  const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
-  // Key-tile walk: logical tile t of this workgroup is physical tile (t + rot) mod nt.  The online softmax does not care where the walk
-  // starts; what does is the L2: with the XCD-aware mapping the 64 workgroups resident on an XCD start together and ask for the SAME K / V^T
-  // lines at the same instant — every tile is a cold miss that all of them wait out together.  A start offset that depends on the query
-  // block de-phases them: one workgroup of a phase group takes the miss, its followers hit.  rot is a function of (qblk, nt) only, so a
-  // query row's result does not depend on how the launch was batched or mapped (it does depend on the rotation mode: another summation order).
-  const int rot_mode = ROT ? (bs.xcd_remap >> 8) & 0xff : 0;  // ROT = false: the instantiation without any of the wrap arithmetic
-  int rot = 0;
-  if (rot_mode == 1) rot = (qblk & 7);                       // stagger: up to 7 tiles apart
-  else if (rot_mode == 2) rot = (qblk & 3) * (nt >> 2);      // four phase groups a quarter of the walk apart
-  else if (rot_mode == 3) rot = (qblk & 1) * (nt >> 1);      // two phase groups
-  else if (rot_mode == 4) rot = (qblk & 7) * (nt >> 3);      // eight phase groups
-  else if (rot_mode == 5) rot = (qblk & 3) * 2;              // stagger 0 / 2 / 4 / 6 tiles
-  if (rot >= nt - 1) rot = 0;
-  rot = __builtin_amdgcn_readfirstlane(rot);
-  // the walk as running byte offsets of the next K / V^T tile to fetch.  Only the first nt - 1 (full) tiles rotate — logical tile t < nt - 1 is
-  // physical tile (t + rot) mod (nt - 1) — and the physical last tile, the one that may hold fewer than 64 keys, stays last, so the key mask
-  // lives in the final softmax only (a mask test in every tile's softmax costs 37 spilled SGPRs in this kernel).
-  const unsigned k_last = (unsigned)(nt - 1) * k_tile_bytes, v_last = (unsigned)(nt - 1) * AT_K_BYTES;
-  unsigned kso = (unsigned)rot * k_tile_bytes, vso = (unsigned)rot * AT_K_BYTES;
-#define A8_NEXT_K() if constexpr (ROT) { kso += k_tile_bytes; kso = kso == k_last ? 0u : kso; }
-#define A8_NEXT_V() if constexpr (ROT) { vso += AT_K_BYTES; vso = vso == v_last ? 0u : vso; }
-#define A8_KOFF(T_) (ROT ? ((T_) == nt - 1 ? k_last : kso) : (unsigned)(T_) * k_tile_bytes)
-#define A8_VOFF(T_) (ROT ? ((T_) == nt - 1 ? v_last : vso) : (unsigned)(T_) * AT_K_BYTES)
-
-#define A8_SB() __builtin_amdgcn_sched_barrier(0)
-  // matrix half-step: unified stream of fragment slots n = 0..15 (K: key block n&1, head-dim step n>>1) and 16..31 (V^T: dv block
-  // n&3, key group (n-16)>>2), each fragment read DEPTH slots ahead of the MFMA that consumes it.  QK^T(t) goes first: its scores
-  // are what the next half-step needs, so they are long complete at the barrier, and PV(t-1)'s results are not read for a whole step.
-#define A8_FRAG(N_)                                                                                            \
-  ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + ((N_) & 1) * 8192 + kaddr[(N_) >> 1])                \
-             : *reinterpret_cast<const bf16x8_t*>(vb + ((N_) & 3) * 4096 + vaddr[((N_) - 16) >> 2]))
-#define A8_MATRIX(N0_, N1_, VB_, KB_)                                                                          \
-  {                                                                                                            \
-    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                        \
-    const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
-    bf16x8_t fr[DEPTH];                                                                                        \
-    _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A8_FRAG((N0_) + d);                              \
-    _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                    \
-      const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                             \
-      if (n < 16) {                                                                                            \
-        const int ks = n >> 1, u = n & 1;                                                                      \
-        if (ks == 0) /* D early-clobber: the -m tuple stays a pure input */                                    \
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sc[u]) : "v"(f_), "v"(qf[0]), "v"(negm)); \
-        else                                                                                                   \
-          sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, qf[ks], ks == 0 ? negm : sc[u], 0, 0, 0);        \
-      } else {                                                                                                 \
-        const int T = n & 3, uh = (n - 16) >> 2;                                                               \
-        i32x4_t pq = {(int)pw[uh * 4 + 0], (int)pw[uh * 4 + 1], (int)pw[uh * 4 + 2], (int)pw[uh * 4 + 3]};     \
-        oacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f_, __builtin_bit_cast(bf16x8_t, pq), oacc[T], 0, 0, 0); \
-      }                                                                                                        \
-      if (n + DEPTH < (N1_)) fr[(n - (N0_)) % DEPTH] = A8_FRAG(n + DEPTH);                                     \
-      A8_SB();                                                                                                 \
-    }                                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
-  }
-  // vector half-step: softmax of the tile in sc -> packed bf16 P in pw
-#define A8_SOFTMAX(LAST_)                                                                                      \
-  {                                                                                                            \
-    if ((LAST_) && (int64_t)(t + 1) * AT_KV > Sk) {                                                            \
-      const int left = (int)(Sk - (int64_t)t * AT_KV);                                                         \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
-        if (u * 32 + (r & 7) + 8 * hi + 16 * (r >> 3) >= left) sc[u][r] = -1e30f;                              \
-    }                                                                                                          \
-    float pm[4];                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
-      const int uu = i >> 1, r0 = (i & 1) * 8;                                                                 \
-      const float a_ = vmax3(sc[uu][r0], sc[uu][r0 + 1], sc[uu][r0 + 2]);                                      \
-      const float b_ = vmax3(sc[uu][r0 + 3], sc[uu][r0 + 4], sc[uu][r0 + 5]);                                  \
-      const float c_ = vmax2(sc[uu][r0 + 6], sc[uu][r0 + 7]);                                                  \
-      pm[i] = vmax3(a_, b_, c_);                                                                               \
-    }                                                                                                          \
-    float mx = vmax2(vmax2(pm[0], pm[1]), vmax2(pm[2], pm[3]));                                                \
-    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);        \
-    mx = vmax2(__uint_as_float(sw[0]), __uint_as_float(sw[1])); /* row max relative to m_run */                \
-    if (force || __any(mx > (float)RESCALE_THR)) { /* cold: some row's max grew by more than THR (or first tile) */ \
-      const float d = force ? mx : fmaxf(mx, 0.f);                                                             \
-      m_run += d;                                                                                              \
-      if (!force) {                                                                                            \
-        const float al = __builtin_amdgcn_exp2f(-d);                                                           \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) lsum[e] *= al;                                           \
-        _Pragma("unroll") for (int T = 0; T < 4; ++T) _Pragma("unroll") for (int e = 0; e < 16; ++e) oacc[T][e] *= al; \
-      }                                                                                                        \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) negm[e] = -m_run;                                         \
-      _Pragma("unroll") for (int u2 = 0; u2 < 2; ++u2) _Pragma("unroll") for (int e = 0; e < 16; ++e) sc[u2][e] -= d; \
-      force = false;                                                                                           \
-    }                                                                                                          \
-    _Pragma("unroll") for (int uu = 0; uu < 2; ++uu) _Pragma("unroll") for (int e = 0; e < 16; e += 2) {       \
-      const float p0 = __builtin_amdgcn_exp2f(sc[uu][e]), p1 = __builtin_amdgcn_exp2f(sc[uu][e + 1]);         \
-      lsum[e & 3] += p0;                                                                                       \
-      lsum[(e + 1) & 3] += p1;                                                                                 \
-      pw[uu * 8 + (e >> 1)] = pack_bf2(p0, p1);                                                                \
-    }                                                                                                          \
-    { /* the row sums belong to THIS half-step: without the pin hipcc sinks the adds behind the next PV MFMAs */ \
-      asm volatile("" : "+v"(lsum[0]), "+v"(lsum[1]), "+v"(lsum[2]), "+v"(lsum[3]));                           \
-      A8_SB();                                                                                                 \
-    }                                                                                                          \
-  }
-
-  // ---- prologue: K(0)
-  if (wid >= NW / 2) {
-    A8_DMA_K(A8_KOFF(0), 0)
-    A8_NEXT_K()
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- global half-steps g = 0 .. 2 nt + 1; a wave's own step is gl = g - late (late = the upper half of the waves):
-  //      gl = 2t   : matrix half-step  QK^T(t) [t < nt]  +  PV(t-1) [t > 0]
-  //      gl = 2t+1 : vector half-step  softmax(t)
-  // Written out per role (straight-line loops keep the accumulator tuples in place; a single loop with a phase switch made
-  // the register allocator copy and spill them).  Every wave passes 2 nt + 2 barriers.
-  int t = 0;
-#define A8_ISSUE(TG_) /* even half-step g = 2 TG_ */ \
-  if ((TG_) + 1 < nt) {                               \
-    A8_DMA_K(A8_KOFF((TG_) + 1), ((TG_) + 1) & 1)     \
-    A8_NEXT_K()                                       \
-  }                                                   \
-  if ((TG_) < nt) {                                   \
-    A8_DMA_V(A8_VOFF(TG_), (TG_) & 1)                 \
-    A8_NEXT_V()                                       \
-  }                                                   \
-  A8_SB();
-  // the data issued in an even half-step is awaited at the end of the following odd one: two half-steps of flight
-#define A8_BAR_EVEN() __syncthreads();
-#define A8_BAR_ODD()                                   \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
-  __syncthreads();
-  if (wid < NW / 2) {
-    A8_MATRIX(0, 16, 0, 0)
-    A8_BAR_EVEN()
-    // iteration t: softmax(t) | matrix {QK^T(t+1) from K buffer (t+1)&1, PV(t) from V^T buffer t&1}; t starts even (x2: constant buffer offsets)
-    while (t < nt - 1) {
-      A8_SOFTMAX(false)
-      A8_BAR_ODD()
-      A8_MATRIX(0, 32, 0, 1)
-      A8_BAR_EVEN()
-      if (++t >= nt - 1) break;
-      A8_SOFTMAX(false)
-      A8_BAR_ODD()
-      A8_MATRIX(0, 32, 1, 0)
-      A8_BAR_EVEN()
-      ++t;
-    }
-    A8_SOFTMAX(true)
-    A8_BAR_ODD()
-    A8_MATRIX(16, 32, t & 1, 0)
-    A8_BAR_EVEN()
-    A8_BAR_ODD()
-  } else {
-    A8_ISSUE(0)
-    A8_BAR_EVEN()
-    A8_MATRIX(0, 16, 0, 0)
-    A8_BAR_ODD()
-    while (t < nt - 1) {
-      A8_ISSUE(t + 1)
-      A8_SOFTMAX(false)
-      A8_BAR_EVEN()
-      A8_MATRIX(0, 32, 0, 1)
-      A8_BAR_ODD()
-      if (++t >= nt - 1) break;
-      A8_ISSUE(t + 1)
-      A8_SOFTMAX(false)
-      A8_BAR_EVEN()
-      A8_MATRIX(0, 32, 1, 0)
-      A8_BAR_ODD()
-      ++t;
-    }
-    A8_SOFTMAX(true)
-    A8_BAR_EVEN()
-    A8_MATRIX(16, 32, t & 1, 0)
-    A8_BAR_ODD()
-  }
-#undef A8_ISSUE
-#undef A8_NEXT_K
-#undef A8_NEXT_V
-#undef A8_KOFF
-#undef A8_VOFF
-#undef A8_BAR_EVEN
-#undef A8_BAR_ODD
-#undef A8_SOFTMAX
-#undef A8_MATRIX
-#undef A8_FRAG
-#undef A8_SB
-#undef A8_DMA_K
-#undef A8_DMA_V
-
-  const float l_run = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int64_t qrow = q0 + fl;
-  if (qrow < Sq) {
-    unsigned short* op = O + qrow * ldo + (int64_t)head * AT_D;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = 32 * T + 8 * g + 4 * hi;
-        uint2 pk;
-        pk.x = pack_bf2(oacc[T][4 * g + 0] * inv, oacc[T][4 * g + 1] * inv);
-        pk.y = pack_bf2(oacc[T][4 * g + 2] * inv, oacc[T][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + dv) = pk;
-      }
-  }
-#endif
-}
-
-// "v9": the ping-pong kernel on v_mfma_f32_16x16x32_bf16.  Same workgroup (8 waves x 32 query rows), same LDS-DMA double buffering, same
-// half-step protocol and roles as v8; what changes is the register geometry.  At the board's power limit the 16x16x32 shape delivers more
-// FLOP per joule than 32x32x16 (tools/probes/mfma_power_probe: 1582 vs 1529-1540 TFLOP/s with attention's fragment traffic at 32 rows per
-// wave), the same effect that moved the GEMMs (gemm256.hip).
+// "ping-pong" kernel (generation v9; what the fused drivers launch through x2v_attn_fwd_bf16_vt): every wave alternates a pure matrix half-step
+// {QK^T(t) then PV(t-1): 64 MFMAs + their 32 LDS fragment reads} with a pure vector half-step {softmax(t): row max, exp2, row sum, bf16 pack},
+// and the two waves of a SIMD (wid and wid + NW/2) run half a step apart — while one occupies the matrix pipe the other occupies the VALU port.
+// In phase (the v2 pipeline above) both waves want the VALU during the softmax (exp2 is quarter rate) and both want the matrix pipe during PV;
+// the measured decomposition showed the parts adding up rather than overlapping.
+//   * V is consumed pre-transposed (V^T [H][S/64][128 dv][64 keys], written by the v projection's epilogue x2v_gemm_bf16_vt or by
+//     x2v_transpose_heads_bf16), so both operand tiles arrive by LDS-DMA into swizzled images and both fragments are plain ds_read_b128;
+//   * one barrier per half-step; data movement is by global half-step g, identical for all waves: even g = 2t issues K(t+1) and V^T(t) (both
+//     double buffered), the odd half-step that follows ends with s_waitcnt vmcnt(0).  Only the waves in their vector half-step issue the DMA
+//     (an LDS-DMA issue costs ~60 cycles between bare MFMAs, about half in VALU-only gaps);
+//   * scores leave the MFMA already relative to the running max (C = -m_run, known before QK^T(t) starts because softmax(t-1) is the same wave's
+//     previous half-step), q carries scale*log2(e) (PRESCALED: folded in by the producer), so P = exp2(S') with no per-score FMA; rescale stays
+//     lazy (cold branch, threshold RESCALE_THR in base-2 units); the first MFMA of every score chain is an asm statement with an early-clobber
+//     destination so that hipcc never computes into (and then restores) the -m tuple;
+//   * a straight-line loop per role (early / late waves), unrolled x2 so both LDS buffer indices are compile-time and every fragment address is
+//     register + immediate; one score buffer: nothing spills at 2 waves per SIMD (224 VGPRs).
+// Register geometry — v_mfma_f32_16x16x32_bf16.  At the board's power limit the 16x16x32 shape delivers more FLOP per joule than 32x32x16
+// (tools/probes/mfma_power_probe: 1582 vs 1529-1540 TFLOP/s with attention's fragment traffic at 32 rows per wave), the same effect that moved
+// the GEMMs (gemm256.hip): the round-2 kernel (same protocol on 32x32x16, 32 MFMAs per tile) ran 4.8 % slower on the same box
+// (profiles/r03_attn_v9_map_rot_matrix_and_pmc.txt; its source is in git history).
 //   * a wave's 32 query rows are two groups g of 16; lane = (c = lane & 15, qd = lane >> 4).
 //   * S^T = K . Q^T per 16-key sub-tile kt (4 per tile): A = K fragment (row = key kappa(kt, c), k-slot 8 qd + e <-> d = 32 ks + 8 qd + e),
 //     B = Q fragment (col = query 16 g + c, same k-slots): 4 kt x 2 g x 4 ks = 32 MFMAs; a K fragment read feeds both groups.
@@ -660,6 +328,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v8_kernel(const unsigned 
 //     hash, would collide two-fold.  The DMA pieces of a wave are chosen so that h is the same for all of them (one voffset register).
 //   * a query's 64 scores of a tile sit in 4 lanes (the 4 qd of its column): row maxima of both groups cross lanes with 3 swaps
 //     (permlane16_swap, permlane32_swap, permlane16_swap) and 2 max.
+struct AttnBatch {
+  int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
+  int xcd_remap;        // bit 0: XCD-aware head-major work mapping (see the kernel), bit 8: staggered key walk; 0: the grid as dispatched, walk from tile 0
+};
 template <int NW, int RESCALE_THR, bool PRESCALED, bool ROT>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
@@ -669,18 +341,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(NW == 8, "DMA piece assignment below is written for 4 issuing waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Work mapping.  The launch grid is (query blocks, heads, sequences) and the dispatcher hands workgroup number L = x + gx (y + gy z) to XCD
+  // L % 8 (observed placement; a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch").  Taken as it comes, the 64 workgroups
+  // resident on an XCD (32 CUs x 2) belong to ~2 heads whose K / V^T streams all eight 4 MiB L2s pull through together.  XCD-aware form
+  // (bit 0 of bs.xcd_remap): XCD c owns the contiguous range c of the (sequence, head, query block) list (bijective for any count), so
+  // its resident workgroups are consecutive query blocks of ONE head walking the same K / V^T tiles at about the same time.  Measured
+  // (profiles/r03_attn_*): L2 hit rate 73-79 % -> 96 %, L2<->fabric traffic 99-123 GB -> 16 GB per Wan-14B 720p launch — and the launch is
+  // 4-8 % SLOWER there, with any key-walk rotation and with K stored head-contiguous as well: eight XCDs on eight different heads keep
+  // 8 x 38.7 MB of K / V^T in flight, more than the 256 MB Infinity Cache holds, while the plain grid keeps the whole chip on ~2 heads
+  // (77 MB, cache-resident) and is not bound by fabric traffic to begin with.  The mapping pays where the heads in flight do fit (Ulysses rank
+  // of the same video, 5 heads: +4 %; Wan-1.3B 480p: +1.5 %): the launcher's rule (launch_attn_vt) turns it on exactly there.
   int qblk = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
-  const int map_mode = bs.xcd_remap & 0xff;
-  if (map_mode) {  // XCD-aware work mapping: see attn_fwd_v8_kernel
+  if (bs.xcd_remap & 1) {
     const unsigned gx = gridDim.x, gy = gridDim.y;
     const unsigned nwg = gx * gy * gridDim.z;
     const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const unsigned xcd = L & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
-    unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
-    if (map_mode == 2 && (gy & 1u) == 0 && r8 == 0 && ((gy * gridDim.z) & 15u) == 0) {
-      const unsigned pair = id / (2 * gx), w = id % (2 * gx);
-      id = (2 * pair + (w & 1u)) * gx + (w >> 1);
-    }
+    const unsigned id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
     qblk = (int)(id % gx);
     const unsigned hz = id / gx;
     head = (int)(hz % gy);
@@ -764,13 +441,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   bool force = true;  // first tile: adopt its row max in either direction
   unsigned pw[2][2][4];  // [key group j][query group g]: 8 bf16 probabilities = the B operand of a PV MFMA
   const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
-  const int rot_mode = ROT ? (bs.xcd_remap >> 8) & 0xff : 0;
-  int rot = 0;
-  if (rot_mode == 1) rot = (qblk & 7);
-  else if (rot_mode == 2) rot = (qblk & 3) * (nt >> 2);
-  else if (rot_mode == 3) rot = (qblk & 1) * (nt >> 1);
-  else if (rot_mode == 4) rot = (qblk & 7) * (nt >> 3);
-  else if (rot_mode == 5) rot = (qblk & 3) * 2;
+  // Key-tile walk.  With ROT (flag X2V_ATTN_VT_STAGGER) query block b starts (b mod 8) tiles in: co-resident workgroups then ask for a tile at
+  // slightly different times (one takes the L2 miss, its followers hit) instead of all at the same instant: +1.3 % on the plain grid at Wan-14B
+  // 720p.  Only the first nt - 1 (full) tiles rotate — logical tile t < nt - 1 is physical tile (t + rot) mod (nt - 1) — and the physical last
+  // tile, the one that may hold fewer than 64 keys, stays last, so the key mask lives in the final softmax only (a mask test in every tile's
+  // softmax costs 37 spilled SGPRs).  The walk is kept as running byte offsets of the next K / V^T tile to fetch.  rot depends on (qblk, nt)
+  // only: a query row's result does not depend on how a launch is batched or mapped, but it does on which 256-row block of the launch it is in.
+  int rot = ROT ? (qblk & 7) : 0;
   if (rot >= nt - 1) rot = 0;
   rot = __builtin_amdgcn_readfirstlane(rot);
   const unsigned k_last = (unsigned)(nt - 1) * k_tile_bytes, v_last = (unsigned)(nt - 1) * AT_K_BYTES;
@@ -1041,10 +718,8 @@ static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk
   const bool mall_resident = heads_in_flight * Sk * (2 * AT_D * 2) <= (224ll << 20);
   const int map_mode = map_env >= 0 ? map_env : ((nwg >= 512 && mall_resident) ? 1 : 0);
   const int rot_mode = rot_env >= 0 ? rot_env : ((stagger && Sk >= 16 * AT_KV) ? 1 : 0);
-  bs.xcd_remap = (map_mode & 0xff) | ((rot_mode & 0xff) << 8);
-  static const int gen_env = [] { const char* e = getenv("X2V_ATTN_GEN"); return e ? atoi(e) : AT_DEFAULT_GEN; }();  // 8: 32x32x16 MFMA, 9: 16x16x32
-  auto kern = gen_env == 9 ? (rot_mode ? attn_fwd_v9_kernel<NW, THR, PRESCALED, true> : attn_fwd_v9_kernel<NW, THR, PRESCALED, false>)
-                           : (rot_mode ? attn_fwd_v8_kernel<NW, THR, PRESCALED, true> : attn_fwd_v8_kernel<NW, THR, PRESCALED, false>);
+  bs.xcd_remap = (map_mode ? 1 : 0) | (rot_mode ? 0x100 : 0);
+  auto kern = rot_mode ? attn_fwd_v9_kernel<NW, THR, PRESCALED, true> : attn_fwd_v9_kernel<NW, THR, PRESCALED, false>;
   int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
   if (rc != X2V_OK) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), 4 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,

@@ -320,6 +320,16 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
   }
   const int chosen = kind == 0 ? choose_kernel(M, N, nk, ldxb, ldwb, FP8, gb) : kind;
   if constexpr (!FP8) {
+    // the single-stream kernel addresses its output (and residual) tile with 32-bit offsets from the tile's first row
+    const int64_t y_cols_span = gb.y_cbw > 0 ? (int64_t)((N - 1) / gb.y_cbw) * gb.y_cbs + gb.y_cbw : (int64_t)N;
+    const bool y32 = (255 * ldy + y_cols_span) * 2 < (1ll << 32) && (resid == nullptr || (255 * ldr + (int64_t)N) * 2 < (1ll << 32));
+    if (chosen == 3 && !y32) {
+      if (kind == 3) {
+        set_error("gemm: output leading dimension / block stride too large for the single-stream 256x256 kernel (32-bit tile addressing)");
+        return X2V_E_SHAPE;
+      }
+      return dispatch_epi<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, 2 | (gm_tiles << 8), st, gb);
+    }
     if (chosen == 3) return gemm256s_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
   }
   if (chosen == 2) {

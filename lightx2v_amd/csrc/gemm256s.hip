@@ -43,6 +43,13 @@ constexpr int S_EARLY = (127 - S_FREE - 1) / S_STEP + 1 < 16 ? (127 - S_FREE - 1
 static_assert(S_LATE0 + (16 - S_EARLY - 1) * S_STEP < S_FREE && S_READY + 2 + 30 <= 127, "slot plan");
 
 typedef __attribute__((address_space(3))) void* s_lds_ptr_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// Every asm statement that touches the accumulator half names ALL of it as clobbered: hipcc must never park a value of its own in an AGPR
+// across one of them.  (Round 3: with only a0 / a255 named once at kernel entry, the register allocator put part of the hoisted residual
+// chunks into a1..a8 — `v_accvgpr_write` outside the asm blocks — and two accumulator tiles per wave were overwritten: the AUDIT rule in
+// the header exists for exactly this.)
+#define S_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 
 template <int B, int E, class F>
 __device__ __forceinline__ void s_for(F&& f) {  // f(integral_constant<int, i>) for i = B .. E-1, fully unrolled with constant indices
@@ -55,16 +62,16 @@ __device__ __forceinline__ void s_for(F&& f) {  // f(integral_constant<int, i>) 
 // accumulator tile I (= x block * 8 + W block) is a[4 I : 4 I + 3]
 template <int I>
 __device__ __forceinline__ void s_mfma(const bf16x8_t& wf, const bf16x8_t& xf) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(4 * I), "i"(4 * I + 3));
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(4 * I), "i"(4 * I + 3) : S_AGPRS);
 }
 template <int R>
 __device__ __forceinline__ void s_acc_zero() {
-  asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(R));
+  asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(R) : S_AGPRS);
 }
 template <int R>
 __device__ __forceinline__ float s_acc_read() {
   float x;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R));
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R) : S_AGPRS);
   return x;
 }
 
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned short* __restrict__ gate, int ntm, int ntn, int gm_tiles, GemmBlocking gb) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  asm volatile("" ::: "a0", "a255");  // the accumulator half belongs to the asm statements of this kernel
+  asm volatile("" ::: S_AGPRS);  // the accumulator half belongs to the asm statements of this kernel
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,19 +282,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   } else {
+  // ---- epilogue addressing: the output tile (and the residual tile) through buffer descriptors whose base is the tile's first element; a thread's
+    //      chunk (row tid>>5 + 8 it, columns 8 (tid&31)..) is a per-thread 32-bit offset + a per-iteration SCALAR offset 8 it rows — no 64-bit
+    //      address registers per iteration (they cost the residual variant 9 spilled VGPRs once its loads were hoisted).  Rows / columns past M / N
+    //      are predicated off below; the descriptor range only has to cover the tile.
+    const int erow = tid >> 5, ecc = tid & 31;
+    const int egn = n0 + ecc * 8;
+    const int64_t eycol = gb.y_cbw > 0 ? (int64_t)(egn / gb.y_cbw) * gb.y_cbs + egn % gb.y_cbw : egn;  // N-blocked y (GemmBlocking)
+    const bool ecol_ok = egn < N;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ldy), 0, 0xffffffffu, 0x00020000);
+    const unsigned y_voff = (unsigned)((erow * ldy + eycol) * 2), y_step = (unsigned)(8 * ldy * 2);
   // ---- epilogue phase 0 (residual epilogue): this thread's 32 residual chunks (the rows / columns it will store in phase 2) are requested NOW,
     //      into the registers the fragments no longer need, so that ONE memory latency runs under the accumulator -> LDS pass instead of eight
     //      dependent round trips inside the store loop (the residual variant ran 8 % below the plain one per FLOP: ~10 us of a 117 us tile).
-    uint4 rres[32];
+    u32x4_t rres[32];
     if constexpr (EPI == X2V_EPI_RESIDUAL) {
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(resid + m0 * ldr), 0, 0xffffffffu, 0x00020000);
+      const unsigned r_voff = (unsigned)((erow * ldr + egn) * 2), r_step = (unsigned)(8 * ldr * 2);
   #pragma unroll
       for (int it = 0; it < 32; ++it) {
-        const int id = it * 256 + tid;
-        const int row = id >> 5, cc = id & 31;
-        const int64_t gmr = m0 + row;
-        const int gn = n0 + cc * 8;
-        rres[it] = make_uint4(0u, 0u, 0u, 0u);
-        if (gmr < M && gn < N) rres[it] = *reinterpret_cast<const uint4*>(resid + gmr * ldr + gn);
+        rres[it] = u32x4_t{0u, 0u, 0u, 0u};
+        if (ecol_ok && m0 + erow + 8 * it < M) rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff, (unsigned)it * r_step, 0);
       }
     }
   // ---- epilogue phase 1: acc (+bias, activation) -> bf16 -> LDS [256][S_EPI_LD]
@@ -323,25 +338,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     // ---- epilogue phase 2: 16-byte stores, 32 lanes per 512-byte output row
     if constexpr (EPI == X2V_EPI_RESIDUAL) {
-      // per-column gate chunk: the same 8 columns in every iteration of this thread (cc = tid & 31)
-      float gv[8];
+      float gv[8];  // per-column gate chunk: the same 8 columns in every iteration of this thread
       {
-        const int gn = n0 + (tid & 31) * 8;
         uint4 g4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-        if (gate != nullptr && gn < N) g4 = *reinterpret_cast<const uint4*>(gate + gn);
+        if (gate != nullptr && ecol_ok) g4 = *reinterpret_cast<const uint4*>(gate + egn);
         unpack8(g4, gv);
       }
   #pragma unroll
       for (int it = 0; it < 32; ++it) {
-        const int id = it * 256 + tid;
-        const int row = id >> 5, cc = id & 31;
-        const int64_t gmr = m0 + row;
-        const int gn = n0 + cc * 8;
-        if (gmr < M && gn < N) {
-          const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
+        if (ecol_ok && m0 + erow + 8 * it < M) {
           float yv[8], xv[8], ov[8];
-          unpack8(*reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16), yv);
-          unpack8(rres[it], xv);
+          unpack8(*reinterpret_cast<const uint4*>(smem + (erow + 8 * it) * S_EPI_LD + ecc * 16), yv);
+          unpack8(__builtin_bit_cast(uint4, rres[it]), xv);
           if (gate != nullptr) {
   #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = xv[e] + rbf(yv[e] * gv[e]);
@@ -349,20 +357,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = xv[e] + yv[e];
           }
-          *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = pack8(ov);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pack8(ov)), ry, y_voff, (unsigned)it * y_step, 0);
         }
       }
     } else {
   #pragma unroll 4
       for (int it = 0; it < 32; ++it) {
-        const int id = it * 256 + tid;
-        const int row = id >> 5, cc = id & 31;
-        const int64_t gmr = m0 + row;
-        const int gn = n0 + cc * 8;
-        if (gmr < M && gn < N) {
-          const int64_t ycol = gb.y_cbw > 0 ? (int64_t)(gn / gb.y_cbw) * gb.y_cbs + gn % gb.y_cbw : gn;  // N-blocked y (GemmBlocking)
-          *reinterpret_cast<uint4*>(Y + gmr * ldy + ycol) = *reinterpret_cast<const uint4*>(smem + row * S_EPI_LD + cc * 16);
-        }
+        if (ecol_ok && m0 + erow + 8 * it < M)
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4_t*>(smem + (erow + 8 * it) * S_EPI_LD + ecc * 16), ry, y_voff, (unsigned)it * y_step, 0);
       }
     }
 }
