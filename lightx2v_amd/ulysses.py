@@ -303,16 +303,15 @@ class CfgBranchStreams:
     and are independent until the CFG combine, so here block i of the unconditional branch is enqueued on a second stream right behind
     block i of the conditional one: whenever one branch's stream waits for its communication stream, the other's GEMMs / attention own
     the CUs — including the FFN-up GEMM of one branch under the head->seq exchange of the other.  Each branch has its own UlyssesAttention
-    (exchange buffers, communication stream) and, over RCCL, its own process group (= its own communicator, so the two branches' collectives
-    do not queue behind each other).  Every kernel sees the same operands as in the sequential order: results are bit-identical
-    (tests/_dist_gpu_worker.py).  Host-side order of the collectives is the same on every rank (branch A's block i, then branch B's)."""
+    (exchange buffers); both feed ONE communication stream and one process group in host order (branch A's block i, then branch B's — the
+    same on every rank), so RCCL is used exactly as in the sequential form.  Every kernel sees the same operands as in the sequential order:
+    results are bit-identical (tests/_dist_gpu_worker.py)."""
 
     def __init__(self, wan_model, group=None, attn_fn=None):
         self.model, self.group, self.attn_fn = wan_model, group, attn_fn
         self.enabled = True
         self._pa_b = None
         self._streams = None
-        self._group_b = None
 
     def usable(self, inputs):
         m = self.model
@@ -323,13 +322,13 @@ class CfgBranchStreams:
     def _setup(self):
         if self._streams is None:
             self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
-            if dist.get_backend(self.group) == "nccl" and _world(self.group)[0] > 1:
-                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
-                self._group_b = dist.new_group(ranks=ranks, backend="nccl")  # collective call: every rank of the group gets here in its first step
-            else:
-                self._group_b = self.group
-            self._pa_b = UlyssesAttention(self._group_b, self.attn_fn)
-            self._pa_b.split_head2seq = self.model.transformer_infer.parallel_attention.split_head2seq
+            pa_a = self.model.transformer_infer.parallel_attention
+            # branch B: its own exchange buffers, but the SAME process group and the SAME communication stream as branch A — RCCL sees one
+            # communicator fed from one stream in host order, exactly as in the sequential form (two communicators running concurrently on
+            # one GPU would be a new way to deadlock that nothing here could test)
+            self._pa_b = UlyssesAttention(self.group, self.attn_fn)
+            self._pa_b.comm_stream = pa_a._comm()
+            self._pa_b.split_head2seq = pa_a.split_head2seq
         return self._streams
 
     def forward_pair(self, inputs):
@@ -358,9 +357,9 @@ class CfgBranchStreams:
         finally:
             tr.parallel_attention = pa_a
         outs = []
-        for st, xs, grp in ((sa, xa, self.group), (sb, xb, self._group_b)):
+        for st, xs in ((sa, xa), (sb, xb)):
             with torch.cuda.stream(st):
-                full = post_process(xs, grp)
+                full = post_process(xs, self.group)
                 outs.append(m.post_infer.infer(m.post_weight, full, embed, grid_sizes)[0])
         cur.wait_stream(sa)
         cur.wait_stream(sb)
