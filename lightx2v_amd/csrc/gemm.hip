@@ -309,7 +309,6 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
                         GemmBlocking gb = GemmBlocking()) {
   const int kind = variant & 0xff;
   const int gm_tiles = (variant >> 8) & 0xff;
-  gb.stagger = gemm_stagger_default();
   const bool fits256 = spans_fit_256(nk, ldxb, ldwb, gb);
   if ((kind == 2 || kind == 3) && !fits256) {
     set_error("gemm: leading dimension / K-block span too large for the 256x256 kernels (32-bit tile addressing)");

@@ -61,7 +61,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const char* __restrict_
 
   // ---- tile coordinates: XCD chunking + grouped ordering (gm_tiles m-tiles x all n-tiles per group)
   const unsigned nblk = (unsigned)ntm * (unsigned)ntn;
-  gemm_stagger_wait(gb.stagger);
   const unsigned v = xcd_remap(blockIdx.x, nblk);
   const unsigned GM = (unsigned)gm_tiles;
   const unsigned per_group = GM * (unsigned)ntn;

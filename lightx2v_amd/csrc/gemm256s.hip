@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wr = wid >> 1, wc = wid & 1;
   const int r16 = lane & 15, g16 = lane >> 4;
 
-  gemm_stagger_wait(gb.stagger);
   // ---- tile coordinates: XCD chunking + grouped ordering (gm_tiles m-tiles x all n-tiles per group), as gemm256.hip
   const unsigned nblk = (unsigned)ntm * (unsigned)ntn;
   const unsigned v = xcd_remap(blockIdx.x, nblk);
@@ -400,9 +399,7 @@ int gemm256s_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, 
 
 // V^T-producing form (x2v_gemm_bf16_vt): y = V^T [N/128][ldvt/64][128][64]; `ldvt` travels in the ldy argument
 int gemm256s_vt_dispatch(const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int nk, hipStream_t st) {
-  GemmBlocking gb;
-  gb.stagger = gemm_stagger_default();
-  return launch_gemm256s<X2V_EPI_NONE, true>(x, ldxb, w, ldwb, bias, vt, ldvt, M, N, nk, nullptr, 0, nullptr, 0, st, gb);
+  return launch_gemm256s<X2V_EPI_NONE, true>(x, ldxb, w, ldwb, bias, vt, ldvt, M, N, nk, nullptr, 0, nullptr, 0, st, GemmBlocking());
 }
 
 }  // namespace x2v

@@ -48,27 +48,7 @@ struct GemmBlocking {
   unsigned a_cbs = 0;   // bytes between x blocks
   int y_cbw = 0;        // columns per y block (a multiple of 8)
   int64_t y_cbs = 0;    // elements between y blocks
-  int stagger = 0;      // 256x256 kernels: first-round workgroup b waits (b mod 16) * stagger * 1024 cycles before its first tile (see gemm_stagger_wait)
 };
-
-// Tile-phase stagger of the 256x256 GEMM kernels.  One workgroup per CU, equal tiles: all 256 workgroups of a round finish together and their
-// epilogues — 32 MB of y stores (+ 32 MB of residual loads) per round — reach HBM as one burst during which no MFMA runs (measured: the
-// residual epilogue's extra time = its bytes / HBM bandwidth).  A one-off delay of the FIRST-round workgroups, different per CU, spreads the
-// tile boundaries of the whole launch (later workgroups inherit their slot's phase), so a CU's epilogue meets an HBM that 15/16 of the other
-// CUs are not using.  Costs (15/2) * stagger * 1024 cycles once per launch.
-#ifndef X2V_GEMM_STAGGER_DEFAULT
-#define X2V_GEMM_STAGGER_DEFAULT 0
-#endif
-static inline int gemm_stagger_default() {  // host: X2V_GEMM_STAGGER overrides the built-in default (A/B runs)
-  static const int v = [] { const char* e = getenv("X2V_GEMM_STAGGER"); return e ? atoi(e) : X2V_GEMM_STAGGER_DEFAULT; }();
-  return v;
-}
-__device__ __forceinline__ void gemm_stagger_wait(int stagger) {
-  if (stagger > 0 && blockIdx.x < 256u) {
-    const int n = (int)(blockIdx.x & 15u) * stagger;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
-  }
-}
 
 // ---- bf16 <-> fp32 (device) -------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
