@@ -337,7 +337,8 @@ int x2v_vae_prep_f16(const float* x, void* y, int T, int H, int W, int C, const 
                      int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, void* stream);
 
 /* x2v_vae_prep_f16 writing the hi/lo fp16 split of its result (x = hi + lo, hi = fp16(x), lo = fp16(x - hi): ~22 mantissa bits) as channels
- * [hi | hi | lo] (3*C halves per pixel, y_px_stride >= 3*C).  With weights laid out [hi | lo | hi] along Cin, x2v_vae_conv_f16 accumulates
+ * [hi | hi * 2^-12 | lo] (3*C halves per pixel, y_px_stride >= 3*C; hi saturates at the fp16 range instead of overflowing).  With weights laid out
+ * [hi | lo * 2^12 | hi] along Cin (the power-of-two pair keeps the weights' lo halves normal fp16 numbers), x2v_vae_conv_f16 accumulates
  * xh.wh + xh.wl + xl.wh in fp32: the Wan VAE's fp32 convolutions (vae.py:794) at fp32-grade accuracy on the 16-bit matrix instruction. */
 int x2v_vae_prep_split_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a, const float* b, int silu, int upsample,
                            int64_t y_frame_stride, int64_t y_row_stride, int64_t y_px_stride, void* stream);

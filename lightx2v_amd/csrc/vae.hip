@@ -419,7 +419,19 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = o[e] / (1.f + __expf(-o[e]));
       }
-      const Out4 ov = {{(OT)o[0], (OT)o[1], (OT)o[2], (OT)o[3]}};
+      if constexpr (sizeof(OT) == 2) {
+        if (split) {  // hi = fp16(x) must stay finite: beyond the fp16 range hi saturates at 65504 and lo carries the remainder at fp16 precision (2^-12 relative instead of inf)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], -131008.f), 131008.f);
+        }
+      }
+      Out4 ov = {{(OT)o[0], (OT)o[1], (OT)o[2], (OT)o[3]}};
+      if constexpr (sizeof(OT) == 2) {
+        if (split) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.e[e] = (OT)fminf(fmaxf(o[e], -65504.f), 65504.f);
+        }
+      }
       *reinterpret_cast<Out4*>(yb + c4 * 4) = ov;
       if (up) {
         *reinterpret_cast<Out4*>(yb + y_px_stride + c4 * 4) = ov;
@@ -428,13 +440,18 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
       }
       if constexpr (sizeof(OT) == 2) {
         if (split) {
-          // hi/lo operand split (x = hi + lo to ~22 mantissa bits): channels [hi | hi | lo], to meet weights laid out [hi | lo | hi] —
-          // the 16-bit convolution then accumulates xh.wh + xh.wl + xl.wh in fp32 (the xl.wl term is below fp32 resolution)
+          // hi/lo operand split (x = hi + lo to ~22 mantissa bits): channels [hi | hi * 2^-12 | lo], to meet weights laid out
+          // [hi | lo * 2^12 | hi] — the 16-bit convolution then accumulates xh.wh + xh.wl + xl.wh in fp32 (the xl.wl term is below fp32
+          // resolution).  The power-of-two pair on the middle plane keeps the weights' lo halves NORMAL fp16 numbers (|w_lo| <= 2^-12 |w|
+          // would be subnormal for every |w| < 1/4, i.e. nearly all of a conv kernel: ~17 instead of 22 bits, and dependent on the matrix
+          // unit not flushing subnormals — ADVICE r2); x_hi * 2^-12 only has to carry the 11 bits a 2^-11-sized correction term needs.
           const Out4 lv = {{(OT)(o[0] - (float)ov.e[0]), (OT)(o[1] - (float)ov.e[1]), (OT)(o[2] - (float)ov.e[2]), (OT)(o[3] - (float)ov.e[3])}};
+          const Out4 mv = {{(OT)((float)ov.e[0] * 0.000244140625f), (OT)((float)ov.e[1] * 0.000244140625f), (OT)((float)ov.e[2] * 0.000244140625f),
+                            (OT)((float)ov.e[3] * 0.000244140625f)}};
 #pragma unroll
           for (int q = 0; q < (up ? 4 : 1); ++q) {
             OT* yq = yb + (q & 1) * y_px_stride + (q >> 1) * y_row_stride;
-            *reinterpret_cast<Out4*>(yq + C + c4 * 4) = ov;
+            *reinterpret_cast<Out4*>(yq + C + c4 * 4) = mv;
             *reinterpret_cast<Out4*>(yq + 2 * C + c4 * 4) = lv;
           }
         }
@@ -973,8 +990,8 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_f16(const flo
   return vae_prep_f16_impl(x, y, T, Hh, Ww, C, gamma, a, b, silu, upsample, y_frame_stride, y_row_stride, y_px_stride, 0, stream);
 }
 
-// The same pass writing the hi/lo split of its result, channels [hi | hi | lo] (3 C halves per pixel): operand of x2v_vae_conv_f16 with weights
-// [hi | lo | hi] — fp32-grade convolution (~22 mantissa bits per operand) on the 16-bit matrix instruction
+// The same pass writing the hi/lo split of its result, channels [hi | hi * 2^-12 | lo] (3 C halves per pixel): operand of x2v_vae_conv_f16 with weights
+// [hi | lo * 2^12 | hi] — fp32-grade convolution (~22 mantissa bits per operand) on the 16-bit matrix instruction
 extern "C" __attribute__((visibility("default"))) int x2v_vae_prep_split_f16(const float* x, void* y, int T, int Hh, int Ww, int C, const float* gamma, const float* a,
                                                                              const float* b, int silu, int upsample, int64_t y_frame_stride, int64_t y_row_stride,
                                                                              int64_t y_px_stride, void* stream) {

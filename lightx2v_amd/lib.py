@@ -668,7 +668,7 @@ def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0
 
 def vae_prep(x, y_view, y_strides, gamma=None, a=None, b=None, silu=False, upsample=False, split=False):
     """x [T,H,W,C] contiguous fp32 -> y_view (first element = destination of pixel (0,0,0)); y_strides = (frame, row) in floats.
-    split (fp16 y_view only): write the hi/lo split [hi | hi | lo] (3*C channels per pixel, x2v_vae_prep_split_f16)."""
+    split (fp16 y_view only): write the hi/lo split [hi | hi * 2^-12 | lo] (3*C channels per pixel, x2v_vae_prep_split_f16; weights [hi | lo * 2^12 | hi])."""
     T, H, W, C = _f32dense(x, "vae_prep x", 4).shape
     for nm, t in (("gamma", gamma), ("a", a), ("b", b)):
         _f32dense(t, f"vae_prep {nm}", numel=C)

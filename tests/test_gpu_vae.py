@@ -208,15 +208,41 @@ def test_vae_decode_split_fp16_is_fp32_grade():
         strides = ((H + 2 * ph) * (W + 2 * pw) * cp, (W + 2 * pw) * cp, cp)
         lib.vae_prep(x.cuda(), buf[kt - 1 :, ph:, pw:], strides[:2], split=True)
         hi = x.half()
-        assert torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, :Cin].cpu(), hi) and torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, Cin : 2 * Cin].cpu(), hi)
+        # planes [hi | hi * 2^-12 | lo] against weights [hi | lo * 2^12 | hi]: the power-of-two pair keeps the weights' lo halves normal fp16 numbers
+        assert torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, :Cin].cpu(), hi)
+        assert torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, Cin : 2 * Cin].cpu(), (hi.float() / 4096).half())
         assert torch.equal(buf[kt - 1 :, ph : ph + H, pw : pw + W, 2 * Cin : 3 * Cin].cpu(), (x - hi.float()).half())
         wcl = w.permute(0, 2, 3, 4, 1).contiguous()
         whi = wcl.half()
+        wlo = ((wcl - whi.float()) * 4096).half()
+        assert (wlo.float().abs() >= 2.0 ** -14).float().mean().item() > 0.99 and ((wcl - whi.float()).half().float().abs() < 2.0 ** -14).float().mean().item() > 0.5, \
+            "the scaled lo halves must be normal fp16 numbers (most unscaled ones are subnormal)"
         w16 = torch.zeros(Cout, kt, kh, kw, cp, dtype=torch.float16)
-        w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, (wcl - whi.float()).half(), whi
+        w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, wlo, whi
         out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
         lib.vae_conv16(buf, strides, w16.cuda(), out, T, H, W, bias=b.cuda())
         _check(out, ref, f"split conv {(kt, kh, kw)} Cin={Cin} Cout={Cout}", atol=2e-5, rel=2e-6)
+    # large-magnitude activations (beyond the fp16 range: hi saturates at 65504, lo carries the rest) against tiny weights (1e-3
+    # scale: every unscaled lo half would be a subnormal) — still fp32-grade relative to the result's scale
+    T, H, W, Cin, Cout, kt, kh, kw = 1, 8, 16, 64, 32, 1, 3, 3
+    x = torch.randn(T, H, W, Cin, generator=g) * 300
+    x[0, 3, 5, :8] = torch.tensor([7.0e4, -9.0e4, 6.6e4, 1.2e5, -6.55e4, 3.0e4, -1.0e5, 6.5504e4])
+    w = torch.randn(Cout, Cin, kt, kh, kw, generator=g) * 1e-3
+    xin = F.pad(x.permute(3, 0, 1, 2), (1, 1, 1, 1, 0, 0))
+    ref = F.conv3d(xin.unsqueeze(0).double(), w.double())[0].permute(1, 2, 3, 0).float()
+    cp = (3 * Cin + 63) // 64 * 64
+    buf = torch.zeros(T, H + 2, W + 2, cp, dtype=torch.float16, device="cuda")
+    strides = ((H + 2) * (W + 2) * cp, (W + 2) * cp, cp)
+    lib.vae_prep(x.cuda(), buf[:, 1:, 1:], strides[:2], split=True)
+    assert torch.isfinite(buf.float()).all(), "hi must saturate, not overflow"
+    wcl = w.permute(0, 2, 3, 4, 1).contiguous()
+    whi = wcl.half()
+    w16 = torch.zeros(Cout, kt, kh, kw, cp, dtype=torch.float16)
+    w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, ((wcl - whi.float()) * 4096).half(), whi
+    out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
+    lib.vae_conv16(buf, strides, w16.cuda(), out, T, H, W, bias=torch.zeros(Cout).cuda())
+    scale = ref.abs().max().item()
+    assert (out.cpu() - ref).abs().max().item() <= 4e-6 * scale, ((out.cpu() - ref).abs().max().item(), scale)
     gld = load_file(os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
     dim, seed = int(gld["dim"]), int(gld["seed"])
     sd_t = synth.synth_wan_vae_weights(dim=dim, seed=seed)
