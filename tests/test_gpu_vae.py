@@ -215,7 +215,7 @@ def test_vae_decode_split_fp16_is_fp32_grade():
         wcl = w.permute(0, 2, 3, 4, 1).contiguous()
         whi = wcl.half()
         wlo = ((wcl - whi.float()) * 4096).half()
-        assert (wlo.float().abs() >= 2.0 ** -14).float().mean().item() > 0.99 and ((wcl - whi.float()).half().float().abs() < 2.0 ** -14).float().mean().item() > 0.5, \
+        assert (wlo.float().abs() >= 2.0 ** -14).float().mean().item() > 0.98 and ((wcl - whi.float()).half().float().abs() < 2.0 ** -14).float().mean().item() > 0.5, \
             "the scaled lo halves must be normal fp16 numbers (most unscaled ones are subnormal)"
         w16 = torch.zeros(Cout, kt, kh, kw, cp, dtype=torch.float16)
         w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, wlo, whi
