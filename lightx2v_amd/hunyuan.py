@@ -310,6 +310,70 @@ class HunyuanTransformerInfer:
         return x
 
 
+
+class HunyuanTransformerInferTeaCaching(HunyuanTransformerInfer):
+    """reference: hunyuan/infer/feature_caching/transformer_infer.py:7-135 — TeaCache around the fused block stack.  After every forward the
+    first double block's modulated input of the returned image tokens (LayerNorm + modulate with `img_mod(vec)` — applied to vec WITHOUT the
+    SiLU the blocks put in front, as the reference does, :21) is compared with the previous step's: the polynomial-rescaled relative L1
+    change accumulates in `accumulated_rel_l1_distance`; while it stays below `teacache_thresh` the NEXT step skips the block stack and
+    re-applies the cached residual img_out - img_in (`scheduler.caching_records[i + 1]`).  First and last step always compute.  The decision
+    is host-side control flow exactly as in the reference (one .item() per step); LayerNorm+modulate is the HIP kernel, the two [L, D]
+    elementwise passes (residual capture / re-apply) run on the gate-residual kernel."""
+
+    COEFFICIENTS = [7.33226126e02, -4.01131952e02, 6.75869174e01, -3.14987800e00, 9.61237896e-02]
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.teacache_thresh = config["teacache_thresh"]
+        self.accumulated_rel_l1_distance = 0
+        self.previous_modulated_input = None
+        self.previous_residual = None
+        self.coefficients = list(self.COEFFICIENTS)
+        self._minus_one = None
+
+    def calculate_should_calc(self, img, vec, weights):
+        import numpy as np
+
+        mod = weights.double_blocks[0].img_mod.apply(vec)  # [1, 6 D]: shift, scale, ... of block 0 (no SiLU: reference :21)
+        D = self.hidden_size
+        modulated = lib.layernorm(img, scale=mod[:, D : 2 * D], shift=mod[:, :D], eps=1e-6)
+        index = self.scheduler.step_index
+        if index == 0 or index == self.scheduler.infer_steps - 1:
+            should_calc = True
+            self.accumulated_rel_l1_distance = 0
+        else:
+            prev = self.previous_modulated_input
+            rel = ((modulated - prev).abs().mean() / prev.abs().mean()).cpu().item()
+            self.accumulated_rel_l1_distance += np.poly1d(self.coefficients)(rel)
+            should_calc = not (self.accumulated_rel_l1_distance < self.teacache_thresh)
+            if should_calc:
+                self.accumulated_rel_l1_distance = 0
+        self.previous_modulated_input = modulated
+        return should_calc
+
+    def infer(self, weights, img, txt, vec, cu_seqlens_qkv, max_seqlen_qkv, freqs_cis, token_replace_vec=None, frist_frame_token_num=None):
+        index = self.scheduler.step_index
+        records = self.scheduler.caching_records
+        if records[index]:
+            ori = img.clone()
+            img, vec = super().infer(weights, img, txt, vec, cu_seqlens_qkv, max_seqlen_qkv, freqs_cis, token_replace_vec, frist_frame_token_num)
+            if self._minus_one is None or self._minus_one.device != img.device:
+                self._minus_one = torch.full((img.shape[1],), -1.0, dtype=img.dtype, device=img.device)
+            res = img.clone()
+            lib.gate_residual_(res, ori, self._minus_one)  # res = img_out - img_in (bf16, as the reference's tensor subtraction :116)
+            self.previous_residual = res
+        else:
+            img = img.contiguous()
+            lib.gate_residual_(img, self.previous_residual)  # img += previous_residual (:121)
+        if index <= self.scheduler.infer_steps - 2:
+            records[index + 1] = self.calculate_should_calc(img, vec, weights)
+        return img, vec
+
+    def clear(self):
+        self.previous_modulated_input = None
+        self.previous_residual = None
+
+
 def _t_embed(t, device):
     """pre_infer.py:62-64: cos|sin of t * exp(-ln(1e4) j/128), fp32 → bf16, [1, 256] (256 values: host-side glue)."""
     freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=128, dtype=torch.float32, device=device) / 128)
@@ -409,6 +473,7 @@ class HunyuanScheduler:
         self.sigmas = (self.shift * sig) / (1 + (self.shift - 1) * sig)
         self.timesteps = (self.sigmas[:-1] * 1000).to(dtype=torch.float32, device=self.device)
         self.step_index, self.latents, self.noise_pred = 0, None, None
+        self.caching_records = [True] * self.infer_steps  # schedulers/scheduler.py:11 (read and written by the TeaCache driver)
 
     def prepare(self, latents):
         """latents: [1,16,T,H,W] (the reference draws them from a device generator, scheduler.py:262-264; parity runs feed a file)."""
@@ -447,7 +512,11 @@ class HunyuanModel:
         self.pre_weight, self.post_weight, self.transformer_weights = HunyuanPreWeights(config), HunyuanPostWeights(config), HunyuanTransformerWeights(config)
         for w in (self.pre_weight, self.post_weight, self.transformer_weights):
             w.load(weight_dict)
-        self.pre_infer, self.post_infer, self.transformer_infer = HunyuanPreInfer(config), HunyuanPostInfer(config), HunyuanTransformerInfer(config)
+        fc = config.get("feature_caching", "NoCaching")  # reference: hunyuan/model.py:55-66
+        if fc not in ("NoCaching", "Tea"):
+            raise NotImplementedError(f"feature_caching={fc}: only 'NoCaching' and 'Tea' are built")
+        tr_cls = HunyuanTransformerInferTeaCaching if fc == "Tea" else HunyuanTransformerInfer
+        self.pre_infer, self.post_infer, self.transformer_infer = HunyuanPreInfer(config), HunyuanPostInfer(config), tr_cls(config)
 
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler

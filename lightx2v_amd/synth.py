@@ -166,6 +166,7 @@ HUNYUAN_DIMS = {
     "hunyuan-13b": dict(hidden=3072, heads=24, mlp=12288, double_blocks=20, single_blocks=40, text_dim=4096, text_dim_2=768, text_len=256, refiner_mlp=12288),
     "hunyuan-tiny": dict(hidden=256, heads=2, mlp=512, double_blocks=2, single_blocks=3, text_dim=64, text_dim_2=64, text_len=16, refiner_mlp=512),
 }
+HUNYUAN_TEACACHE_TINY_THRESH = 0.33  # TeaCache threshold of the tiny fixture (tests/golden/hunyuan_teacache.safetensors): a mix of computed and skipped steps
 HUNYUAN_WORKLOADS = {
     # latent target_shape (1, 16, T, H, W): 720p x 129 frames (BASELINE config #5) and a plumbing size
     "hunyuan13b_720px129f": dict(model="hunyuan-13b", target_shape=(1, 16, 33, 90, 160), frames=129),

@@ -330,6 +330,83 @@ def gen_hunyuan(name="hunyuan-tiny", seed=4):
     print("hunyuan_tiny.safetensors:", len(out), "tensors; noise_pred", tuple(out["noise_pred"].shape), out["noise_pred"].dtype)
 
 
+def gen_hunyuan_teacache(name="hunyuan-tiny", seed=4, steps=10, thresh=None):
+    """HunyuanVideo TeaCache fixture (hunyuan/infer/feature_caching/transformer_infer.py:7-135): the reference's own
+    `HunyuanTransformerInferTeaCaching` inside a `steps`-step denoise loop at the tiny width — the reference's pre-infer / post-infer per step, its
+    TeaCache class deciding per step whether the block stack runs or the cached residual is re-applied, the Euler update
+    (schedulers/hunyuan/scheduler.py:256-260, restated: the scheduler class itself needs `diffusers`).  Stored: the per-step decisions
+    (caching_records), the accumulated distances, the transformer output and the latents of every step."""
+    ref_import.patch_and_import()
+    from easydict import EasyDict
+    from lightx2v.common.modules.weight_module import WeightModule, WeightModuleList
+    from lightx2v.models.networks.hunyuan.infer.feature_caching.transformer_infer import HunyuanTransformerInferTeaCaching
+    from lightx2v.models.networks.hunyuan.infer.post_infer import HunyuanPostInfer
+    from lightx2v.models.networks.hunyuan.infer.pre_infer import HunyuanPreInfer
+    from lightx2v.models.networks.hunyuan.weights.post_weights import HunyuanPostWeights
+    from lightx2v.models.networks.hunyuan.weights.pre_weights import HunyuanPreWeights
+    from lightx2v.models.networks.hunyuan.weights.transformer_weights import HunyuanTransformerDoubleBlock, HunyuanTransformerSingleBlock, HunyuanTransformerWeights
+    from lightx2v.models.schedulers.hunyuan import scheduler as ref_sched
+    from oracle import hunyuan_oracle as HO
+
+    dims = synth.HUNYUAN_DIMS[name]
+    ts = synth.HUNYUAN_WORKLOADS[name]["target_shape"]
+    wd = synth.synth_hunyuan_weights(dims, seed=seed)
+    lat, text_states, text_mask, text_states_2 = synth.synth_hunyuan_inputs(dims, ts)
+    thresh = synth.HUNYUAN_TEACACHE_TINY_THRESH if thresh is None else thresh
+    cfg = EasyDict(task="t2v", do_mm_calib=False, mm_config={}, attention_type="torch_sdpa", cpu_offload=False, feature_caching="Tea", teacache_thresh=thresh)
+    timesteps, sigmas = ref_sched.set_timesteps_sigmas(steps, 7.0, device=torch.device("cpu"))
+    fc, fs = ref_sched.get_nd_rotary_pos_embed([16, 56, 56], [ts[2], ts[3] // 2, ts[4] // 2], theta=256, use_real=True, theta_rescale_factor=1)
+
+    class Sched:  # what pre-/post-infer and the TeaCache class read (pre_infer.py:15-19, post_infer.py:19, feature_caching/transformer_infer.py:28,45-56)
+        pass
+
+    sch = Sched()
+    sch.timesteps, sch.infer_steps, sch.caching_records = timesteps, steps, [True] * steps
+    sch.freqs_cos, sch.freqs_sin = fc.to(BF16), fs.to(BF16)
+    sch.guidance = torch.tensor([6.0], dtype=BF16) * 1000.0
+    pre_w, post_w = HunyuanPreWeights(cfg), HunyuanPostWeights(cfg)
+    tr_w = HunyuanTransformerWeights.__new__(HunyuanTransformerWeights)
+    WeightModule.__init__(tr_w)
+    tr_w.config = cfg
+    tr_w.add_module("double_blocks", WeightModuleList([HunyuanTransformerDoubleBlock(i, cfg) for i in range(dims["double_blocks"])]))
+    tr_w.add_module("single_blocks", WeightModuleList([HunyuanTransformerSingleBlock(i, cfg) for i in range(dims["single_blocks"])]))
+    for w in (pre_w, post_w, tr_w):
+        w.load(wd)
+
+    class SDPA4D:
+        def apply(self, q, k, v, attn_mask=None):
+            x = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=attn_mask)
+            x = x.transpose(1, 2)
+            return x.reshape(x.shape[0], x.shape[1], -1)
+
+    pre_w.txt_in_attn_1 = SDPA4D()
+    pre, tr, post = HunyuanPreInfer(cfg), HunyuanTransformerInferTeaCaching(cfg), HunyuanPostInfer(cfg)
+    pre.heads_num = tr.heads_num = dims["heads"]
+    tr.hidden_size, tr.mlp_hidden_dim = dims["hidden"], dims["mlp"]
+    tr.double_blocks_num, tr.single_blocks_num = dims["double_blocks"], dims["single_blocks"]
+    for m in (pre, post, tr):
+        m.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"text_encoder_1_text_states": text_states, "text_encoder_1_attention_mask": text_mask, "text_encoder_2_text_states": text_states_2}}
+    out = dict(latents0=lat, thresh=torch.tensor([thresh], dtype=torch.float64), timesteps=timesteps, sigmas=sigmas)
+    latents, acc = lat.clone(), []
+    with torch.no_grad():
+        for i in range(steps):
+            sch.step_index, sch.latents = i, latents.to(BF16)
+            img, txt, vec, cu, max_len, freqs = pre.infer(pre_w, inputs)
+            img_o, vec_o = tr.infer(tr_w, img, txt, vec, cu, max_len, freqs)
+            noise_pred = post.infer(post_w, img_o, vec_o)
+            latents = HO.euler_step(latents, noise_pred, sigmas, i)
+            acc.append(float(tr.accumulated_rel_l1_distance))
+            out[f"tr_img_{i}"] = img_o.clone()
+            out[f"latents_{i}"] = latents.clone()
+    out["records"] = torch.tensor([int(bool(r)) for r in sch.caching_records])
+    out["accumulated"] = torch.tensor(acc, dtype=torch.float64)
+    out["weights_checksum"] = weights_checksum(wd)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, "hunyuan_teacache.safetensors"))
+    print("hunyuan_teacache.safetensors: records", out["records"].tolist(), "accumulated", [round(a, 4) for a in acc])
+    return out
+
+
 def run_reference_hunyuan(dims, ts, seed):
     """The reference run behind gen_hunyuan for any (dims, latent target_shape, seed): returns the tensor dict (also used live by
     tests/test_oracle_golden.py on shapes the committed fixture does not hold)."""
@@ -523,7 +600,7 @@ def gen_converter():
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "converter", "hunyuan_vae", "fp8"]
+    which = sys.argv[1:] or ["ops", "model", "sched", "vae", "hunyuan", "teacache", "hunyuan_teacache", "converter", "hunyuan_vae", "fp8"]
     if "ops" in which:
         gen_ops()
     if "model" in which:
@@ -536,6 +613,8 @@ if __name__ == "__main__":
         gen_hunyuan()
     if "teacache" in which:
         gen_teacache()
+    if "hunyuan_teacache" in which:
+        gen_hunyuan_teacache()
     if "converter" in which:
         gen_converter()
     if "hunyuan_vae" in which:

@@ -20,6 +20,7 @@ provides that symbol, everything checked here (sigmas, timesteps, RoPE tables, E
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -148,6 +149,48 @@ def transformer_infer(wd, dims, img, txt, vec, cu_seqlens, freqs):
     for i in range(dims["single_blocks"]):
         x = single_block(wd, i, x, vec, txt.shape[0], freqs, dims["heads"], dims["hidden"], cu_seqlens)
     return x[: img.shape[0]], vec
+
+
+class TeaCacheOracle:
+    """hunyuan/infer/feature_caching/transformer_infer.py:7-135 (HunyuanTransformerInferTeaCaching) restated.  After every forward the
+    first double block's modulated input of the RETURNED image tokens decides whether the NEXT step runs the block stack: the polynomial-
+    rescaled relative L1 change against the previous step's modulated input is accumulated; below `thresh` the next step re-applies the cached
+    residual img_out - img_in instead.  The first and the last step always compute.  Quirk kept (:21): the modulation is `img_mod(vec)`
+    WITHOUT the SiLU the blocks apply in front of it.  Pinned bit-exactly to tests/golden/hunyuan_teacache.safetensors."""
+
+    COEFFICIENTS = [7.33226126e02, -4.01131952e02, 6.75869174e01, -3.14987800e00, 9.61237896e-02]
+
+    def __init__(self, infer_steps, thresh):
+        self.infer_steps, self.thresh = infer_steps, thresh
+        self.records = [True] * infer_steps
+        self.accumulated = 0
+        self.prev_mod = None
+        self.prev_res = None
+
+    def should_calc(self, wd, step_index, img, vec):  # calculate_should_calc :17-43
+        sh, sc, _, _, _, _ = _lin(wd, "double_blocks.0.img_mod.linear", vec.clone()).chunk(6, dim=-1)
+        mod = F.layer_norm(img.clone(), (img.shape[1],), None, None, 1e-6) * (1 + sc) + sh
+        if step_index == 0 or step_index == self.infer_steps - 1:
+            calc = True
+            self.accumulated = 0
+        else:
+            self.accumulated += np.poly1d(self.COEFFICIENTS)(((mod - self.prev_mod).abs().mean() / self.prev_mod.abs().mean()).cpu().item())
+            calc = not (self.accumulated < self.thresh)
+            if calc:
+                self.accumulated = 0
+        self.prev_mod = mod
+        return calc
+
+    def infer(self, wd, dims, step_index, img, txt, vec, cu_seqlens, freqs):  # infer :45-58
+        if self.records[step_index]:
+            ori = img.clone()
+            img, vec = transformer_infer(wd, dims, img, txt, vec, cu_seqlens, freqs)
+            self.prev_res = img - ori
+        else:
+            img = img + self.prev_res  # `img += previous_residual` (:121)
+        if step_index <= self.infer_steps - 2:
+            self.records[step_index + 1] = self.should_calc(wd, step_index, img, vec)
+        return img, vec
 
 
 # ----------------------------------------------------------------------------- pre / post

@@ -60,6 +60,7 @@ def test_multi_gpu_launch_contract(script):
     import torch
 
     if not torch.cuda.is_available():
-        assert p.returncode != 0 and "rank 0 needs cuda:0" in text and "rank 1 needs cuda:1" in text
+        # the launcher tears the other rank down as soon as one exits, so only one of the two messages is guaranteed to make it out
+        assert p.returncode != 0 and ("rank 0 needs cuda:0" in text or "rank 1 needs cuda:1" in text)
     p = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert p.returncode != 0 and "--nproc-per-node must equal --gpus" in (p.stderr + p.stdout)

@@ -138,3 +138,47 @@ def test_forward_default_rounding_fast_attention(setup):
     sch.step_pre(1)
     model.infer(_inputs(g))
     assert_rel(sch.noise_pred, g["noise_pred"], 2e-2, "HunyuanModel.infer (default rounding)")
+
+
+@pytest.mark.parametrize("ref_rounding", [False, True])
+def test_hunyuan_teacache_matches_the_reference_run(ref_rounding):
+    """HunyuanModel(feature_caching="Tea") over the 10-step loop of tests/golden/hunyuan_teacache.safetensors (generated by running the
+    reference's own HunyuanTransformerInferTeaCaching, hunyuan/infer/feature_caching/transformer_infer.py:7-135): the same per-step
+    decisions — steps 2 and 3 re-apply the cached residual — and latents / transformer outputs within the model-level tolerances
+    (the skipped steps must reproduce `img += previous_residual` to rounding: their error is the previous computed step's)."""
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import hunyuan as hy, synth
+    from tests.util import rel_l2
+
+    g = load_file(os.path.join(GOLDEN, "hunyuan_teacache.safetensors"))
+    dims = synth.HUNYUAN_DIMS["hunyuan-tiny"]
+    ts = synth.HUNYUAN_WORKLOADS["hunyuan-tiny"]["target_shape"]
+    wd = synth.synth_hunyuan_weights(dims, seed=4)
+    lat, text_states, text_mask, text_states_2 = synth.synth_hunyuan_inputs(dims, ts)
+    steps = g["records"].numel()
+    cfg = hy.default_config(dims, infer_steps=steps, hip_ref_rounding=ref_rounding, feature_caching="Tea", teacache_thresh=float(g["thresh"]))
+    model = hy.HunyuanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+    assert type(model.transformer_infer) is hy.HunyuanTransformerInferTeaCaching
+    sch = hy.HunyuanScheduler(cfg)
+    sch.prepare(lat)
+    model.set_scheduler(sch)
+    inputs = {"text_encoder_output": {"text_encoder_1_text_states": text_states.cuda(), "text_encoder_1_attention_mask": text_mask.cuda(),
+                                      "text_encoder_2_text_states": text_states_2.cuda()}}
+    outs = []
+    orig = model.transformer_infer.infer
+
+    def spy(*a, **kw):
+        img, vec = orig(*a, **kw)
+        outs.append(img.float().cpu().clone())
+        return img, vec
+
+    model.transformer_infer.infer = spy
+    for i in range(steps):
+        sch.step_pre(i)
+        model.infer(inputs)
+        sch.step_post()
+        assert rel_l2(outs[i], g[f"tr_img_{i}"]) <= 3e-2, (i, rel_l2(outs[i], g[f"tr_img_{i}"]))
+        assert rel_l2(sch.latents, g[f"latents_{i}"]) <= 3e-2, (i, rel_l2(sch.latents, g[f"latents_{i}"]))
+    assert [int(bool(r)) for r in sch.caching_records] == g["records"].tolist(), sch.caching_records
+    assert g["records"].tolist().count(0) == 2

@@ -175,6 +175,48 @@ def test_hunyuan_oracle_bit_exact():
     assert torch.equal(c2, fc) and torch.equal(s2, fs)
 
 
+def _hunyuan_teacache_inputs(g):
+    from lightx2v_amd import synth
+
+    dims = synth.HUNYUAN_DIMS["hunyuan-tiny"]
+    ts = synth.HUNYUAN_WORKLOADS["hunyuan-tiny"]["target_shape"]
+    wd = synth.synth_hunyuan_weights(dims, seed=4)
+    lat, text_states, text_mask, text_states_2 = synth.synth_hunyuan_inputs(dims, ts)
+    assert torch.equal(lat, g["latents0"])
+    return dims, ts, wd, text_states, text_mask, text_states_2
+
+
+def test_hunyuan_teacache_oracle_bit_exact():
+    """oracle.hunyuan_oracle.TeaCacheOracle inside the oracle's 10-step loop reproduces the run of the reference's own
+    HunyuanTransformerInferTeaCaching (tests/golden/hunyuan_teacache.safetensors, oracle/gen_golden.py::gen_hunyuan_teacache): same per-step
+    decisions (two consecutive skipped steps among them), same accumulated distances, bit-identical transformer outputs and latents."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from oracle import hunyuan_oracle as H
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hunyuan_teacache.safetensors"))
+    dims, ts, wd, text_states, text_mask, text_states_2 = _hunyuan_teacache_inputs(g)
+    steps, thresh = g["records"].numel(), float(g["thresh"])
+    assert g["records"].tolist() == [1, 1, 0, 0, 1, 1, 1, 1, 1, 1], "the fixture must hold skipped steps"
+    timesteps, sigmas = H.set_timesteps_sigmas(steps, 7.0)
+    assert torch.equal(timesteps, g["timesteps"]) and torch.equal(sigmas, g["sigmas"])
+    freqs = H.rope_tables([ts[2], ts[3] // 2, ts[4] // 2])
+    guidance = torch.tensor([6.0], dtype=torch.bfloat16) * 1000.0
+    tea = H.TeaCacheOracle(steps, thresh)
+    latents = g["latents0"].clone()
+    with torch.no_grad():
+        for i in range(steps):
+            img, txt, vec, cu, _ = H.pre_infer(wd, dims, latents.to(torch.bfloat16), timesteps[i], guidance, text_states, text_mask, text_states_2)
+            img, vec = tea.infer(wd, dims, i, img, txt, vec, cu, freqs)
+            assert torch.equal(img, g[f"tr_img_{i}"]), f"step {i}: transformer output"
+            latents = H.euler_step(latents, H.post_infer(wd, img, vec, latents.shape), sigmas, i)
+            assert torch.equal(latents, g[f"latents_{i}"]), f"step {i}: latents"
+            assert float(tea.accumulated) == float(g["accumulated"][i]), (i, tea.accumulated, g["accumulated"][i])
+    assert [int(r) for r in tea.records] == g["records"].tolist()
+
+
 def test_teacache_oracle_bit_exact():
     """TeaCacheOracle + the oracle denoise loop reproduce the reference's WanTransformerInferTeaCaching run: same
     calc/skip decisions in both CFG branches and bit-identical latents after every step, both `use_ret_steps` modes."""
