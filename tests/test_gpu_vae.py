@@ -241,8 +241,14 @@ def test_vae_decode_split_fp16_is_fp32_grade():
     w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, ((wcl - whi.float()) * 4096).half(), whi
     out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
     lib.vae_conv16(buf, strides, w16.cuda(), out, T, H, W, bias=torch.zeros(Cout).cuda())
-    scale = ref.abs().max().item()
-    assert (out.cpu() - ref).abs().max().item() <= 4e-6 * scale, ((out.cpu() - ref).abs().max().item(), scale)
+    err = (out.cpu() - ref).abs()
+    near = torch.zeros(T, H, W, dtype=torch.bool)
+    near[0, 2:5, 4:7] = True  # outputs whose 3x3 window holds the out-of-range pixel
+    scale_far, scale_near = ref[~near].abs().max().item(), ref[near].abs().max().item()
+    # in range: fp32-grade.  Out of range: hi saturates, lo = x - 65504 is O(x), so the dropped lo.lo product is 2^-12 of that pixel's term — the
+    # guard buys a finite, 11-bit-accurate result where an unguarded split would produce inf / NaN
+    assert err[~near].max().item() <= 4e-6 * scale_far, (err[~near].max().item(), scale_far)
+    assert err[near].max().item() <= 2.0 ** -10 * scale_near, (err[near].max().item(), scale_near)
     gld = load_file(os.path.join(GOLDEN, "wan_vae_tiny.safetensors"))
     dim, seed = int(gld["dim"]), int(gld["seed"])
     sd_t = synth.synth_wan_vae_weights(dim=dim, seed=seed)
