@@ -390,7 +390,10 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, S, ts, dims["text_len"], wl["frames"], args.infer_steps, fwd, args.cpu_baseline_rows, not args.no_cpu_config1)
+            try:
+                out["cpu_baseline"] = cpu_baseline(dims, S, ts, dims["text_len"], wl["frames"], args.infer_steps, fwd, args.cpu_baseline_rows, not args.no_cpu_config1)
+            except Exception as e:  # noqa: BLE001 — the measured line must not be lost to a host-side failure (e.g. out of host memory)
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {type(e).__name__}: {str(e)[:200]}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
