@@ -113,7 +113,7 @@ def hunyuan_checks(r, n, ulysses, O):
     (attentions/distributed/ulysses/attn.py:7-91) and hunyuan processor (utils/hunyuan/processor.py:5-77) in this same 2-process run."""
     gen = torch.Generator().manual_seed(11)
     H, d = 2 * n, 128
-    t_, hh, ww = 2, 4, 6  # token grid (latent 8 x 12): split along h when h % n == 0 (world 2), else along w (world 3)
+    t_, hh, ww = (2, 4, 6) if n <= 3 else (2, n, 3)  # token grid (latent 8 x 12): split along h when h % n == 0 (world 2), else along w (world 3); world 8: h = 8
     axis = 1 if hh % n == 0 else 2
     n_img_full, n_txt = t_ * hh * ww, 10
     qf, kf, vf = (torch.randn(n_img_full + n_txt, H * d, generator=gen).to(torch.bfloat16) for _ in range(3))
@@ -176,8 +176,9 @@ def hunyuan_checks(r, n, ulysses, O):
     l2, c2, s2, split_dim = ulysses.hunyuan_pre_process(lat, cos, sin)
     assert split_dim == axis - 3 and torch.equal(l2, torch.chunk(lat, n, dim=split_dim)[r]) and torch.equal(c2, cos[mine]) and torch.equal(s2, sin[mine])
     assert torch.equal(ulysses.hunyuan_post_process(l2, split_dim), lat)
-    latw = torch.randn(1, 16, t_, 2 * 3, 2 * ww, generator=gen)  # h = 3: the other axis than above at either world size
-    l3, c3, s3, sd3 = ulysses.hunyuan_pre_process(latw, torch.randn(t_ * 3 * ww, d, generator=gen), torch.randn(t_ * 3 * ww, d, generator=gen))
+    w3 = ww if n <= 3 else n  # world 8: a w axis the group divides
+    latw = torch.randn(1, 16, t_, 2 * 3, 2 * w3, generator=gen)  # h = 3: the other axis than above at either world size
+    l3, c3, s3, sd3 = ulysses.hunyuan_pre_process(latw, torch.randn(t_ * 3 * w3, d, generator=gen), torch.randn(t_ * 3 * w3, d, generator=gen))
     assert sd3 == (-2 if 3 % n == 0 else -1) and torch.equal(ulysses.hunyuan_post_process(l3, sd3), latw)
 
     from oracle import ref_import
@@ -195,7 +196,7 @@ def hunyuan_checks(r, n, ulysses, O):
         rl, rc, rs, rsd = ref_proc.pre_process(lat, cos, sin)
         assert rsd == split_dim and torch.equal(rl, l2) and torch.equal(rc, c2) and torch.equal(rs, s2)
         assert torch.equal(ref_proc.post_process(rl.contiguous(), rsd), ulysses.hunyuan_post_process(l2, split_dim))
-        rl3, _, _, rsd3 = ref_proc.pre_process(latw, torch.zeros(t_ * 3 * ww, d), torch.zeros(t_ * 3 * ww, d))
+        rl3, _, _, rsd3 = ref_proc.pre_process(latw, torch.zeros(t_ * 3 * w3, d), torch.zeros(t_ * 3 * w3, d))
         assert rsd3 == sd3 and torch.equal(rl3, l3)
         if r == 0:
             print("REFERENCE_HUNYUAN_EXCHANGE_OK")
