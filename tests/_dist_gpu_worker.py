@@ -36,9 +36,13 @@ def main():
     from lightx2v_amd import lib, scheduler, synth, wan
 
     lib.init(0)
-    # 4 heads so that H % 2 == 0 with 2 heads per rank; S = 3*6*5 = 90 tokens -> 45 per rank (ragged vs the 32/64 tiles)
-    dims = dict(synth.WAN_DIMS["wan-tiny"], dim=512, num_heads=4, ffn_dim=1024, num_layers=2)
-    ts = (16, 3, 12, 10)
+    # 4 heads so that H % 2 == 0 with 2 heads per rank; S = 3*6*5 = 90 tokens -> 45 per rank (ragged vs the 32/64 tiles).  World 8 (the node
+    # size, all ranks on the one GPU): 8 heads, 3*8*6 = 144 tokens -> 18 per rank.  (A token count the group does not divide is zero-padded
+    # and — a reference quirk kept bit for bit, ulysses/attn.py:60-66 — the pad rows then take part in the attention as keys, so the sharded
+    # forward legitimately differs from the single-GPU one: 2.9e-2 with 6 pad rows among 96.  The 720p grids divide by 8.)
+    heads = max(4, n)
+    dims = dict(synth.WAN_DIMS["wan-tiny"], dim=128 * heads, num_heads=heads, ffn_dim=1024, num_layers=2)
+    ts = (16, 3, 12, 10) if n == 2 else (16, 3, 16, 12)
     wd = synth.synth_wan_weights(dims, seed=3)
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}

@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_ulysses_world2_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ulysses_world2_on_one_gpu(world):
+    """world 8 = the node size, all eight ranks driving the one GPU of the box: the HIP Ulysses path (blocked exchange buffers, K-blocked output
+    projection, sharded RoPE offsets with padding rows, the CFG branches on two streams) at the partitioning the scaling bench uses."""
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29541 + 10 * (world > 2)),
            os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
