@@ -208,7 +208,7 @@ def ulysses_self_check(dist, world, rank):
     if path is None:
         raise SystemExit("bench: no Ulysses exchange path works on this node: " + " | ".join(errors))
     rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).reshape(1)
-    worst = rel.clone()
+    worst = rel.clone() if dist.get_backend() == "nccl" else rel.cpu().clone()
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     ok = bool(worst.item() < 5e-3)
     if not ok:
@@ -228,7 +228,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if launch.one_gpu_test():  # plumbing mode: N ranks on ONE GPU over gloo with host-staged collectives (lightx2v_amd/launch.py) — timings meaningless
+            dist.init_process_group("gloo")
+            launch.host_staged_collectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from lightx2v_amd import lib, scheduler, synth, wan
 
@@ -297,7 +301,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
     assert torch.isfinite(sch.latents).all(), "non-finite latents"
@@ -353,7 +357,7 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "mxfp8 (e4m3 + e8m0/32) GEMMs, bf16 attention" if args.mxfp8 else "fp8-e4m3 w8a8 GEMMs, bf16 attention" if args.fp8 else "bf16",
-        "data": "synthetic",
+        "data": "synthetic" if not launch.one_gpu_test() else "synthetic — PLUMBING RUN: all ranks share one GPU over gloo with host-staged collectives, timings meaningless",
         "config": {
             "workload": args.workload,
             "tokens": S,

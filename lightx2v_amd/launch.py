@@ -32,6 +32,39 @@ def ranks(script_path, gpus):
         raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     import torch
 
+    if one_gpu_test():
+        return world, rank, 0
     if torch.cuda.device_count() < local_rank + 1:
         raise SystemExit(f"{os.path.basename(script_path)}: rank {rank} needs cuda:{local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     return world, rank, local_rank
+
+
+def one_gpu_test():
+    """X2V_ONE_GPU_TEST=1: a PLUMBING mode for boxes with a single GPU — every rank drives cuda:0, the process group is gloo and the two collective
+    entry points the Ulysses driver uses stage device tensors through host memory (`host_staged_collectives`).  It exists so that the N-rank code
+    paths of the drivers (self-check, branch streams, timers, JSON assembly) can be executed before a multi-GPU node ever sees them; its timings mean
+    nothing and the drivers say so in their output."""
+    return os.environ.get("X2V_ONE_GPU_TEST") == "1"
+
+
+def host_staged_collectives(dist):
+    """Wrap dist.all_to_all_single / dist.all_gather_into_tensor so that device tensors travel through host memory (gloo has no device path
+    here).  Test plumbing for `one_gpu_test()` only."""
+    import torch
+
+    def staged(fn):
+        def wrapped(out, inp, *a, **kw):
+            if out.is_cuda:
+                torch.cuda.current_stream().synchronize()
+                o, i = torch.empty(out.shape, dtype=out.dtype), inp.detach().cpu()
+                r = fn(o, i, *a, **kw)
+                out.copy_(o)
+                return r
+            return fn(out, inp, *a, **kw)
+
+        return wrapped
+
+    if not getattr(dist.all_to_all_single, "_x2v_staged", False):
+        dist.all_to_all_single = staged(dist.all_to_all_single)
+        dist.all_to_all_single._x2v_staged = True
+        dist.all_gather_into_tensor = staged(dist.all_gather_into_tensor)

@@ -15,6 +15,8 @@ WAN_DIMS = {
     "wan2.1-14b": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, text_len=512, text_dim=4096),
     # miniature used by CPU tests / golden vectors (same head_dim=128 so RoPE split [22,21,21] is exercised)
     "wan-tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_len=32, text_dim=64),
+    # 8 heads: the smallest model a group of 8 ranks can share (Ulysses needs heads % N == 0); plumbing runs of the N-rank code paths
+    "wan-tiny-h8": dict(dim=1024, ffn_dim=2048, num_heads=8, num_layers=2, text_len=32, text_dim=64),
 }
 
 # BASELINE.json workloads: latent target_shape (C, T, H, W) (reference: wan_runner.py:260-280)
@@ -23,6 +25,7 @@ WORKLOADS = {
     "wan1.3b_480px49f": dict(model="wan2.1-1.3b", target_shape=(16, 13, 60, 104), frames=49),
     "wan14b_720px81f": dict(model="wan2.1-14b", target_shape=(16, 21, 90, 160), frames=81),
     "wan-tiny": dict(model="wan-tiny", target_shape=(16, 3, 8, 8), frames=9),
+    "wan-tiny-h8": dict(model="wan-tiny-h8", target_shape=(16, 3, 16, 12), frames=9),  # 144 tokens: divisible by 8
 }
 
 

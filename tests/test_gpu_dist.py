@@ -57,3 +57,28 @@ def test_ulysses_over_rccl_world1():
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_GPU_RCCL1_OK" in p.stdout
+
+
+def test_bench_n8_code_path_on_one_gpu():
+    """`python bench.py --gpus 8` END TO END on a one-GPU box (X2V_ONE_GPU_TEST=1: all ranks drive cuda:0 over gloo with host-staged collectives,
+    lightx2v_amd/launch.py): the self-launch under torch.distributed.run, the Ulysses self-check walking the designed path (CFG branches on two
+    streams, blocked buffers, two-piece head->seq), the per-instance settings handed to the timed model, the timed loop with barriers and the
+    max-over-ranks reduction, the per-launch attention timers and the JSON line.  Everything the 8-GPU scaling run executes except RCCL itself;
+    the timings mean nothing and the line says so."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", X2V_ONE_GPU_TEST="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "wan-tiny-h8", "--steps", "2", "--warmup", "1", "--infer-steps", "4"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["rccl_world"] == 8 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "PLUMBING RUN" in d["data"]
+    sp = d["sp_self_check"]
+    assert sp["passed"] and sp["ranks"] == 8 and sp["worst_rel_l2"] < 5e-3, sp
+    assert sp["settings"] == {"cfg_branch_streams": True, "blocked_exchange": True, "split_head2seq": True}, sp
+    assert d["config"]["parallelism"] == "ulysses-sp8"
+    r = d["roofline"]
+    assert r["launches_timed"] == 2 * 2 * 2 * 2 and r["forwards_per_launch"] == 0.5, r  # 2 steps x 2 layers x 2 CFG branches x 2 head->seq pieces
