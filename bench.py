@@ -324,7 +324,7 @@ def main():
     launches_per_step = n_self / max(1, args.steps)
     forwards_per_launch = dims["num_layers"] * fwd / max(launches_per_step, 1e-9)
     flop_self *= forwards_per_launch
-    # roofline object = the self-attention launches of the dominant kernel (x2v::attn_fwd_v8_kernel: 99 % of the attention
+    # roofline object = the self-attention launches of the dominant kernel (x2v::attn_fwd_v9_kernel: 99 % of the attention
     # FLOPs, 72 % of the step's); cross-attention runs a different instantiation and is reported beside it
     attn_ms = ms_self / max(n_self, 1)
     flop_launch = flop_self

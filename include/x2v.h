@@ -169,7 +169,8 @@ int x2v_attn_fwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 
 /* Same, selecting the lazy-rescale threshold of the online softmax (validation hook for the rare, data-dependent rescale branch: the three
  * must agree to rounding): 0 = default (= 6), 4 = rescale O on every tile, 5 = when a row max grew by more than 4 (base-2 units), 6 = by
- * more than 8.  X2V_ATTN_Q_PRESCALED is the flag of x2v_attn_fwd_bf16_vt's `q_prescaled` argument. */
+ * more than 8.  X2V_ATTN_Q_PRESCALED is a flag of the Python layer's `variant` word (lib.attention); at the C-ABI the pre-scaled-q form is
+ * X2V_ATTN_VT_PRESCALED in x2v_attn_fwd_bf16_vt's `flags`. */
 #define X2V_ATTN_Q_PRESCALED 0x100
 #define X2V_ATTN_LOG2E_SCALE(head_dim_rsqrt) ((head_dim_rsqrt) * 1.4426950408889634f)
 int x2v_attn_fwd_bf16_variant(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, int64_t Sq,
