@@ -151,6 +151,84 @@ def transformer_infer(wd, dims, img, txt, vec, cu_seqlens, freqs):
     return x[: img.shape[0]], vec
 
 
+# ----------------------------------------------------------------------------- blocks on a row subset (full-size parity)
+def _rope1(x, cos, sin):
+    """apply_rotary_emb for one tensor (same statements; utils_bf16.py:11-31)."""
+    L, H, D = x.shape
+    re, im = x.reshape(L, H, -1, 2).unbind(-1)
+    return x * cos.view(L, 1, D) + torch.stack([-im, re], dim=-1).flatten(2) * sin.view(L, 1, D)
+
+
+def _attend_rows(q_sel, sel_pos, k, v, cu_seqlens):
+    """varlen attention for selected query rows: q_sel [n, H, D] sit at joint positions `sel_pos` (LongTensor); k / v are ALL joint rows.
+    A query attends the keys of its own [cu[i], cu[i+1]) segment."""
+    out = torch.empty(q_sel.shape[0], q_sel.shape[1] * q_sel.shape[2], dtype=q_sel.dtype)
+    for a, b in zip(cu_seqlens[:-1].tolist(), cu_seqlens[1:].tolist()):
+        m = (sel_pos >= a) & (sel_pos < b)
+        if b > a and bool(m.any()):
+            o = F.scaled_dot_product_attention(q_sel[m].unsqueeze(0).transpose(1, 2), k[a:b].unsqueeze(0).transpose(1, 2), v[a:b].unsqueeze(0).transpose(1, 2)).transpose(1, 2)
+            out[m] = o.reshape(int(m.sum()), -1)
+    return out
+
+
+def double_block_rows(wd, i, img, txt, vec, freqs, heads, cu_seqlens, rows):
+    """`double_block` for a SUBSET of the image rows (all text rows): every op is row-wise except the joint attention, whose keys / values need
+    all rows — LayerNorm + modulate and the k / v thirds of `img_attn_qkv` run on all image rows, everything else on `rows` (LongTensor of
+    image-row indices).  Returns (img_out[rows], txt_out).  Same statements as `double_block` (transformer_infer.py:81-310); the CPU suite
+    requires it to equal double_block(...)[0][rows] to rounding."""
+    p = f"double_blocks.{i}."
+    D = img.shape[1]
+    vec_silu = F.silu(vec)
+    i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2 = _lin(wd, p + "img_mod.linear", vec_silu).chunk(6, dim=-1)
+    t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2 = _lin(wd, p + "txt_mod.linear", vec_silu).chunk(6, dim=-1)
+    cos, sin = freqs
+    x = layer_norm(img) * (1 + i_sc1) + i_sh1
+    W, B = wd[p + "img_attn_qkv.weight"], wd[p + "img_attn_qkv.bias"]
+    kv = mm(x, W[D:], B[D:])
+    L = img.shape[0]
+    ik = _rope1(rms_norm(kv[:, :D].reshape(L, heads, -1), wd[p + "img_attn_k_norm.weight"]), cos, sin)
+    iv = kv[:, D:].reshape(L, heads, -1)
+    iq = _rope1(rms_norm(mm(x[rows], W[:D], B[:D]).reshape(len(rows), heads, -1), wd[p + "img_attn_q_norm.weight"]), cos[rows], sin[rows])
+    y = layer_norm(txt) * (1 + t_sc1) + t_sh1
+    tq, tk, tv = _split_heads(_lin(wd, p + "txt_attn_qkv", y), heads)
+    tq, tk = rms_norm(tq, wd[p + "txt_attn_q_norm.weight"]), rms_norm(tk, wd[p + "txt_attn_k_norm.weight"])
+    n_txt = txt.shape[0]
+    pos = torch.cat((rows, L + torch.arange(n_txt)))
+    attn = _attend_rows(torch.cat((iq, tq), 0), pos, torch.cat((ik, tk), 0), torch.cat((iv, tv), 0), cu_seqlens)
+    n = len(rows)
+    img_r = img[rows] + _lin(wd, p + "img_attn_proj", attn[:n]) * i_g1
+    xr = layer_norm(img_r) * (1 + i_sc2) + i_sh2
+    xr = _lin(wd, p + "img_mlp.fc2", F.gelu(_lin(wd, p + "img_mlp.fc1", xr), approximate="tanh"))
+    txt_n = txt + _lin(wd, p + "txt_attn_proj", attn[n:]) * t_g1
+    yy = layer_norm(txt_n) * (1 + t_sc2) + t_sh2
+    yy = _lin(wd, p + "txt_mlp.fc2", F.gelu(_lin(wd, p + "txt_mlp.fc1", yy), approximate="tanh"))
+    return img_r + xr * i_g2, txt_n + yy * t_g2
+
+
+def single_block_rows(wd, i, x, vec, txt_len, freqs, heads, hidden, cu_seqlens, rows):
+    """`single_block` for a subset of the IMAGE rows plus all text rows (transformer_infer.py:312-384): returns the block's output at joint
+    positions cat(rows, text rows).  The k / v thirds of linear1 run on all rows."""
+    p = f"single_blocks.{i}."
+    shift, scale, gate = _lin(wd, p + "modulation.linear", F.silu(vec)).chunk(3, dim=-1)
+    L = x.shape[0]
+    n_img = L - txt_len
+    sel = torch.cat((rows, n_img + torch.arange(txt_len)))
+    xn = layer_norm(x) * (1 + scale) + shift
+    W, B = wd[p + "linear1.weight"], wd[p + "linear1.bias"]
+    kv = mm(xn, W[hidden : 3 * hidden], B[hidden : 3 * hidden])
+    k = rms_norm(kv[:, :hidden].reshape(L, heads, -1), wd[p + "k_norm.weight"])
+    v = kv[:, hidden:].reshape(L, heads, -1)
+    cos, sin = freqs
+    k = torch.cat((_rope1(k[:n_img], cos, sin), k[n_img:]), 0)
+    xs = xn[sel]
+    q = rms_norm(mm(xs, W[:hidden], B[:hidden]).reshape(len(sel), heads, -1), wd[p + "q_norm.weight"])
+    q = torch.cat((_rope1(q[: len(rows)], cos[rows], sin[rows]), q[len(rows) :]), 0)
+    mlp = mm(xs, W[3 * hidden :], B[3 * hidden :])
+    attn = _attend_rows(q, sel, k, v, cu_seqlens)
+    out = _lin(wd, p + "linear2", torch.cat((attn, F.gelu(mlp, approximate="tanh")), 1))
+    return x[sel] + out * gate
+
+
 class TeaCacheOracle:
     """hunyuan/infer/feature_caching/transformer_infer.py:7-135 (HunyuanTransformerInferTeaCaching) restated.  After every forward the
     first double block's modulated input of the RETURNED image tokens decides whether the NEXT step runs the block stack: the polynomial-

@@ -329,3 +329,43 @@ def test_wan14b_block_720p_pair_pass_vs_oracle_rows():
         record(f"Wan-14B block S=75600 pair pass ({name})", rows=len(rows), rel_l2_vs_oracle=e, err_hip_vs_fp32=e_hip, err_oracle_vs_fp32=e_ref)
         assert e <= 1e-2, f"{name}: relative L2 vs oracle {e:.3e}"
         assert e_hip <= 1.5 * e_ref + 1e-4, f"{name}: err vs fp32 truth {e_hip:.3e} > 1.5 x the bf16 oracle's {e_ref:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ HunyuanVideo blocks at config #5's size
+@pytest.mark.parametrize("kind", ["double", "single"])
+def test_hunyuan13b_block_720p_129f_vs_oracle_rows(kind):
+    """One HunyuanVideo-13B double block / single block (hidden 3072, 24 heads, mlp 12288) at config #5's full token count — 118 800 image tokens
+    (token grid 33 x 45 x 80) + 256 text tokens, 200 of them valid (two attention segments) — through `HunyuanTransformerInfer.infer`, against
+    `oracle.hunyuan_oracle.double_block_rows` / `single_block_rows` (hunyuan/infer/transformer_infer.py:81-384 restricted to sampled image rows;
+    the k / v projections of all 119 056 rows run on the host).  Inputs are seeded tensors at the block boundary; relative L2 <= 1e-2 like the
+    2 560-token version of this test (test_gpu_bench_shapes.py)."""
+    from lightx2v_amd import hunyuan as hy, synth
+    from oracle import hunyuan_oracle as H
+
+    dims = dict(synth.HUNYUAN_DIMS["hunyuan-13b"], double_blocks=1 if kind == "double" else 0, single_blocks=0 if kind == "double" else 1)
+    pref = "double_blocks." if kind == "double" else "single_blocks."
+    wd = {k: v for k, v in synth.synth_hunyuan_weights(dict(dims, double_blocks=1, single_blocks=1), seed=21).items() if k.startswith(pref)}
+    grid = (33, 45, 80)
+    n_img, n_txt, n_valid = grid[0] * grid[1] * grid[2], dims["text_len"], 200
+    assert n_img == 118800 and n_txt == 256
+    gen = torch.Generator().manual_seed(6)
+    img = torch.randn(n_img, dims["hidden"], generator=gen).to(torch.bfloat16)
+    txt = torch.randn(n_txt, dims["hidden"], generator=gen).to(torch.bfloat16)
+    vec = torch.randn(1, dims["hidden"], generator=gen).to(torch.bfloat16)
+    cos, sin = H.rope_tables(list(grid))
+    cu = torch.tensor([0, n_img + n_valid, n_img + n_txt], dtype=torch.int32)
+    rows = sample_rows(n_img, 96, seed=8)
+    with torch.no_grad():
+        if kind == "double":
+            ref, _ = H.double_block_rows(wd, 0, img, txt, vec, (cos, sin), dims["heads"], cu, rows)
+        else:
+            ref = H.single_block_rows(wd, 0, torch.cat((img, txt), 0), vec, n_txt, (cos, sin), dims["heads"], dims["hidden"], cu, rows)[: len(rows)]
+    cfg = hy.default_config(dims, infer_steps=4)
+    tw = hy.HunyuanTransformerWeights(cfg)
+    tw.load({k: v.cuda() for k, v in wd.items()})
+    tr = hy.HunyuanTransformerInfer(cfg)
+    out, _ = tr.infer(tw, img.cuda(), txt.cuda(), vec.cuda(), cu, n_img + n_txt, (cos.cuda(), sin.cuda()))
+    assert out.shape[0] == n_img and torch.isfinite(out.float()).all()
+    e = rel_l2(out[rows.cuda()], ref)
+    record(f"Hunyuan-13B {kind} block at 118800 + 256 tokens", rows=len(rows), rel_l2_vs_oracle=e)
+    assert e <= 1e-2, f"Hunyuan-13B {kind} block at full size: relative L2 vs oracle {e:.3e}"

@@ -63,3 +63,30 @@ def test_truth_precision_block_and_forward():
         tr = O.wan_model_infer(O.upcast(wd), dims, lat.to(torch.bfloat16), t, O.upcast(ctx), O.upcast(ctx), 5.0)
     assert tr.dtype == torch.float32 and 1e-4 < rel_l2(ref, tr) < 5e-2
     assert O._ACT == [torch.bfloat16]
+
+
+def test_hunyuan_block_rows_equal_blocks():
+    """oracle.hunyuan_oracle.double_block_rows / single_block_rows (a block evaluated on a subset of the image rows + all text rows; used by the
+    119 056-token parity test) against the full blocks, with padded text (two attention segments)."""
+    from oracle import hunyuan_oracle as H
+
+    dims = synth.HUNYUAN_DIMS["hunyuan-tiny"]
+    wd = synth.synth_hunyuan_weights(dims, seed=9)
+    gen = torch.Generator().manual_seed(1)
+    grid = (2, 6, 8)
+    n_img, n_txt, n_valid, D = grid[0] * grid[1] * grid[2], dims["text_len"], 11, dims["hidden"]
+    img = torch.randn(n_img, D, generator=gen).to(torch.bfloat16)
+    txt = torch.randn(n_txt, D, generator=gen).to(torch.bfloat16)
+    vec = torch.randn(1, D, generator=gen).to(torch.bfloat16)
+    freqs = H.rope_tables(list(grid))
+    cu = torch.tensor([0, n_img + n_valid, n_img + n_txt], dtype=torch.int32)
+    rows = torch.tensor([0, 1, 17, n_img // 2, n_img - 2, n_img - 1, 5])
+    with torch.no_grad():
+        fi, ft = H.double_block(wd, 0, img, txt, vec, freqs, dims["heads"], cu)
+        ri, rt = H.double_block_rows(wd, 0, img, txt, vec, freqs, dims["heads"], cu, rows)
+        assert rel_l2(ri, fi[rows]) <= 5e-3 and rel_l2(rt, ft) <= 5e-3, (rel_l2(ri, fi[rows]), rel_l2(rt, ft))
+        x = torch.cat((img, txt), 0)
+        fs = H.single_block(wd, 0, x, vec, n_txt, freqs, dims["heads"], D, cu)
+        rs = H.single_block_rows(wd, 0, x, vec, n_txt, freqs, dims["heads"], D, cu, rows)
+        sel = torch.cat((rows, n_img + torch.arange(n_txt)))
+        assert rel_l2(rs, fs[sel]) <= 5e-3, rel_l2(rs, fs[sel])
