@@ -457,3 +457,43 @@ def test_teacache_oracle_bit_exact_against_live_reference(steps, thresh, use_ret
     assert [bool(c) for c in tea.records[False]] == [bool(c) for c in sch.caching_records_2]
     assert 0 < sum(bool(c) for c in sch.caching_records) < steps  # both the compute and the skip path ran
     assert len(mine) == steps and all(torch.equal(a, b) for a, b in zip(mine, ref_lat))
+
+
+def test_fp8_block_mode_bit_exact_against_live_reference_model():
+    """Where /root/reference exists: the reference's Wan forward built with `mm_type: W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Vllm`,
+    `weight_auto_quant` (BASELINE config #4's operator class; the two vLLM kernels are the restated stubs of oracle/ref_shims/vllm, as for
+    tests/golden/fp8_mm.safetensors) against the oracle inside `fp8_blocks()`: the CFG noise prediction of two steps, bit for bit — pins WHICH
+    layers are w8a8 (the blocks' ten linears, not pre-/post-infer) and how the quantised operator composes with the rest of the graph."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present (authoring container only)")
+    ref_import.patch_and_import()
+    from lightx2v.models.schedulers.wan.scheduler import WanScheduler as RefScheduler
+
+    from lightx2v_amd import synth
+    from oracle import wan_oracle as O
+    from oracle.gen_golden import _ref_model_infer
+
+    dims = dict(synth.WAN_DIMS["wan-tiny"], num_layers=2)
+    ts = (16, 2, 8, 12)
+    wd = synth.synth_wan_weights(dims, seed=13)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    cfg = ref_import.make_config(dims, target_shape=ts, target_video_length=5, infer_steps=3,
+                                 mm_config={"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Vllm", "weight_auto_quant": True})
+    R = ref_import.build_reference_wan(cfg, wd)
+    sch = RefScheduler(cfg)
+    sch.device = torch.device("cpu")
+    sch.prepare()
+    sch.latents = lat.clone()
+    for m in ("pre", "post"):
+        R[m].set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": ctx, "context_null": ctx_null}}
+    for i in range(2):
+        sch.step_pre(i)
+        _ref_model_infer(R, sch, cfg, inputs)
+        with O.fp8_blocks():
+            mine = O.wan_model_infer(wd, dims, sch.latents, sch.timesteps[i], ctx, ctx_null, 6.0)
+        assert torch.equal(mine, sch.noise_pred), f"step {i}: max |d| = {(mine - sch.noise_pred).abs().max().item():.3e}"
+        assert not torch.equal(mine, O.wan_model_infer(wd, dims, sch.latents, sch.timesteps[i], ctx, ctx_null, 6.0)), "the w8a8 graph must differ from the bf16 one"
+        sch.step_post()
