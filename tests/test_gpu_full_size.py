@@ -416,3 +416,37 @@ def test_wan14b_fp8_block_vs_oracle_rows(tokens, ref_rounding):
     record(f"Wan-14B w8a8 block S={S} (ref_rounding={ref_rounding})", rows=len(rows), rel_l2_vs_fp8_oracle=e, fp8_oracle_vs_bf16_oracle=e_q)
     # the w8a8 graph sits e_q (quantisation error) away from the bf16 graph; the HIP block must match the w8a8 ORACLE much closer than that
     assert e <= 1.5e-2 and e <= 0.5 * e_q, f"w8a8 block at S={S}: relative L2 vs the w8a8 oracle {e:.3e} (quantisation error of the graph itself: {e_q:.3e})"
+
+
+# ------------------------------------------------------------------------------------------------ config #2: the whole 30-layer forward at S = 20 280
+def test_wan13b_config2_full_forward_vs_fp32_truth():
+    """BASELINE config #2 in full depth and length: the 30-layer Wan2.1-1.3B conditional forward at 480p x 49 frames (20 280 tokens), HIP path vs
+    the oracle's statements evaluated in fp32 through plain PyTorch on the GPU (`O.truth_precision(float32, device="cuda")`; the bf16 CPU
+    oracle would need ~8e13 FLOP of host attention).  The anchored test at 1 280 tokens measured the HIP forward AND the reference's bf16 CPU path
+    1.2e-2 from this fp32 graph (30 layers of bf16 rounding); the same bound, with head room, must hold at the real sequence length."""
+    from lightx2v_amd import scheduler, synth, wan
+    from oracle import wan_oracle as O
+
+    dims = synth.WAN_DIMS["wan2.1-1.3b"]
+    wl = synth.WORKLOADS["wan1.3b_480px49f"]
+    ts = wl["target_shape"]
+    assert synth.seq_len_of(ts) == 20280
+    wd = synth.synth_wan_weights(dims, seed=17)
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    t = torch.tensor(640)
+    with O.truth_precision(torch.float32, device="cuda"), torch.no_grad():
+        tru = O.wan_forward(O.upcast(wd, device="cuda"), dims, lat.to(torch.bfloat16).float().cuda(), t, O.upcast(ctx, device="cuda")).cpu()
+    torch.cuda.empty_cache()
+    cfg = wan.default_config(dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=4)
+    model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    sch.timesteps[1] = 640
+    model.set_scheduler(sch)
+    sch.step_pre(1)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    got = model._forward(inputs, True)
+    assert got.shape == tru.shape and torch.isfinite(got).all()
+    e = rel_l2(got, tru)
+    record("Wan-1.3B 30-layer forward at S=20280 (config #2) vs fp32 truth", err_hip_vs_fp32=e)
+    assert e <= 2e-2, f"config #2 forward: {e:.3e} from the fp32 graph (1.2e-2 at S = 1280 for the HIP path and for the reference's bf16 path alike)"
