@@ -450,3 +450,44 @@ def test_wan13b_config2_full_forward_vs_fp32_truth():
     e = rel_l2(got, tru)
     record("Wan-1.3B 30-layer forward at S=20280 (config #2) vs fp32 truth", err_hip_vs_fp32=e)
     assert e <= 2e-2, f"config #2 forward: {e:.3e} from the fp32 graph (1.2e-2 at S = 1280 for the HIP path and for the reference's bf16 path alike)"
+
+
+# ------------------------------------------------------------------------------------------------ configs #3 / #4: the whole benched forward
+def test_wan14b_720p_full_forward_vs_fp32_truth():
+    """THE forward the benchmark times — Wan2.1-14B, all 40 layers, 720p x 81 frames = 75 600 tokens (pre-infer, 40 fused blocks with the staggered
+    16x16x32 attention launch, post-infer) — against the oracle's statements evaluated in fp32 through plain PyTorch on the same GPU
+    (`O.truth_precision(float32, device="cuda")`; attention exactly, in query chunks: the full fp32 score tensor would be 914 GB).  ~2 min of fp32
+    GEMMs.  Bound: 2e-2 relative L2 on the noise prediction; the anchored tests show both the HIP path and the reference's bf16 CPU path 1.2e-2 from the
+    fp32 graph after 30 layers at 1 280 tokens (and the HIP path 1.28e-2 at 20 280), so 40 layers at 75 600 tokens have head room without hiding a
+    broken layer (one wrong block moves the result by O(1))."""
+    from lightx2v_amd import scheduler, synth, wan
+    from oracle import wan_oracle as O
+
+    dims = synth.WAN_DIMS["wan2.1-14b"]
+    wl = synth.WORKLOADS["wan14b_720px81f"]
+    ts = wl["target_shape"]
+    assert synth.seq_len_of(ts) == S_WAN
+    wd = synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda")  # what bench.py builds
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    t = torch.tensor(500)
+    cfg = wan.default_config(dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=4)
+    model = wan.WanModel(cfg, wd)
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    sch.timesteps[1] = 500
+    model.set_scheduler(sch)
+    sch.step_pre(1)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
+    got = model._forward(inputs, True).float().cpu()
+    assert torch.isfinite(got).all()
+    del model
+    torch.cuda.empty_cache()
+    with O.truth_precision(torch.float32, device="cuda"), torch.no_grad():
+        wd32 = {k: v.float() for k, v in wd.items()}
+        del wd
+        tru = O.wan_forward(wd32, dims, lat.to(torch.bfloat16).float().cuda(), t, O.upcast(ctx, device="cuda")).cpu()
+    del wd32
+    torch.cuda.empty_cache()
+    e = rel_l2(got, tru)
+    record("Wan-14B 40-layer forward at S=75600 (the benched forward) vs fp32 truth", err_hip_vs_fp32=e)
+    assert got.shape == tru.shape and e <= 2e-2, f"the benched forward is {e:.3e} from the fp32 graph"
