@@ -1,4 +1,4 @@
-"""world_size-2 worker: Ulysses-sharded Hunyuan forward (both ranks on cuda:0, gloo + host-staged collectives — see
+"""world_size-2 (or -8) worker: Ulysses-sharded Hunyuan forward (all ranks on cuda:0, gloo + host-staged collectives — see
 tests/_dist_gpu_worker.py) must match the single-GPU forward."""
 import os
 import sys
@@ -21,8 +21,12 @@ def main():
     from lightx2v_amd import hunyuan as hy, lib, synth, ulysses
 
     lib.init(0)
+    n = dist.get_world_size()
     dims = synth.HUNYUAN_DIMS["hunyuan-tiny"]
     ts = synth.HUNYUAN_WORKLOADS["hunyuan-tiny"]["target_shape"]
+    if n > 2:  # the node size on one GPU: one head per rank, a token grid whose h axis the group divides (16 rows of tokens)
+        dims = dict(dims, hidden=128 * n, heads=n, mlp=2048, refiner_mlp=2048)
+        ts = (1, 16, 3, 4 * n, 12)
     wd = {k: v.cuda() for k, v in synth.synth_hunyuan_weights(dims, seed=2).items()}
     lat, text_states, mask, ts2 = synth.synth_hunyuan_inputs(dims, ts, seed=5, valid_text=11)
     inputs = {"text_encoder_output": {"text_encoder_1_text_states": text_states.cuda(), "text_encoder_1_attention_mask": mask.cuda(), "text_encoder_2_text_states": ts2.cuda()}}

@@ -22,9 +22,10 @@ def test_ulysses_world2_on_one_gpu(world):
     assert "DIST_GPU_OK" in p.stdout
 
 
-def test_ulysses_hunyuan_world2_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ulysses_hunyuan_world2_on_one_gpu(world):
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29543 + 10 * (world > 2)),
            os.path.join(ROOT, "tests", "_dist_gpu_worker_hunyuan.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
