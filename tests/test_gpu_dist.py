@@ -83,3 +83,17 @@ def test_bench_n8_code_path_on_one_gpu():
     assert d["config"]["parallelism"] == "ulysses-sp8"
     r = d["roofline"]
     assert r["launches_timed"] == 2 * 2 * 2 * 2 and r["forwards_per_launch"] == 0.5, r  # 2 steps x 2 layers x 2 CFG branches x 2 head->seq pieces
+
+
+def test_e2e_n8_code_path_on_one_gpu():
+    """`python tools/e2e.py --gpus 8` end to end in the one-GPU plumbing mode: the Ulysses denoise loop (CFG branches on two streams) followed by
+    the 8-way halo-split parallel VAE decode (`decode_dist`, vae.py:883-929) on a 2-layer, 8-head model — the N-rank code of the end-to-end driver."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", X2V_ONE_GPU_TEST="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e.py"), "--gpus", "8", "--workload", "wan-tiny-h8", "--steps", "3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["parallelism"] == "ulysses-sp8 + decode_dist" and d["steps"] == 3 and d["video_shape"] == [1, 3, 9, 128, 96], d

@@ -38,7 +38,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if launch.one_gpu_test():  # plumbing mode (lightx2v_amd/launch.py): all ranks on one GPU over gloo with host-staged collectives, timings meaningless
+            dist.init_process_group("gloo")
+            launch.host_staged_collectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib.init(local_rank)
     wl = synth.WORKLOADS[a.workload]
     dims = synth.WAN_DIMS[wl["model"]]

@@ -39,7 +39,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if launch.one_gpu_test():  # plumbing mode (lightx2v_amd/launch.py): all ranks on one GPU over gloo with host-staged collectives, timings meaningless
+            dist.init_process_group("gloo")
+            launch.host_staged_collectives(dist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib.init(local_rank)
     wl = synth.HUNYUAN_WORKLOADS[a.workload]
     dims = synth.HUNYUAN_DIMS[wl["model"]]
@@ -79,7 +83,7 @@ def main():
     fence()
     dt = (time.perf_counter() - t0) / a.steps
     if dist is not None:  # slowest rank
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     assert torch.isfinite(sch.latents).all()
