@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-config1", action="store_true", help="skip the end-to-end CPU run of BASELINE config #1 beside the baseline (~80 s on 128 threads)")
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
     ap.add_argument("--no-cfg-pair", action="store_true", help="run the conditional and unconditional forwards of a step separately (default: by size)")
+    ap.add_argument("--cfg-streams", action="store_true", help="one GPU, CFG: force the two forwards block by block on two compute streams (wan.CfgBranchStreams; the default where the pair pass is off)")
+    ap.add_argument("--no-cfg-streams", action="store_true", help="never put the two CFG forwards on two compute streams")
     ap.add_argument("--cfg-pair", action="store_true", help="force the one-pass form of the two CFG forwards (default: by size — on for 14B 720p, off for 1.3B 480p)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
@@ -253,9 +255,11 @@ def main():
         extra["mm_config"] = {"mm_type": "W-mxfp8-A-mxfp8-dynamic-Hip", "weight_auto_quant": True}
     if args.distill:
         extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
+    if args.no_cfg_streams:
+        extra["cfg_branch_streams"] = False
     cfg = wan.default_config(
         dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
-        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=(False if args.no_cfg_pair else True if args.cfg_pair else "auto"), **extra,
+        parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=(False if (args.no_cfg_pair or args.cfg_streams) else True if args.cfg_pair else "auto"), **extra,
     )
     if world > 1 and dims["num_heads"] % world != 0:
         raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
@@ -342,6 +346,10 @@ def main():
     model_label = {"wan2.1-14b": "Wan2.1-14B", "wan2.1-1.3b": "Wan2.1-1.3B"}.get(wl["model"], wl["model"])
     res_label = {"wan14b_720px81f": "720p 81f", "wan1.3b_480px49f": "480p 49f", "wan1.3b_256x256x17f": "256x256 17f"}.get(args.workload, args.workload)
     fast_attn = not args.ref_rounding
+    il = getattr(model, "_cfg_interleave", None)
+    cfg_form = ("no CFG" if fwd == 1 else "pair pass: both forwards as one launch sequence over stacked rows" if model._pair_ok(inputs)
+                else "two compute streams, block by block (kernel durations are measured while the other branch's kernels share the chip)" if il is not None and il._streams is not None
+                else "one forward after the other")
     out = {
         "metric": f"denoise-step latency (ms) + video frames/sec, {model_label} {res_label} @{world}/8 GPU",
         "value": fps,
@@ -365,6 +373,7 @@ def main():
             "frames": wl["frames"],
             "infer_steps": args.infer_steps,
             "cfg_forwards_per_step": fwd,
+            "cfg_form": cfg_form,
             "parallelism": f"ulysses-sp{world}" if world > 1 else "single",
             "schedule": "step-distill 4 steps (no CFG)" if args.distill else "UniPC",
             "fps_definition": "frames / (infer_steps * ms_per_step), denoise loop only (no text encoder / VAE)",

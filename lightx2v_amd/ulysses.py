@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import lib
+from .wan import CfgBranchStreams as _WanCfgBranchStreams
 
 
 def _world(group=None):
@@ -294,8 +295,9 @@ def parallelize_wan(wan_model, group=None, attn_fn=None):
     return wan_model
 
 
-class CfgBranchStreams:
-    """The conditional and unconditional forwards of a CFG step under Ulysses, interleaved block by block on two compute streams.
+class CfgBranchStreams(_WanCfgBranchStreams):
+    """The conditional and unconditional forwards of a CFG step under Ulysses, interleaved block by block on two compute streams
+    (the stream / join mechanics are wan.CfgBranchStreams; this class adds the sharding and the per-branch exchange state).
 
     Sequentially (the reference: wan/model.py:197-226 runs one forward after the other, each block waiting for its all-to-alls with
     torch.cuda.synchronize(), ulysses/attn.py:48,85) every exchange a block cannot hide behind its own kernels is dead time on the GPU: the q / k
@@ -308,68 +310,36 @@ class CfgBranchStreams:
     results are bit-identical (tests/_dist_gpu_worker.py)."""
 
     def __init__(self, wan_model, group=None, attn_fn=None):
-        self.model, self.group, self.attn_fn = wan_model, group, attn_fn
-        self.enabled = True
-        self._pa_b = None
-        self._streams = None
+        super().__init__(wan_model)
+        self.group, self.attn_fn = group, attn_fn
+        self._pa_a = self._pa_b = None
 
-    def usable(self, inputs):
-        m = self.model
-        tr = m.transformer_infer
-        return (self.enabled and m.config["enable_cfg"] and m.scheduler.latents.is_cuda and type(tr).__name__ == "WanTransformerInfer"
-                and hasattr(tr.parallel_attention, "attend_blocked"))
+    def _attention_ok(self, tr):
+        return hasattr(tr.parallel_attention, "attend_blocked")
 
     def _setup(self):
         if self._streams is None:
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
             pa_a = self.model.transformer_infer.parallel_attention
             # branch B: its own exchange buffers, but the SAME process group and the SAME communication stream as branch A — RCCL sees one
             # communicator fed from one stream in host order, exactly as in the sequential form (two communicators running concurrently on
             # one GPU would be a new way to deadlock that nothing here could test)
             self._pa_b = UlyssesAttention(self.group, self.attn_fn)
             self._pa_b.comm_stream = pa_a._comm()
-            self._pa_b.split_head2seq = pa_a.split_head2seq
-        return self._streams
+        self._pa_a = self.model.transformer_infer.parallel_attention
+        self._pa_b.split_head2seq = self._pa_a.split_head2seq
+        return super()._setup()
 
-    def forward_pair(self, inputs):
-        """Returns (cond, uncond) noise predictions, each a list-less fp32 tensor as WanModel._forward returns."""
-        m = self.model
-        tr = m.transformer_infer
-        sa, sb = self._setup()
-        pa_a, pa_b = tr.parallel_attention, self._pa_b
-        pa_b.split_head2seq = pa_a.split_head2seq
-        cur = torch.cuda.current_stream()
-        embed, grid_sizes, (x, embed0, seq_lens, freqs, ctx_c) = m.pre_infer.infer(m.pre_weight, inputs, positive=True)
-        ctx_u = m.pre_infer._text_context(m.pre_weight, inputs["text_encoder_output"]["context_null"])
-        xa = pre_process(x, self.group)
-        xb = xa.clone()
-        sa.wait_stream(cur)
-        sb.wait_stream(cur)
-        blocks = m.transformer_weights.blocks
-        try:
-            for i in range(tr.blocks_num):
-                with torch.cuda.stream(sa):
-                    tr.parallel_attention = pa_a
-                    xa = tr.infer_block(blocks[i], grid_sizes, embed, xa, embed0, seq_lens, freqs, ctx_c)
-                with torch.cuda.stream(sb):
-                    tr.parallel_attention = pa_b
-                    xb = tr.infer_block(blocks[i], grid_sizes, embed, xb, embed0, seq_lens, freqs, ctx_u)
-        finally:
-            tr.parallel_attention = pa_a
-        outs = []
-        for st, xs in ((sa, xa), (sb, xb)):
-            with torch.cuda.stream(st):
-                full = post_process(xs, self.group)
-                outs.append(m.post_infer.infer(m.post_weight, full, embed, grid_sizes)[0])
-        cur.wait_stream(sa)
-        cur.wait_stream(sb)
-        # allocator bookkeeping: xa / xb were allocated under `cur` and used under a branch stream, the outputs the other way round (the joins
-        # above already order every later use behind both branches)
-        xa.record_stream(sa)
-        xb.record_stream(sb)
-        for t in outs:
-            t.record_stream(cur)
-        return outs[0], outs[1]
+    def _shard(self, x):
+        return pre_process(x, self.group)
+
+    def _gather(self, x):
+        return post_process(x, self.group)
+
+    def _enter_branch(self, tr, b):
+        tr.parallel_attention = self._pa_b if b else self._pa_a
+
+    def _leave(self, tr):
+        tr.parallel_attention = self._pa_a
 
 
 # ------------------------------------------------------------------------------------------------ HunyuanVideo

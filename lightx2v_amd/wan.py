@@ -514,6 +514,87 @@ class WanPostInfer:
 
 
 # ------------------------------------------------------------------------------------------------ model
+class CfgBranchStreams:
+    """The conditional and unconditional forwards of a CFG step (wan/model.py:197-226) enqueued block by block on two compute streams.
+
+    The two forwards share latents, timestep and weights and are independent until the CFG combine.  Run one after the other, every launch
+    that does not divide into whole rounds of the 256 CUs leaves its last round part empty (Wan-1.3B 480p: a self-attention is 960 workgroups
+    for 512 slots, a D x D projection 480 tiles for 256 CUs) and nothing can use the idle CUs; with the two branches on two streams the
+    hardware fills one branch's tail with the other's next kernel.  Every kernel sees the same operands as in the sequential order, so
+    the result is bit-identical (tests/test_gpu_model.py).  Large shapes take the pair pass instead (WanModel._pair_ok): there a launch is
+    tens of rounds and one stacked launch is the better form.  lightx2v_amd.ulysses derives the sequence-parallel form (whose gain is the
+    exchange of one branch under the kernels of the other)."""
+
+    def __init__(self, wan_model):
+        self.model = wan_model
+        self.enabled = True
+        self._streams = None
+
+    def _attention_ok(self, tr):
+        return tr.parallel_attention is None
+
+    def usable(self, inputs):
+        m = self.model
+        tr = m.transformer_infer
+        return self.enabled and m.config["enable_cfg"] and m.scheduler.latents.is_cuda and type(tr) is WanTransformerInfer and self._attention_ok(tr)
+
+    def _setup(self):
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        return self._streams
+
+    # hooks of the sequence-parallel form
+    def _shard(self, x):
+        return x
+
+    def _gather(self, x):
+        return x
+
+    def _enter_branch(self, tr, b):
+        pass
+
+    def _leave(self, tr):
+        pass
+
+    def forward_pair(self, inputs):
+        """Returns (cond, uncond) noise predictions, each a list-less fp32 tensor as WanModel._forward returns."""
+        m = self.model
+        tr = m.transformer_infer
+        sa, sb = self._setup()
+        cur = torch.cuda.current_stream()
+        embed, grid_sizes, (x, embed0, seq_lens, freqs, ctx_c) = m.pre_infer.infer(m.pre_weight, inputs, positive=True)
+        ctx_u = m.pre_infer._text_context(m.pre_weight, inputs["text_encoder_output"]["context_null"])
+        xa = self._shard(x)
+        xb = xa.clone()
+        sa.wait_stream(cur)
+        sb.wait_stream(cur)
+        blocks = m.transformer_weights.blocks
+        try:
+            for i in range(tr.blocks_num):
+                for b, (st, ctx) in enumerate(((sa, ctx_c), (sb, ctx_u))):
+                    with torch.cuda.stream(st):
+                        self._enter_branch(tr, b)
+                        if b == 0:
+                            xa = tr.infer_block(blocks[i], grid_sizes, embed, xa, embed0, seq_lens, freqs, ctx)
+                        else:
+                            xb = tr.infer_block(blocks[i], grid_sizes, embed, xb, embed0, seq_lens, freqs, ctx)
+        finally:
+            self._leave(tr)
+        outs = []
+        for st, xs in ((sa, xa), (sb, xb)):
+            with torch.cuda.stream(st):
+                outs.append(m.post_infer.infer(m.post_weight, self._gather(xs), embed, grid_sizes)[0])
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
+        # allocator bookkeeping: xa / xb were allocated under `cur` and used under a branch stream, the outputs the other way round (the joins
+        # above already order every later use behind both branches)
+        xa.record_stream(sa)
+        xb.record_stream(sb)
+        for t in outs:
+            t.record_stream(cur)
+        return outs[0], outs[1]
+
+
 class WanModel:
     """reference: wan/model.py:28-226.  Built from an in-memory checkpoint dict (the reference's
     `_init_weights(weight_dict)` path, :146-170); tensors must already be on the target device."""
@@ -623,9 +704,17 @@ class WanModel:
     def infer(self, inputs):
         """cond forward, uncond forward, fp32 CFG combine (model.py:197-226)."""
         pair = self._forward_pair(inputs) if (self.config["enable_cfg"] and self._pair_ok(inputs)) else None
-        il = getattr(self, "_cfg_interleave", None)
-        if pair is None and il is not None and _cfg(self.config, "cfg_branch_streams", True) and il.usable(inputs):
-            pair = il.forward_pair(inputs)  # Ulysses: the two CFG branches block by block on two compute streams (ulysses.CfgBranchStreams)
+        if pair is None and self.config["enable_cfg"]:
+            # the two CFG branches block by block on two compute streams (config `cfg_branch_streams`, default on): under Ulysses
+            # ulysses.CfgBranchStreams (set by parallelize_wan), on one GPU CfgBranchStreams above — measured on MI355X: Wan-1.3B 480p
+            # 214.4 -> 206.1 ms/step (-3.9 %, profiles/r03_cfg_two_streams_ab.txt); the shapes where it would lose (Wan-14B 720p: +3.5 % against
+            # the pair pass) have taken the pair pass above
+            il = getattr(self, "_cfg_interleave", None)
+            want = _cfg(self.config, "cfg_branch_streams", True) and self.scheduler.latents.is_cuda
+            if want and il is None:
+                il = self._cfg_interleave = CfgBranchStreams(self)
+            if want and il.usable(inputs):
+                pair = il.forward_pair(inputs)
         if pair is not None:
             cond, uncond = pair
         else:

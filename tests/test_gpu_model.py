@@ -352,13 +352,14 @@ def test_cfg_pair_pass_is_bit_identical_to_separate_forwards(fp8):
         lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
         inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
         outs = {}
-        for pair in (True, False):
-            cfg = wan.default_config(dims, target_shape=ts, target_video_length=frames, infer_steps=3, cfg_pair=pair, **extra)
+        # True / False: the pair pass forced on / off; "streams": the two forwards block by block on two compute streams (wan.CfgBranchStreams)
+        for pair in (True, False, "streams"):
+            cfg = wan.default_config(dims, target_shape=ts, target_video_length=frames, infer_steps=3, cfg_pair=pair is True, cfg_branch_streams=pair == "streams", **extra)
             model = wan.WanModel(cfg, wd)
             sch = scheduler.WanScheduler(cfg, device="cuda")
             sch.prepare(latents=lat)
             model.set_scheduler(sch)
-            assert model._pair_ok(inputs) == pair  # forced either way here; the default ("auto") decides by size
+            assert model._pair_ok(inputs) == (pair is True)  # forced either way here; the default ("auto") decides by size
             sch.step_pre(0)
             model.infer(inputs)
             pred = sch.noise_pred.float().clone()
@@ -371,3 +372,5 @@ def test_cfg_pair_pass_is_bit_identical_to_separate_forwards(fp8):
         assert torch.isfinite(outs[True][1]).all()
         assert torch.equal(outs[True][0], outs[False][0]), f"noise prediction differs: max |d| = {(outs[True][0] - outs[False][0]).abs().max().item():.3e}"
         assert torch.equal(outs[True][1], outs[False][1]), "latents after 3 steps differ"
+        assert torch.equal(outs["streams"][0], outs[False][0]) and torch.equal(outs["streams"][1], outs[False][1]), "two-stream CFG branches changed the result"
+        assert model._cfg_interleave._streams is not None, "the two-stream path was not taken"
