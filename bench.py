@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-config1", action="store_true", help="skip the end-to-end CPU run of BASELINE config #1 beside the baseline (~80 s on 128 threads)")
     ap.add_argument("--ref-rounding", action="store_true", help="norm kernels reproduce the reference's bf16 rounding chain")
     ap.add_argument("--no-cfg-pair", action="store_true", help="run the conditional and unconditional forwards of a step separately (default: by size)")
-    ap.add_argument("--cfg-streams", action="store_true", help="one GPU, CFG: force the two forwards block by block on two compute streams (wan.CfgBranchStreams; the default where the pair pass is off)")
+    ap.add_argument("--cfg-streams", action="store_true", help="one GPU, CFG: force the two forwards block by block on two compute streams (wan.CfgBranchStreams; default: by size — on for 1.3B 480p)")
     ap.add_argument("--no-cfg-streams", action="store_true", help="never put the two CFG forwards on two compute streams")
     ap.add_argument("--cfg-pair", action="store_true", help="force the one-pass form of the two CFG forwards (default: by size — on for 14B 720p, off for 1.3B 480p)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
@@ -255,8 +255,8 @@ def main():
         extra["mm_config"] = {"mm_type": "W-mxfp8-A-mxfp8-dynamic-Hip", "weight_auto_quant": True}
     if args.distill:
         extra.update(denoising_step_list=[1000, 750, 500, 250], sample_shift=5.0)
-    if args.no_cfg_streams:
-        extra["cfg_branch_streams"] = False
+    if args.no_cfg_streams or args.cfg_streams:
+        extra["cfg_branch_streams"] = bool(args.cfg_streams)
     cfg = wan.default_config(
         dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=args.infer_steps, enable_cfg=enable_cfg,
         parallel_attn_type="ulysses" if world > 1 else None, hip_ref_rounding=args.ref_rounding, cfg_pair=(False if (args.no_cfg_pair or args.cfg_streams) else True if args.cfg_pair else "auto"), **extra,
@@ -291,9 +291,34 @@ def main():
     sp_check = None
     if world > 1:
         sp_check = ulysses_self_check(dist, world, rank)
-        model.config["cfg_branch_streams"] = sp_check["settings"]["cfg_branch_streams"]
+        model.config["cfg_branch_streams"] = sp_check["settings"]["cfg_branch_streams"] and not args.no_cfg_streams
         model.transformer_infer.blocked_exchange = sp_check["settings"]["blocked_exchange"]
         model.transformer_infer.parallel_attention.split_head2seq = sp_check["settings"]["split_head2seq"]
+    cfg_form_timing = None
+    if world > 1 and enable_cfg and sp_check["settings"]["cfg_branch_streams"] and not args.no_cfg_streams and not args.cfg_streams:
+        # N > 1, untimed: the two CFG forms by the clock, one step each after one step of first use (buffers, allocator pools).  On one GPU the
+        # two-stream form costs 3.5 % at 14B sizes (two big attention launches evict each other's K / V) and what it gains under Ulysses — one
+        # branch's kernels under the other's exchanges — has never been measured on a node, so the bench does not guess: every rank times both,
+        # the MAX over ranks decides, the same on every rank.  (`--cfg-streams` / `--no-cfg-streams` pin the form.)
+        cfg_form_timing = {}
+        def restart():  # back to the initial noise and an empty multistep history (as tools/e2e.py does after its warm-up step)
+            sch.reset()
+            sch.prepare(latents=lat)
+
+        for form, flag in (("two_streams_ms", True), ("sequential_ms", False)):
+            model.config["cfg_branch_streams"] = flag
+            restart()
+            one_step(0)
+            fence()
+            tf = time.perf_counter()
+            one_step(1)
+            fence()
+            dt = torch.tensor([time.perf_counter() - tf], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            cfg_form_timing[form] = dt.item() * 1e3
+        model.config["cfg_branch_streams"] = cfg_form_timing["two_streams_ms"] <= cfg_form_timing["sequential_ms"]
+        cfg_form_timing["chosen"] = "two streams" if model.config["cfg_branch_streams"] else "sequential"
+        restart()
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -348,7 +373,7 @@ def main():
     fast_attn = not args.ref_rounding
     il = getattr(model, "_cfg_interleave", None)
     cfg_form = ("no CFG" if fwd == 1 else "pair pass: both forwards as one launch sequence over stacked rows" if model._pair_ok(inputs)
-                else "two compute streams, block by block (kernel durations are measured while the other branch's kernels share the chip)" if il is not None and il._streams is not None
+                else "two compute streams, block by block (kernel durations are measured while the other branch's kernels share the chip)" if il is not None and il._streams is not None and model.config.get("cfg_branch_streams", "auto") is not False
                 else "one forward after the other")
     out = {
         "metric": f"denoise-step latency (ms) + video frames/sec, {model_label} {res_label} @{world}/8 GPU",
@@ -374,6 +399,7 @@ def main():
             "infer_steps": args.infer_steps,
             "cfg_forwards_per_step": fwd,
             "cfg_form": cfg_form,
+            "cfg_form_timing": cfg_form_timing,
             "parallelism": f"ulysses-sp{world}" if world > 1 else "single",
             "schedule": "step-distill 4 steps (no CFG)" if args.distill else "UniPC",
             "fps_definition": "frames / (infer_steps * ms_per_step), denoise loop only (no text encoder / VAE)",

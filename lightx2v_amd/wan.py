@@ -705,12 +705,16 @@ class WanModel:
         """cond forward, uncond forward, fp32 CFG combine (model.py:197-226)."""
         pair = self._forward_pair(inputs) if (self.config["enable_cfg"] and self._pair_ok(inputs)) else None
         if pair is None and self.config["enable_cfg"]:
-            # the two CFG branches block by block on two compute streams (config `cfg_branch_streams`, default on): under Ulysses
-            # ulysses.CfgBranchStreams (set by parallelize_wan), on one GPU CfgBranchStreams above — measured on MI355X: Wan-1.3B 480p
-            # 214.4 -> 206.1 ms/step (-3.9 %, profiles/r03_cfg_two_streams_ab.txt); the shapes where it would lose (Wan-14B 720p: +3.5 % against
-            # the pair pass) have taken the pair pass above
+            # the two CFG branches block by block on two compute streams (config `cfg_branch_streams`: True / False / "auto", the default): under
+            # Ulysses ulysses.CfgBranchStreams (set by parallelize_wan; "auto" = on, the exchange overlap is its point), on one GPU CfgBranchStreams
+            # above, "auto" = by size.  Measured on MI355X (profiles/r03_cfg_two_streams_ab.txt), self-attention workgroups per forward -> effect on
+            # the step: 960 (Wan-1.3B 480p) -3.9 ... -7.8 %; 3552 (1.3B 720p) +0.8 %; 5120 (14B 480p) +3.7 %; 11 840 (14B 720p) +3.5 %: it pays
+            # where a launch is a few part-empty rounds of the chip and costs where two big launches evict each other's K / V
             il = getattr(self, "_cfg_interleave", None)
-            want = _cfg(self.config, "cfg_branch_streams", True) and self.scheduler.latents.is_cuda
+            want = _cfg(self.config, "cfg_branch_streams", "auto")
+            if want == "auto":
+                want = il is not None or ((self.scheduler.seq_len + 255) // 256) * self.transformer_infer.num_heads < 2048
+            want = bool(want) and self.scheduler.latents.is_cuda
             if want and il is None:
                 il = self._cfg_interleave = CfgBranchStreams(self)
             if want and il.usable(inputs):

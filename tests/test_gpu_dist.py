@@ -81,6 +81,9 @@ def test_bench_n8_code_path_on_one_gpu():
     assert sp["passed"] and sp["ranks"] == 8 and sp["worst_rel_l2"] < 5e-3, sp
     assert sp["settings"] == {"cfg_branch_streams": True, "blocked_exchange": True, "split_head2seq": True}, sp
     assert d["config"]["parallelism"] == "ulysses-sp8"
+    ft = d["config"]["cfg_form_timing"]  # N > 1: the two CFG forms are timed (untimed region) and the MAX over ranks picks one
+    assert ft["chosen"] in ("two streams", "sequential") and ft["two_streams_ms"] > 0 and ft["sequential_ms"] > 0, ft
+    assert d["config"]["cfg_form"].startswith("two compute streams" if ft["chosen"] == "two streams" else "one forward after the other"), d["config"]["cfg_form"]
     r = d["roofline"]
     assert r["launches_timed"] == 2 * 2 * 2 * 2 and r["forwards_per_launch"] == 0.5, r  # 2 steps x 2 layers x 2 CFG branches x 2 head->seq pieces
 
