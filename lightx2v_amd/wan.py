@@ -514,6 +514,20 @@ class WanPostInfer:
 
 
 # ------------------------------------------------------------------------------------------------ model
+def cfg_form_by_size(seq_len, num_heads):
+    """How one GPU runs the two forwards of a CFG step (wan/model.py:197-226 runs one after the other) when the config leaves it to the size
+    ("auto"): by the self-attention workgroups of ONE forward (256-row query blocks x heads; the chip holds 512 at a time).  Measured on MI355X,
+    step time against one forward after the other (profiles/r03_cfg_two_streams_ab.txt, r02_cfg_pair_ab.log):
+        960 (Wan-1.3B 480p)   two streams -3.9 ... -7.8 %   pair pass +1 %
+       3552 (Wan-1.3B 720p)   two streams +0.8 %            pair pass -0.1 %
+       5120 (Wan-14B 480p)    two streams +3.7 %            pair pass -0.2 %
+      11840 (Wan-14B 720p)    two streams +2.7 %            pair pass -0.8 %
+    'streams' (CfgBranchStreams) where a launch is a few part-empty rounds of the chip, 'pair' (WanModel._forward_pair) where one forward's
+    attention already fills it many times over, 'sequential' in between."""
+    workgroups = ((int(seq_len) + 255) // 256) * int(num_heads)
+    return "pair" if workgroups >= 4096 else "streams" if workgroups < 2048 else "sequential"
+
+
 class CfgBranchStreams:
     """The conditional and unconditional forwards of a CFG step (wan/model.py:197-226) enqueued block by block on two compute streams.
 
@@ -676,7 +690,7 @@ class WanModel:
         if want == "auto":
             # measured on MI355X: -0.8 % of a Wan-14B 720p step (11 840 attention workgroups per forward), +1 % of a Wan-1.3B 480p step (960):
             # pair only when one forward's self-attention already fills the chip many times over (lib.attention_batched's rule)
-            want = ((self.scheduler.seq_len + 255) // 256) * tr.num_heads >= 4096
+            want = cfg_form_by_size(self.scheduler.seq_len, tr.num_heads) == "pair"
         return (bool(want) and type(tr) is WanTransformerInfer and tr.parallel_attention is None and tr.round_mode == lib.ROUND_FP32
                 and tr.attention_type == "hip_flash" and self.scheduler.latents.is_cuda)
 
@@ -713,7 +727,7 @@ class WanModel:
             il = getattr(self, "_cfg_interleave", None)
             want = _cfg(self.config, "cfg_branch_streams", "auto")
             if want == "auto":
-                want = il is not None or ((self.scheduler.seq_len + 255) // 256) * self.transformer_infer.num_heads < 2048
+                want = il is not None or cfg_form_by_size(self.scheduler.seq_len, self.transformer_infer.num_heads) == "streams"
             want = bool(want) and self.scheduler.latents.is_cuda
             if want and il is None:
                 il = self._cfg_interleave = CfgBranchStreams(self)

@@ -141,3 +141,22 @@ def test_vae_chunk_bounds_cover_every_latent_frame_once():
             assert all(a < b for a, b in ch) and all(ch[i][1] == ch[i + 1][0] for i in range(len(ch) - 1))
             assert all(b - a <= g for a, b in ch[1:])
     assert chunk_bounds(21, 4) == [(0, 1), (1, 5), (5, 9), (9, 13), (13, 17), (17, 21)]
+
+
+def test_cfg_form_by_size_rule():
+    """The by-size choice of how one GPU runs the two CFG forwards (wan.cfg_form_by_size), at the four measured shapes and the thresholds."""
+    from lightx2v_amd import synth
+    from lightx2v_amd.wan import cfg_form_by_size
+
+    def form(workload):
+        wl = synth.WORKLOADS[workload]
+        return cfg_form_by_size(synth.seq_len_of(wl["target_shape"]), synth.WAN_DIMS[wl["model"]]["num_heads"])
+
+    assert form("wan1.3b_480px49f") == "streams"      # 80 query blocks x 12 heads = 960 workgroups
+    assert form("wan1.3b_720px81f") == "sequential"   # 296 x 12 = 3552
+    assert form("wan14b_480px81f") == "pair"          # 128 x 40 = 5120
+    assert form("wan14b_720px81f") == "pair"          # 296 x 40 = 11 840
+    assert form("wan1.3b_256x256x17f") == "streams"
+    assert cfg_form_by_size(256 * 170, 12) == "streams" and cfg_form_by_size(256 * 171, 12) == "sequential"  # 2040 / 2052 workgroups
+    assert cfg_form_by_size(256 * 341, 12) == "sequential" and cfg_form_by_size(256 * 342, 12) == "pair"     # 4092 / 4104
+    assert cfg_form_by_size(256 * 341 + 1, 12) == "pair"  # a ragged last block counts
