@@ -165,7 +165,7 @@ def ulysses_self_check(dist, world, rank):
     path: RCCL all-to-alls on the blocked exchange buffers) and unsharded on every rank; the two noise predictions must agree to 5e-3
     relative L2 on every rank (same kernels on re-partitioned rows).  The result travels in the JSON line so that a scaling record
     proves N ranks really exchanged data."""
-    from lightx2v_amd import scheduler, synth, ulysses, wan
+    from lightx2v_amd import scheduler, synth, wan
 
     dims = dict(synth.WAN_DIMS["wan-tiny"], dim=256 * world, num_heads=2 * world, ffn_dim=1024, num_layers=2)
     ts = (16, 3, 8 * world, 12)  # tokens divisible by N

@@ -14,7 +14,6 @@ Prints one JSON line: ms per step and per-op-class times; compare with `python b
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
