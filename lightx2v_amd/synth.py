@@ -27,6 +27,7 @@ WORKLOADS = {
     # two sizes between the BASELINE configs, used to calibrate the by-size rules (CFG pair pass / two-stream form): 32 760 and 75 600 tokens
     "wan14b_480px81f": dict(model="wan2.1-14b", target_shape=(16, 21, 60, 104), frames=81),
     "wan1.3b_720px81f": dict(model="wan2.1-1.3b", target_shape=(16, 21, 90, 160), frames=81),
+    "wan1.3b_480px81f": dict(model="wan2.1-1.3b", target_shape=(16, 21, 60, 104), frames=81),  # 32 760 tokens x 12 heads: 1536 attention workgroups
     "wan-tiny": dict(model="wan-tiny", target_shape=(16, 3, 8, 8), frames=9),
     "wan-tiny-h8": dict(model="wan-tiny-h8", target_shape=(16, 3, 16, 12), frames=9),  # 144 tokens: divisible by 8
 }

@@ -519,6 +519,7 @@ def cfg_form_by_size(seq_len, num_heads):
     ("auto"): by the self-attention workgroups of ONE forward (256-row query blocks x heads; the chip holds 512 at a time).  Measured on MI355X,
     step time against one forward after the other (profiles/r03_cfg_two_streams_ab.txt, r02_cfg_pair_ab.log):
         960 (Wan-1.3B 480p)   two streams -3.9 ... -7.8 %   pair pass +1 %
+       1536 (Wan-1.3B 480p x 81f) two streams -1.0 %        pair pass -0.8 %
        3552 (Wan-1.3B 720p)   two streams +0.8 %            pair pass -0.1 %
        5120 (Wan-14B 480p)    two streams +3.7 %            pair pass -0.2 %
       11840 (Wan-14B 720p)    two streams +2.7 %            pair pass -0.8 %

@@ -144,7 +144,7 @@ def test_vae_chunk_bounds_cover_every_latent_frame_once():
 
 
 def test_cfg_form_by_size_rule():
-    """The by-size choice of how one GPU runs the two CFG forwards (wan.cfg_form_by_size), at the four measured shapes and the thresholds."""
+    """The by-size choice of how one GPU runs the two CFG forwards (wan.cfg_form_by_size), at the measured shapes and the thresholds."""
     from lightx2v_amd import synth
     from lightx2v_amd.wan import cfg_form_by_size
 
@@ -153,6 +153,7 @@ def test_cfg_form_by_size_rule():
         return cfg_form_by_size(synth.seq_len_of(wl["target_shape"]), synth.WAN_DIMS[wl["model"]]["num_heads"])
 
     assert form("wan1.3b_480px49f") == "streams"      # 80 query blocks x 12 heads = 960 workgroups
+    assert form("wan1.3b_480px81f") == "streams"      # 128 x 12 = 1536
     assert form("wan1.3b_720px81f") == "sequential"   # 296 x 12 = 3552
     assert form("wan14b_480px81f") == "pair"          # 128 x 40 = 5120
     assert form("wan14b_720px81f") == "pair"          # 296 x 40 = 11 840
