@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cfg-pair", action="store_true", help="force the one-pass form of the two CFG forwards (default: by size — on for 14B 720p, off for 1.3B 480p)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the in-process MFMA probe before / after the timed region and the power / clock samples")
+    ap.add_argument("--probe-ms", type=int, default=1500, help="duration of each box-calibration probe (lib.mfma_probe)")
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule of config #4 (no CFG, denoising_step_list 1000/750/500/250, shift 5)")
     return ap.parse_args()
 
@@ -92,6 +94,62 @@ class AttnTimer:
 
     def count(self, kind):
         return len(self.pairs[kind])
+
+
+class SmiSampler:
+    """Board power / engine clock / temperature of this rank's GPU during the timed region, read by `rocm-smi --json` from a host thread every
+    `period` seconds (rank 0, N = 1 only).  Context for a reader comparing two boxes: the matrix kernels run at the 1400 W board limit, and what
+    differs between boxes is the clock they are granted there.  Never fails the bench: any error leaves `summary()` empty."""
+
+    def __init__(self, device_index, period=5.0):
+        import threading
+
+        self.dev, self.period, self.rows = device_index, period, []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        import subprocess
+
+        p = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showpower", "--showclocks", "--showtemp", "--json"], capture_output=True, text=True, timeout=10)
+        d = json.loads(p.stdout)
+        card = d.get(f"card{self.dev}") or next(iter(d.values()))
+        row = {}
+        for k, v in card.items():
+            kl = k.lower()
+            name = "power_w" if "power" in kl and "socket" in kl else "sclk_mhz" if kl.startswith("sclk") else "mclk_mhz" if kl.startswith("mclk") else "temp_c" if "temperature" in kl and ("hotspot" in kl or "junction" in kl) else None
+            if name is None or name in row:
+                continue
+            num = "".join(ch for ch in str(v).replace("Mhz", "").replace("MHz", "") if ch.isdigit() or ch == ".")
+            if num:
+                row[name] = float(num)
+        return row
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                row = self._read()
+                if row:
+                    self.rows.append(row)
+            except Exception:  # noqa: BLE001
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self):
+        out = {"samples": len(self.rows)}
+        for key in ("power_w", "sclk_mhz", "mclk_mhz", "temp_c"):
+            vals = [r[key] for r in self.rows if key in r]
+            if vals:
+                out[key] = {"mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
+        return out
 
 
 def cpu_baseline(dims, S_full, ts, text_len, frames, infer_steps, cfg_forwards, n_rows, with_config1=True):
@@ -321,14 +379,29 @@ def main():
         restart()
     for i in range(args.warmup):
         one_step(i)
+    # Box calibration, UNTIMED, in this process: what the bare bf16 MFMA instruction sustains on this board right before and right after the timed
+    # region (lib.mfma_probe -> x2v_mfma_probe_bf16).  Boxes of the pool differ by several percent under the 1400 W limit; with these
+    # two numbers in the line, `roofline.frac_of_probe` can be compared between runs where `roofline.frac` (against the nominal 2.5 PFLOP/s) cannot.
+    calib = None
+    if not args.no_calibration:
+        calib = {"kernel": "v_mfma_f32_16x16x32_bf16, operands in registers, 8 waves per CU on every CU (x2v_mfma_probe_bf16)", "probe_ms": args.probe_ms,
+                 "mfma_probe_tflops_before": lib.mfma_probe(args.probe_ms)}
     fence()
+    sampler = SmiSampler(local_rank) if (calib is not None and world == 1) else contextlib.nullcontext()
     timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    with sampler:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
     timer.enabled = False
+    if calib is not None:
+        calib["mfma_probe_tflops_after"] = lib.mfma_probe(args.probe_ms)
+        calib["mfma_probe_tflops"] = 0.5 * (calib["mfma_probe_tflops_before"] + calib["mfma_probe_tflops_after"])
+        calib["mfma_probe_frac_of_nominal_peak"] = calib["mfma_probe_tflops"] / BF16_MFMA_PEAK_TFLOPS
+        if world == 1:
+            calib["smi_during_timed_region"] = sampler.summary()
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -416,6 +489,7 @@ def main():
             "peak": BF16_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
+            "frac_of_probe": (achieved / calib["mfma_probe_tflops"]) if calib and calib.get("mfma_probe_tflops") else None,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": 4.0 * S * heads_local * 128 * 2 * forwards_per_launch,
             "forwards_per_launch": forwards_per_launch,
@@ -427,6 +501,7 @@ def main():
             "traffic_note": traffic_note,
         },
     }
+    out["box_calibration"] = calib
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

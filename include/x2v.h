@@ -192,6 +192,13 @@ int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt,
 int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                          int H, int head_dim, float scale, int flags, void* stream);
 
+/* Which launch form x2v_attn_fwd_bf16_vt / _batched takes for a shape (host-only, no GPU needed): bit 0 = the XCD-aware head-major work mapping
+ * (on while the K / V^T streams of the <= 8 heads in flight fit the Infinity Cache and the launch has >= 512 workgroups — e.g. the Ulysses
+ * rank's 5 heads x 75 600 keys; off for 40 heads at 720p), bit 8 = the staggered key walk (X2V_ATTN_VT_STAGGER and Sk >= 16 tiles).  Lets a parity
+ * test assert that the kernel branch it compared with the oracle is the one a model's shapes take — the launches replace
+ * attentions/distributed/ulysses/attn.py:68-80 (per rank) and transformer_infer.py:369-379 (single GPU).  Negative = X2V_E_SHAPE. */
+int x2v_attn_vt_launch_plan(int64_t Sq, int64_t Sk, int H, int B, int flags);
+
 /* x2v_attn_fwd_bf16_vt over B independent sequences in ONE launch: sequence b uses q / k / V^T / o at b * {q,k,vt,o}_bstride elements from the
  * base pointers (same Sq, Sk, H, strides).  The fused Wan driver runs the conditional and unconditional forwards of a CFG step
  * (models/networks/wan/model.py:197-226) as one pass over both token sets; this is their self-attention — 2 x 11 840 workgroups fill the 256 CUs'
@@ -370,6 +377,12 @@ int x2v_softmax_rows_causal_f32(float* s, int64_t ld, int64_t M, int N, float sc
  * (autoencoder_kl_causal_3d.py:347-364). */
 int x2v_blend_axis_f32(const float* a, float* b, int64_t outer, int na, int nb, int64_t inner, int64_t a_outer_stride, int64_t b_outer_stride, int extent,
                        void* stream);
+
+/* Box calibration (measurement plumbing; no reference counterpart): runs bare v_mfma_f32_16x16x32_bf16 loops (operands in registers,
+ * 8 waves per CU, every CU) for `milliseconds` on `stream` and returns in *tflops what the board sustained over the second half of that time.
+ * bench.py calls it before and after its timed region so that a roofline fraction measured on one box can be compared with another's
+ * (boxes of one pool differ by several percent under the 1400 W board limit).  Synchronises the stream. */
+int x2v_mfma_probe_bf16(int milliseconds, float* tflops, void* stream);
 
 #ifdef __cplusplus
 }

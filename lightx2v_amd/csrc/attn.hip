@@ -696,6 +696,20 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
   return X2V_OK;
 }
 
+// The launch form of the pre-transposed-V kernel for a shape: bit 0 = XCD-aware head-major work mapping, bit 8 = staggered key walk.
+// Host-only and deterministic in its arguments (plus the X2V_ATTN_MAP / X2V_ATTN_ROT overrides for A/B runs); exported as
+// x2v_attn_vt_launch_plan so that a parity test can assert WHICH kernel branch the shape it compared with the oracle took.
+static int attn_vt_plan(int64_t Sq, int64_t Sk, int H, int B, bool stagger, int q_rows_per_wg) {
+  static const int map_env = [] { const char* e = getenv("X2V_ATTN_MAP"); return e ? atoi(e) : -1; }();
+  static const int rot_env = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
+  const uint64_t nwg = (uint64_t)((Sq + q_rows_per_wg - 1) / q_rows_per_wg) * (uint64_t)H * (uint64_t)B;
+  const int64_t heads_in_flight = (int64_t)H * B < 8 ? (int64_t)H * B : 8;
+  const bool mall_resident = heads_in_flight * Sk * (2 * AT_D * 2) <= (224ll << 20);
+  const int map_mode = map_env >= 0 ? map_env : ((nwg >= 512 && mall_resident) ? 1 : 0);
+  const int rot_mode = rot_env >= 0 ? rot_env : ((stagger && Sk >= 16 * AT_KV) ? 1 : 0);
+  return (map_mode ? 1 : 0) | (rot_mode ? 0x100 : 0);
+}
+
 template <int NW, int THR, bool PRESCALED>
 static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                           int H, float scale, hipStream_t st, bool stagger, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0, 0}) {
@@ -711,14 +725,9 @@ static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk
   //   * the stagger of the walk (rot mode 1) is worth +1.3 % on the plain grid; it changes the summation order per query block, so it is
   //     opt-in per call (flag X2V_ATTN_VT_STAGGER) and the drivers that promise partition-independent bits (Ulysses) do not set it.
   // X2V_ATTN_MAP / X2V_ATTN_ROT force a mode (A/B runs).
-  static const int map_env = [] { const char* e = getenv("X2V_ATTN_MAP"); return e ? atoi(e) : -1; }();
-  static const int rot_env = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
-  const uint64_t nwg = (uint64_t)grid.x * grid.y * grid.z;
-  const int64_t heads_in_flight = (int64_t)H * B < 8 ? (int64_t)H * B : 8;
-  const bool mall_resident = heads_in_flight * Sk * (2 * AT_D * 2) <= (224ll << 20);
-  const int map_mode = map_env >= 0 ? map_env : ((nwg >= 512 && mall_resident) ? 1 : 0);
-  const int rot_mode = rot_env >= 0 ? rot_env : ((stagger && Sk >= 16 * AT_KV) ? 1 : 0);
-  bs.xcd_remap = (map_mode ? 1 : 0) | (rot_mode ? 0x100 : 0);
+  const int plan = attn_vt_plan(Sq, Sk, H, B, stagger, NW * 32);
+  const int rot_mode = plan & 0x100;
+  bs.xcd_remap = plan;
   auto kern = rot_mode ? attn_fwd_v9_kernel<NW, THR, PRESCALED, true> : attn_fwd_v9_kernel<NW, THR, PRESCALED, false>;
   int rc = ensure_dynamic_lds((const void*)kern, 4 * AT_K_BYTES, "attn attr");
   if (rc != X2V_OK) return rc;
@@ -737,6 +746,12 @@ extern "C" __attribute__((visibility("default"))) int x2v_transpose_heads_bf16(c
                      (unsigned short*)vt, ldvt, Sk);
   X2V_LAUNCH_CHECK("transpose_heads launch");
   return X2V_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_attn_vt_launch_plan(int64_t Sq, int64_t Sk, int H, int B, int flags) {
+  X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535 && B > 0 && B <= 65535 && (flags & ~3) == 0, X2V_E_SHAPE, "attn_vt_launch_plan: bad shape Sq=%lld Sk=%lld H=%d B=%d flags=%d",
+              (long long)Sq, (long long)Sk, H, B, flags);
+  return attn_vt_plan(Sq, Sk, H, B, (flags & 2) != 0, 8 * 32);
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo,

@@ -343,13 +343,33 @@ class HunyuanTransformerInferTeaCaching(HunyuanTransformerInfer):
             self.accumulated_rel_l1_distance = 0
         else:
             prev = self.previous_modulated_input
-            rel = ((modulated - prev).abs().mean() / prev.abs().mean()).cpu().item()
+            rel = self._sharded_rel_l1(modulated, prev)
+            if rel is None:
+                rel = ((modulated - prev).abs().mean() / prev.abs().mean()).cpu().item()
             self.accumulated_rel_l1_distance += np.poly1d(self.coefficients)(rel)
             should_calc = not (self.accumulated_rel_l1_distance < self.teacache_thresh)
             if should_calc:
                 self.accumulated_rel_l1_distance = 0
         self.previous_modulated_input = modulated
         return should_calc
+
+    def _sharded_rel_l1(self, modulated, prev):
+        """Under Ulysses every rank holds its own image shard, and a decision taken from the local shard can differ between ranks right at the
+        threshold — one rank would skip the block stack (no all-to-all) while the others wait in it: a hang (the reference, whose ranks decide
+        locally in feature_caching/transformer_infer.py:21-50, has the same hazard).  Here the numerator and denominator of the relative L1 change
+        are summed over the sequence-parallel group first, so all ranks see one number (shards are equal-sized: ratio of sums = ratio of means).
+        None when not sharded (the single-GPU arithmetic, pinned to the reference fixture, stays as it is)."""
+        import torch.distributed as dist
+
+        pa = self.parallel_attention
+        if pa is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(getattr(pa, "group", None)) < 2:
+            return None
+        group = getattr(pa, "group", None)
+        pair = torch.stack([(modulated - prev).abs().float().sum(), prev.abs().float().sum()]).double()
+        if dist.get_backend(group) != "nccl":
+            pair = pair.cpu()
+        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+        return (pair[0] / pair[1]).item()
 
     def infer(self, weights, img, txt, vec, cu_seqlens_qkv, max_seqlen_qkv, freqs_cis, token_replace_vec=None, frist_frame_token_num=None):
         index = self.scheduler.step_index

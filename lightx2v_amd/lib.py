@@ -48,6 +48,8 @@ PROTOTYPES = {
     "x2v_attn_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _c_void_p],
     "x2v_transpose_heads_bf16": [_c_void_p, _i64, _c_void_p, _i64, _i64, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_vt_batched": [_c_void_p, _i64, _i64, _c_void_p, _i64, _i64, _c_void_p, _i64, _i64, _c_void_p, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _c_void_p],
+    "x2v_attn_vt_launch_plan": [_i64, _i64, _i32, _i32, _i32],
+    "x2v_mfma_probe_bf16": [_i32, ctypes.POINTER(_f32), _c_void_p],
     "x2v_attn_fwd_bf16_vt": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_attn_fwd_bf16_variant": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _f32, _i32, _c_void_p],
     "x2v_quant_fp8_rowwise": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
@@ -405,6 +407,22 @@ def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False):
     if rc < 0:
         raise X2VError(f"gemm_kernel_choice: bad shape M={M} N={N} K={K}")
     return rc
+
+
+def attn_vt_launch_plan(Sq, Sk, num_heads, batch=1, stagger=False):
+    """(xcd_remap, staggered_walk) that x2v_attn_fwd_bf16_vt(_batched) takes for this shape (x2v_attn_vt_launch_plan; host-only)."""
+    rc = _lib.x2v_attn_vt_launch_plan(Sq, Sk, num_heads, batch, 2 if stagger else 0)
+    if rc < 0:
+        raise X2VError(f"attn_vt_launch_plan: bad shape Sq={Sq} Sk={Sk} H={num_heads} B={batch}")
+    return bool(rc & 1), bool(rc & 0x100)
+
+
+def mfma_probe(milliseconds=1500):
+    """TFLOP/s this board sustains on bare 16x16x32 bf16 MFMAs right now (x2v_mfma_probe_bf16): the box calibration bench.py prints."""
+    init()
+    out = _f32(0.0)
+    _check(_lib.x2v_mfma_probe_bf16(int(milliseconds), ctypes.byref(out), _stream()), "mfma_probe")
+    return float(out.value)
 
 
 def transpose_heads(v, num_heads):

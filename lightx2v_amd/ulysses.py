@@ -145,6 +145,22 @@ class UlyssesAttention:
             self.comm_stream = torch.cuda.Stream()
         return self.comm_stream
 
+    def on_comm(self, fn, src):
+        """Run the collective `fn()` (which reads `src` and returns a fresh tensor) on the communication stream, ordered behind what the current
+        stream has enqueued, and join the current stream behind it.  EVERY collective of this driver goes through the one communication stream
+        (ADVICE r3): with synchronous collectives running on the calling stream, a gather issued from a compute stream would put kernels of the
+        same RCCL communicator on several streams at once and leave their order to RCCL's internals."""
+        if not (self.overlap and src.is_cuda):
+            return fn()
+        cur, cs = torch.cuda.current_stream(), self._comm()
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            out = fn()
+        cur.wait_stream(cs)
+        src.record_stream(cs)   # produced under the compute stream, read by the collective
+        out.record_stream(cur)  # allocated under the communication stream, read by the compute stream
+        return out
+
     def begin_exchange_blocked(self, send, recv):
         """seq->head of one blocked send buffer [N, S/N, hd/N] into `recv` (same shape; viewed as row-major [S, hd/N] by the attention),
         on the communication stream when overlapping, stream-ordered after what the compute stream has enqueued so far."""
@@ -277,8 +293,9 @@ def post_process(x, group=None):
 
 def parallelize_wan(wan_model, group=None, attn_fn=None):
     """reference: ulysses/wrap.py:53-71 — swap the attention, shard x around the block stack.  Beyond the reference: with CFG the two
-    forwards of a step are driven block by block on two compute streams (`cfg_branch_streams`) so that one branch's kernels run
-    while the other waits for an exchange."""
+    forwards of a step CAN be driven block by block on two compute streams (config `cfg_branch_streams=True`) so that one branch's
+    kernels run while the other waits for an exchange.  That form has only ever run on one GPU (gloo plumbing) — it is off by default ("auto" =
+    one forward after the other under Ulysses) until a multi-GPU run has shown it safe and faster; bench.py times both forms at N > 1."""
     tr = wan_model.transformer_infer
     n, r = _world(group)
     tr.parallel_attention = UlyssesAttention(group, attn_fn)
@@ -288,7 +305,7 @@ def parallelize_wan(wan_model, group=None, attn_fn=None):
     def new_infer(weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context, audio_dit_blocks=None):
         x = pre_process(x, group)
         x = original_infer(weights, grid_sizes, embed, x, embed0, seq_lens, freqs, context)
-        return post_process(x, group)
+        return tr.parallel_attention.on_comm(lambda: post_process(x, group), x)
 
     tr.infer = new_infer
     wan_model._cfg_interleave = CfgBranchStreams(wan_model, group, attn_fn)
@@ -333,7 +350,8 @@ class CfgBranchStreams(_WanCfgBranchStreams):
         return pre_process(x, self.group)
 
     def _gather(self, x):
-        return post_process(x, self.group)
+        # called under a branch's compute stream: the gather itself runs on the shared communication stream (UlyssesAttention.on_comm)
+        return self._pa_a.on_comm(lambda: post_process(x, self.group), x)
 
     def _enter_branch(self, tr, b):
         tr.parallel_attention = self._pa_b if b else self._pa_a
@@ -406,6 +424,21 @@ class UlyssesHunyuanAttention:
             b = self._buffers[key] = dict(snd=e(3, n, n_img, hdn), joint=e(3, n * n_img + n_txt, hdn), o=e(n * n_img + n_txt, hdn),
                                           a_img=e(n + mlp // hdn, n_img, hdn), a_txt=e(n + mlp // hdn, n_txt, hdn))
         return b
+
+    def on_comm(self, fn, src):
+        """As UlyssesAttention.on_comm: every collective of the driver on the one communication stream."""
+        if not (self.overlap and src.is_cuda):
+            return fn()
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream()
+        cur, cs = torch.cuda.current_stream(), self.comm_stream
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            out = fn()
+        cur.wait_stream(cs)
+        src.record_stream(cs)
+        out.record_stream(cur)
+        return out
 
     def blocked_ok(self, hd, mlp):
         """K-blocked GEMM operands advance in whole 64-element K tiles."""
@@ -525,7 +558,8 @@ def parallelize_hunyuan(hunyuan_model, group=None, attn_fn=None):
         keep = (sch.latents, sch.freqs_cos, sch.freqs_sin)
         sch.latents, sch.freqs_cos, sch.freqs_sin, split_dim = hunyuan_pre_process(*keep, group=group)
         original_infer(inputs)
-        sch.noise_pred = hunyuan_post_process(sch.noise_pred, split_dim, group)
+        pa = hunyuan_model.transformer_infer.parallel_attention
+        sch.noise_pred = pa.on_comm(lambda: hunyuan_post_process(sch.noise_pred, split_dim, group), sch.noise_pred)
         sch.latents, sch.freqs_cos, sch.freqs_sin = keep
 
     hunyuan_model.infer = new_infer

@@ -519,10 +519,10 @@ def cfg_form_by_size(seq_len, num_heads):
     ("auto"): by the self-attention workgroups of ONE forward (256-row query blocks x heads; the chip holds 512 at a time).  Measured on MI355X,
     step time against one forward after the other (profiles/r03_cfg_two_streams_ab.txt, r02_cfg_pair_ab.log):
         960 (Wan-1.3B 480p)   two streams -3.9 ... -7.8 %   pair pass +1 %
-       1536 (Wan-1.3B 480p x 81f) two streams -1.0 %        pair pass -0.8 %
+       1536 (Wan-1.3B 480p x 81f) two streams -1.0 %        pair pass -0.8 %      (both inside the +-1 % run-to-run noise of one box)
        3552 (Wan-1.3B 720p)   two streams +0.8 %            pair pass -0.1 %
        5120 (Wan-14B 480p)    two streams +3.7 %            pair pass -0.2 %
-      11840 (Wan-14B 720p)    two streams +2.7 %            pair pass -0.8 %
+      11840 (Wan-14B 720p)    two streams +2.7 ... +3.5 %   pair pass -0.8 %
     'streams' (CfgBranchStreams) where a launch is a few part-empty rounds of the chip, 'pair' (WanModel._forward_pair) where one forward's
     attention already fills it many times over, 'sequential' in between."""
     workgroups = ((int(seq_len) + 255) // 256) * int(num_heads)
@@ -721,14 +721,14 @@ class WanModel:
         pair = self._forward_pair(inputs) if (self.config["enable_cfg"] and self._pair_ok(inputs)) else None
         if pair is None and self.config["enable_cfg"]:
             # the two CFG branches block by block on two compute streams (config `cfg_branch_streams`: True / False / "auto", the default): under
-            # Ulysses ulysses.CfgBranchStreams (set by parallelize_wan; "auto" = on, the exchange overlap is its point), on one GPU CfgBranchStreams
-            # above, "auto" = by size.  Measured on MI355X (profiles/r03_cfg_two_streams_ab.txt), self-attention workgroups per forward -> effect on
-            # the step: 960 (Wan-1.3B 480p) -3.9 ... -7.8 %; 3552 (1.3B 720p) +0.8 %; 5120 (14B 480p) +3.7 %; 11 840 (14B 720p) +3.5 %: it pays
-            # where a launch is a few part-empty rounds of the chip and costs where two big launches evict each other's K / V
+            # Ulysses ulysses.CfgBranchStreams (set by parallelize_wan; "auto" = off there), on one GPU CfgBranchStreams above, "auto" = by size —
+            # the measured table is in cfg_form_by_size's docstring (one place)
             il = getattr(self, "_cfg_interleave", None)
             want = _cfg(self.config, "cfg_branch_streams", "auto")
             if want == "auto":
-                want = il is not None or cfg_form_by_size(self.scheduler.seq_len, self.transformer_infer.num_heads) == "streams"
+                # under Ulysses (il installed by parallelize_wan): OFF until a multi-GPU run has shown the two-stream form safe and faster there
+                # (bench.py at N > 1 times both forms and sets the key explicitly); on one GPU: by size
+                want = il is None and cfg_form_by_size(self.scheduler.seq_len, self.transformer_infer.num_heads) == "streams"
             want = bool(want) and self.scheduler.latents.is_cuda
             if want and il is None:
                 il = self._cfg_interleave = CfgBranchStreams(self)

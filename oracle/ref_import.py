@@ -20,8 +20,13 @@ Shims applied (SURVEY.md §8c recipe):
 import os
 import sys
 
-REFERENCE_ROOT = os.environ.get("X2V_REFERENCE_ROOT", "/root/reference")
-_SHIMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_shims")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SHIMS = os.path.join(_HERE, "ref_shims")
+# Where the unmodified reference is: $X2V_REFERENCE_ROOT, else /root/reference (the authoring container), else the staged copy that
+# `__graft_entry__.build()` puts under oracle/_ref/reference/ (oracle/stage_reference.sh: git-ignored — never in history — but it travels to the
+# GPU box with the snapshot, so that the reference-through-the-plugin GPU tests run there instead of skipping).
+_STAGED = os.path.join(_HERE, "_ref", "reference")
+REFERENCE_ROOT = os.environ.get("X2V_REFERENCE_ROOT") or next((p for p in ("/root/reference", _STAGED) if os.path.isdir(os.path.join(p, "lightx2v"))), "/root/reference")
 
 _patched = False
 

@@ -105,3 +105,23 @@ def test_registry_protocol_matches_reference_keys():
     sd = mm.state_dict()
     assert set(sd) == {"a.weight", "a.bias"} and sd["a.weight"].shape == (8, 64)
     assert mm._calculate_size() == 8 * 64 * 2 + 16
+
+
+def test_attention_launch_plan_for_the_benchmark_shapes():
+    """x2v_attn_vt_launch_plan is host arithmetic: the launch forms the benchmark's shapes take are pinned here without a GPU.  40 heads at 720p
+    (single GPU, and the CFG pair launch): plain grid (+ stagger when asked); what an 8-GPU Ulysses rank launches (5 heads x 75 600 keys, either
+    head->seq piece of 37 800 query rows: 148 x 5 = 740 workgroups, 740 % 8 = 4) and HunyuanVideo's rank (3 heads x 119 000 keys): XCD-aware
+    mapping, no stagger; Wan-1.3B 480p: remap on; a launch below 512 workgroups: plain."""
+    from lightx2v_amd import lib
+
+    if os.environ.get("X2V_ATTN_MAP") or os.environ.get("X2V_ATTN_ROT"):
+        pytest.skip("A/B override set")
+    assert lib.attn_vt_launch_plan(75600, 75600, 40, stagger=True) == (False, True)
+    assert lib.attn_vt_launch_plan(75648, 75600, 40, batch=2, stagger=True) == (False, True)
+    assert lib.attn_vt_launch_plan(37800, 75600, 5) == (True, False)
+    assert lib.attn_vt_launch_plan(18900, 75600, 10) == (False, False)  # 4-GPU rank, one of two pieces: 8 heads in flight x 38.7 MB > the cache
+    assert lib.attn_vt_launch_plan(59528, 119000, 3) == (True, False)
+    assert lib.attn_vt_launch_plan(20280, 20280, 12, stagger=True) == (True, True)
+    assert lib.attn_vt_launch_plan(2560, 2560, 5) == (False, False)
+    with pytest.raises(lib.X2VError):
+        lib.attn_vt_launch_plan(0, 10, 1)

@@ -48,16 +48,16 @@ def sample_rows(S, n, block=256, seed=0, must=()):
 N_PLAIN = 8  # leading heads with unit score spread (well-conditioned: elementwise comparison with the reference operator)
 
 
-def _spread(H):
-    return torch.cat([torch.ones(min(N_PLAIN, H)), torch.linspace(1.0, 2.0, max(H - N_PLAIN, 0))]).cuda().repeat_interleave(128)
+def _spread(H, n_plain=N_PLAIN):
+    return torch.cat([torch.ones(min(n_plain, H)), torch.linspace(1.0, 2.0, max(H - n_plain, 0))]).cuda().repeat_interleave(128)
 
 
-def _attn_inputs(S_rows, S, H, seed, ld=None):
+def _attn_inputs(S_rows, S, H, seed, ld=None, n_plain=N_PLAIN):
     """q32 (fp32; score spread 1 on the first N_PLAIN heads, rising to 2 on the others so that diffuse and peaky softmax rows both occur), k, v
     bf16 on the GPU."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     D = H * 128
-    q32 = torch.randn(S_rows, D, generator=g, device="cuda") * _spread(H)
+    q32 = torch.randn(S_rows, D, generator=g, device="cuda") * _spread(H, n_plain)
     k = torch.randn(S_rows, D, generator=g, device="cuda").to(torch.bfloat16)
     v = torch.randn(S_rows, D, generator=g, device="cuda").to(torch.bfloat16)
     return q32, k, v
@@ -71,7 +71,7 @@ def _plant(q32, k, base, S, pairs):
         k[base + j, :128] = (q32[base + r, :128] * 3.0).to(torch.bfloat16)
 
 
-def _check_attention_rows(lib, got_rows, q32_rows, k_cpu, v_cpu, H, name, ulps=1.0, atol=1e-3):
+def _check_attention_rows(lib, got_rows, q32_rows, k_cpu, v_cpu, H, name, ulps=1.0, atol=1e-3, n_plain=N_PLAIN):
     from oracle import wan_oracle as O
 
     n = q32_rows.shape[0]
@@ -97,7 +97,7 @@ def _check_attention_rows(lib, got_rows, q32_rows, k_cpu, v_cpu, H, name, ulps=1
            per_head_first_last=[list(per_head[0]), list(per_head[-1])])
     for h, (eh, er) in enumerate(per_head):
         assert eh <= 1.5 * er + 1e-4, f"{name}: head {h}: err vs fp32 truth {eh:.3e} > 1.5 x the reference operator's {er:.3e}"
-    plain = min(N_PLAIN, H) * 128
+    plain = min(n_plain, H) * 128
     # one bf16 ulp of the output (two independently rounded results may sit on either side of a rounding boundary: 2^-8 .. 2^-7 relative) + atol
     assert_bf16_close(got[:, :plain], ref[:, :plain], ulps=ulps, atol=atol, bad_frac=1e-4, name=name + " (unit-spread heads)")
     return ref

@@ -1,5 +1,5 @@
-"""Drop-in check against the REAL reference (authoring container only: skipped where /root/reference is absent,
-e.g. on the GPU box): our keys register into LightX2V's own registries, and the reference's weight classes build and
+"""Drop-in check against the REAL reference (/root/reference in the authoring container; on the GPU box the copy `__graft_entry__.build()` staged
+under the git-ignored oracle/_ref/reference/, see oracle/ref_import.py — skipped only where neither exists): our keys register into LightX2V's own registries, and the reference's weight classes build and
 load their trees with our operator objects selected purely by config strings."""
 import pytest
 import torch
