@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--cfg-pair", action="store_true", help="force the one-pass form of the two CFG forwards (default: by size — on for 14B 720p, off for 1.3B 480p)")
     ap.add_argument("--mxfp8", action="store_true", help="MXFP8 GEMMs (e4m3 + e8m0 per 32 K, weights and activations; gfx950 block-scaled MFMA), bf16 attention")
     ap.add_argument("--fp8", action="store_true", help="w8a8 e4m3 GEMMs (BASELINE config #4): weights auto-quantised per channel at load, per-token dynamic activations")
+    ap.add_argument("--hang-timeout", type=int, default=0, help="N > 1: seconds without progress after which the watchdog dumps the stage it is stuck in and exits 124 (0 = 240 for N > 1, off for N = 1)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the in-process MFMA probe before / after the timed region and the power / clock samples")
     ap.add_argument("--probe-ms", type=int, default=1500, help="duration of each box-calibration probe (lib.mfma_probe)")
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule of config #4 (no CFG, denoising_step_list 1000/750/500/250, shift 5)")
@@ -94,6 +95,34 @@ class AttnTimer:
 
     def count(self, kind):
         return len(self.pairs[kind])
+
+
+class Watchdog:
+    """First-contact insurance for the multi-GPU run: a collective that RCCL rejects or that hangs must cost minutes, not the
+    driver's whole 1800 s.  `tick(stage)` marks progress; a daemon thread exits the process with code 124 — after printing the stage, the rank and
+    every Python thread's stack to stderr — when no tick arrived for `limit` seconds.  (The process-group timeout passed to init_process_group makes
+    RCCL's own watchdog abort a stuck collective on the same scale; this one also covers a hang outside a collective.)"""
+
+    def __init__(self, limit, rank):
+        import threading
+
+        self.limit, self.rank, self.stage, self.t = limit, rank, "start", time.monotonic()
+        if limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def tick(self, stage):
+        self.stage, self.t = stage, time.monotonic()
+
+    def _run(self):
+        import faulthandler
+
+        while True:
+            time.sleep(2.0)
+            idle = time.monotonic() - self.t
+            if idle > self.limit:
+                print(f"bench watchdog: rank {self.rank} made no progress for {idle:.0f} s in stage '{self.stage}' — giving up (exit 124)", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                os._exit(124)
 
 
 class SmiSampler:
@@ -218,14 +247,18 @@ def cpu_baseline(dims, S_full, ts, text_len, frames, infer_steps, cfg_forwards, 
     return out
 
 
-def ulysses_self_check(dist, world, rank):
-    """N > 1, before the timed region: a small Wan model (heads = 2 N) runs one CFG step sharded over the N ranks (the product Ulysses
+def ulysses_self_check(dist, world, rank, one_gpu_plumbing=False):
+    """N > 1, before the timed region: a one-layer Wan model with the real run's per-rank head count (5 x 128 per rank: at N = 8 exactly a Wan-14B
+    layer; in the one-GPU plumbing mode a small 2-layer one) on a short token grid runs one CFG step sharded over the N ranks (the product Ulysses
     path: RCCL all-to-alls on the blocked exchange buffers) and unsharded on every rank; the two noise predictions must agree to 5e-3
     relative L2 on every rank (same kernels on re-partitioned rows).  The result travels in the JSON line so that a scaling record
     proves N ranks really exchanged data."""
     from lightx2v_amd import scheduler, synth, wan
 
-    dims = dict(synth.WAN_DIMS["wan-tiny"], dim=256 * world, num_heads=2 * world, ffn_dim=1024, num_layers=2)
+    # the per-rank shapes of the real run where the node is full: 5 heads of 128 per rank (N = 8: D = 5120, 40 heads, F = 13824 = one Wan-14B layer)
+    dims = dict(synth.WAN_DIMS["wan2.1-14b"], dim=640 * world, num_heads=5 * world, num_layers=1)
+    if one_gpu_plumbing:
+        dims = dict(synth.WAN_DIMS["wan-tiny"], dim=256 * world, num_heads=2 * world, ffn_dim=1024, num_layers=2)  # N ranks share one GPU: keep it small
     ts = (16, 3, 8 * world, 12)  # tokens divisible by N
     wd = synth.synth_wan_weights(dims, seed=3, device="cuda", gen_device="cuda")
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
@@ -288,11 +321,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
 
+        import datetime
+
+        # a stuck / rejected collective is aborted by the process group's own watchdog after this long instead of the 10-minute default
+        pg_timeout = datetime.timedelta(seconds=max(60, args.hang_timeout or 240))
         if launch.one_gpu_test():  # plumbing mode: N ranks on ONE GPU over gloo with host-staged collectives (lightx2v_amd/launch.py) — timings meaningless
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
             launch.host_staged_collectives(dist)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+    watchdog = Watchdog((args.hang_timeout or 240) if world > 1 else args.hang_timeout, rank)
+    watchdog.tick("process group up")
 
     from lightx2v_amd import lib, scheduler, synth, wan
 
@@ -339,16 +378,20 @@ def main():
         sch.step_pre(i)
         model.infer(inputs)
         sch.step_post()
+        watchdog.tick(f"step {i} enqueued")  # host-side progress; a device-side hang surfaces at the next fence, which then stops ticking
 
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+        watchdog.tick("fence passed")
 
     sp_check = None
     if world > 1:
-        sp_check = ulysses_self_check(dist, world, rank)
+        watchdog.tick("Ulysses self-check")
+        sp_check = ulysses_self_check(dist, world, rank, launch.one_gpu_test())
+        watchdog.tick("Ulysses self-check passed")
         model.config["cfg_branch_streams"] = sp_check["settings"]["cfg_branch_streams"] and not args.no_cfg_streams
         model.transformer_infer.blocked_exchange = sp_check["settings"]["blocked_exchange"]
         model.transformer_infer.parallel_attention.split_head2seq = sp_check["settings"]["split_head2seq"]
@@ -388,6 +431,12 @@ def main():
                  "mfma_probe_tflops_before": lib.mfma_probe(args.probe_ms)}
     fence()
     sampler = SmiSampler(local_rank) if (calib is not None and world == 1) else contextlib.nullcontext()
+    comm_timer = None
+    if world > 1:
+        from lightx2v_amd import ulysses
+
+        comm_timer = ulysses.CommTimer()
+        model.transformer_infer.parallel_attention.comm_timer = comm_timer  # the CFG-branch driver hands it to the second branch's exchanges
     timer.enabled = True
     with sampler:
         t0 = time.perf_counter()
@@ -396,6 +445,17 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     timer.enabled = False
+    comm = None
+    if comm_timer is not None:
+        comm_timer.enabled = False
+        c_ms, e_ms, n_coll = comm_timer.totals_ms()
+        mine = {"rank": rank, "comm_ms_per_step": c_ms / args.steps, "exposed_comm_ms_per_step": e_ms / args.steps, "exchanges_per_step": n_coll / args.steps}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        comm = {"comm_ms_per_step": max(r["comm_ms_per_step"] for r in per_rank), "exposed_comm_ms_per_step": max(r["exposed_comm_ms_per_step"] for r in per_rank),
+                "per_rank": per_rank,
+                "definition": "HIP events on the communication stream around every exchange (comm) and on the compute streams around every join behind it (exposed = "
+                              "the compute stream had nothing to run but the wait); max over ranks; what replaced the reference's two torch.cuda.synchronize() per attention (ulysses/attn.py:48,85)"}
     if calib is not None:
         calib["mfma_probe_tflops_after"] = lib.mfma_probe(args.probe_ms)
         calib["mfma_probe_tflops"] = 0.5 * (calib["mfma_probe_tflops_before"] + calib["mfma_probe_tflops_after"])
@@ -456,6 +516,7 @@ def main():
         "rccl_world": (dist.get_world_size() if dist is not None else 1),
         "rccl_backend": (dist.get_backend() if dist is not None else None),
         "sp_self_check": sp_check,
+        "comm": comm,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,

@@ -106,6 +106,28 @@ def split_form_ok(group, device):
     return _SPLIT_PROBED[key]
 
 
+class CommTimer:
+    """HIP-event accounting of the exchanges (bench.py, N > 1): every collective issued on the communication stream is bracketed by two events
+    on that stream (`comm`: time the exchanges occupy the communication stream, queueing behind one another included), and every join of a
+    compute stream behind the communication stream by two events on the compute stream (`exposed`: how long the compute stream had nothing to
+    run but the wait — the part of the communication that no kernel of that stream hid; with the two CFG branches on two streams the other
+    branch may still have been computing).  The reference pays for the same exchanges with two `torch.cuda.synchronize()` per attention
+    (ulysses/attn.py:48,85); this is what replaced them costs.  Read after a device synchronisation."""
+
+    def __init__(self):
+        self.comm, self.exposed = [], []
+        self.enabled = True
+
+    def bracket(self, which, stream):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        (self.comm if which == "comm" else self.exposed).append((a, b))
+        a.record(stream)
+        return lambda: b.record(stream)
+
+    def totals_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.comm), sum(a.elapsed_time(b) for a, b in self.exposed), len(self.comm)
+
+
 class UlyssesAttention:
     """Callable injected as `transformer_infer.parallel_attention` (reference hook: transformer_infer.py:381-388)."""
 
@@ -118,6 +140,7 @@ class UlyssesAttention:
         self._buffers = {}
         self.copies = 0  # layout copies made by the row-major entry (the blocked entry makes none): asserted by the tests
         self.split_head2seq = self.split_head2seq_default  # head->seq in two halves (all_to_all_single with split sizes) under the second half's attention
+        self.comm_timer = None  # bench.py: a CommTimer (shared by both CFG branches) while the timed region runs
 
     split_head2seq_default = True
 
@@ -145,6 +168,24 @@ class UlyssesAttention:
             self.comm_stream = torch.cuda.Stream()
         return self.comm_stream
 
+    def _issue(self, cs, fn):
+        """fn() = one or more collectives, enqueued on the communication stream `cs` (already ordered behind the compute stream by the caller)."""
+        t = self.comm_timer
+        with torch.cuda.stream(cs):
+            done = t.bracket("comm", cs) if (t is not None and t.enabled) else None
+            out = fn()
+            if done is not None:
+                done()
+        return out
+
+    def _join(self, cur, cs):
+        """The compute stream `cur` waits for everything enqueued on the communication stream so far."""
+        t = self.comm_timer
+        done = t.bracket("exposed", cur) if (t is not None and t.enabled) else None
+        cur.wait_stream(cs)
+        if done is not None:
+            done()
+
     def on_comm(self, fn, src):
         """Run the collective `fn()` (which reads `src` and returns a fresh tensor) on the communication stream, ordered behind what the current
         stream has enqueued, and join the current stream behind it.  EVERY collective of this driver goes through the one communication stream
@@ -154,9 +195,8 @@ class UlyssesAttention:
             return fn()
         cur, cs = torch.cuda.current_stream(), self._comm()
         cs.wait_stream(cur)
-        with torch.cuda.stream(cs):
-            out = fn()
-        cur.wait_stream(cs)
+        out = self._issue(cs, fn)
+        self._join(cur, cs)
         src.record_stream(cs)   # produced under the compute stream, read by the collective
         out.record_stream(cur)  # allocated under the communication stream, read by the compute stream
         return out
@@ -167,8 +207,7 @@ class UlyssesAttention:
         if self.overlap and send.is_cuda:
             cs = self._comm()
             cs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cs):
-                dist.all_to_all_single(recv, send, group=self.group)
+            self._issue(cs, lambda: dist.all_to_all_single(recv, send, group=self.group))
         else:
             dist.all_to_all_single(recv, send, group=self.group)
         return self._Pending(send, recv)
@@ -186,12 +225,15 @@ class UlyssesAttention:
         if use_streams:
             cur, cs = torch.cuda.current_stream(), self._comm()
             cs.wait_stream(cur)
-            with torch.cuda.stream(cs):
+
+            def qkv():
                 dist.all_to_all_single(bufs["rq"], bufs["sq"], group=self.group)
                 dist.all_to_all_single(bufs["rk"], bufs["sk"], group=self.group)
                 if v_pending is None:
                     dist.all_to_all_single(bufs["rv"], bufs["sv"], group=self.group)
-            cur.wait_stream(cs)
+
+            self._issue(cs, qkv)
+            self._join(cur, cs)
         else:
             dist.all_to_all_single(bufs["rq"], bufs["sq"], group=self.group)
             dist.all_to_all_single(bufs["rk"], bufs["sk"], group=self.group)
@@ -219,12 +261,11 @@ class UlyssesAttention:
             timer("self", fn) if timer is not None else fn()
             if use_streams:
                 cs.wait_stream(cur)
-                with torch.cuda.stream(cs):
-                    dist.all_to_all_single(ro[rrows], o[rows], out_split, in_split, group=self.group)
+                self._issue(cs, lambda rows=rows, rrows=rrows, out_split=out_split, in_split=in_split: dist.all_to_all_single(ro[rrows], o[rows], out_split, in_split, group=self.group))
             else:
                 dist.all_to_all_single(ro[rrows], o[rows], out_split, in_split, group=self.group)
         if use_streams:
-            cur.wait_stream(cs)
+            self._join(cur, cs)
         return bufs["ro"]
 
     # ---- row-major entry (the reference's functional form) -----------------------------------------------------------------
@@ -344,6 +385,7 @@ class CfgBranchStreams(_WanCfgBranchStreams):
             self._pa_b.comm_stream = pa_a._comm()
         self._pa_a = self.model.transformer_infer.parallel_attention
         self._pa_b.split_head2seq = self._pa_a.split_head2seq
+        self._pa_b.comm_timer = self._pa_a.comm_timer
         return super()._setup()
 
     def _shard(self, x):

@@ -74,6 +74,7 @@ def main():
             print("REFERENCE_EXCHANGE_OK")
 
     hunyuan_checks(r, n, ulysses, O)
+    teacache_decision_is_rank_invariant(r, n, ulysses)
 
     # distributed oracle forward == single-process oracle forward (pins compute_freqs_dist + sharding; S % N == 0)
     from lightx2v_amd import synth
@@ -105,6 +106,28 @@ def main():
     if r == 0:
         print("DIST_OK")
     dist.destroy_process_group()
+
+
+def teacache_decision_is_rank_invariant(r, n, ulysses):
+    """HunyuanTransformerInferTeaCaching under Ulysses: the relative-L1 change that decides whether the next step skips the block
+    stack is reduced over the sequence-parallel group, so every rank computes the SAME number from different shards (a rank-local decision
+    could diverge at the threshold: one rank skips the all-to-alls, the others hang in them) — and it equals the unsharded tensors' ratio."""
+    from lightx2v_amd import hunyuan as hy
+
+    g = torch.Generator().manual_seed(21)
+    full_prev = torch.randn(8 * n, 64, generator=g).to(torch.bfloat16)
+    full_now = (full_prev.float() + 0.05 * torch.randn(8 * n, 64, generator=g)).to(torch.bfloat16)
+    tc = hy.HunyuanTransformerInferTeaCaching.__new__(hy.HunyuanTransformerInferTeaCaching)
+    tc.parallel_attention = None
+    assert tc._sharded_rel_l1(full_now, full_prev) is None  # not sharded: the single-GPU arithmetic stays as it is
+    tc.parallel_attention = ulysses.UlyssesHunyuanAttention(overlap=False)
+    sl = slice(8 * r, 8 * (r + 1))
+    rel = tc._sharded_rel_l1(full_now[sl], full_prev[sl])
+    want = ((full_now - full_prev).abs().float().sum().double() / full_prev.abs().float().sum().double()).item()
+    assert abs(rel - want) <= 1e-6 * want, (rel, want)
+    gathered = [None] * n
+    dist.all_gather_object(gathered, rel)
+    assert all(x == gathered[0] for x in gathered), gathered
 
 
 def hunyuan_checks(r, n, ulysses, O):

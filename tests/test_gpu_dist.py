@@ -60,8 +60,9 @@ def test_ulysses_over_rccl_world1():
     assert "DIST_GPU_RCCL1_OK" in p.stdout
 
 
-def test_bench_n8_code_path_on_one_gpu():
-    """`python bench.py --gpus 8` END TO END on a one-GPU box (X2V_ONE_GPU_TEST=1: all ranks drive cuda:0 over gloo with host-staged collectives,
+@pytest.mark.parametrize("gpus", [2, 4, 8])
+def test_bench_n8_code_path_on_one_gpu(gpus):
+    """`python bench.py --gpus N` (N = 2, 4, 8: what the driver's scaling run launches) END TO END on a one-GPU box (X2V_ONE_GPU_TEST=1: all ranks drive cuda:0 over gloo with host-staged collectives,
     lightx2v_amd/launch.py): the self-launch under torch.distributed.run, the Ulysses self-check walking the designed path (CFG branches on two
     streams, blocked buffers, two-piece head->seq), the per-instance settings handed to the timed model, the timed loop with barriers and the
     max-over-ranks reduction, the per-launch attention timers and the JSON line.  Everything the 8-GPU scaling run executes except RCCL itself;
@@ -70,17 +71,24 @@ def test_bench_n8_code_path_on_one_gpu():
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", X2V_ONE_GPU_TEST="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "wan-tiny-h8", "--steps", "2", "--warmup", "1", "--infer-steps", "4"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "wan-tiny-h8", "--steps", "2", "--warmup", "1", "--infer-steps", "4", "--probe-ms", "100"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 8 and d["rccl_world"] == 8 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["n_gpus"] == gpus and d["rccl_world"] == gpus and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
     assert "PLUMBING RUN" in d["data"]
     sp = d["sp_self_check"]
-    assert sp["passed"] and sp["ranks"] == 8 and sp["worst_rel_l2"] < 5e-3, sp
+    assert sp["passed"] and sp["ranks"] == gpus and sp["worst_rel_l2"] < 5e-3, sp
     assert sp["settings"] == {"cfg_branch_streams": True, "blocked_exchange": True, "split_head2seq": True}, sp
-    assert d["config"]["parallelism"] == "ulysses-sp8"
+    assert d["config"]["parallelism"] == f"ulysses-sp{gpus}"
+    # exchange accounting (HIP events on the communication stream / around the joins), per rank and max over ranks
+    cm = d["comm"]
+    assert len(cm["per_rank"]) == gpus and cm["comm_ms_per_step"] > 0 and cm["exposed_comm_ms_per_step"] >= 0, cm
+    # per step: 2 layers x 2 CFG branches x (v | q,k | 2 head->seq pieces) + the gather behind each branch's block stack
+    assert all(r["exchanges_per_step"] == 2 * 2 * 4 + 2 for r in cm["per_rank"]), cm
+    cal = d["box_calibration"]
+    assert cal["mfma_probe_tflops_before"] > 0 and cal["mfma_probe_tflops_after"] > 0 and d["roofline"]["frac_of_probe"] is not None
     ft = d["config"]["cfg_form_timing"]  # N > 1: the two CFG forms are timed (untimed region) and the MAX over ranks picks one
     assert ft["chosen"] in ("two streams", "sequential") and ft["two_streams_ms"] > 0 and ft["sequential_ms"] > 0, ft
     assert d["config"]["cfg_form"].startswith("two compute streams" if ft["chosen"] == "two streams" else "one forward after the other"), d["config"]["cfg_form"]

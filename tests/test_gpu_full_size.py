@@ -337,8 +337,8 @@ def test_hunyuan13b_block_720p_129f_vs_oracle_rows(kind):
     """One HunyuanVideo-13B double block / single block (hidden 3072, 24 heads, mlp 12288) at config #5's full token count — 118 800 image tokens
     (token grid 33 x 45 x 80) + 256 text tokens, 200 of them valid (two attention segments) — through `HunyuanTransformerInfer.infer`, against
     `oracle.hunyuan_oracle.double_block_rows` / `single_block_rows` (hunyuan/infer/transformer_infer.py:81-384 restricted to sampled image rows;
-    the k / v projections of all 119 056 rows run on the host).  Inputs are seeded tensors at the block boundary; relative L2 <= 1e-2 like the
-    2 560-token version of this test (test_gpu_bench_shapes.py)."""
+    the k / v projections of all 119 056 rows run on the host).  Inputs are seeded tensors at the block boundary; relative L2 <= 4e-3 (about 3 x the
+    measured 1.2e-3 / 3.4e-4; the 60-block forward against the fp32 graph is test_hunyuan13b_720p_129f_full_forward_vs_fp32_truth)."""
     from lightx2v_amd import hunyuan as hy, synth
     from oracle import hunyuan_oracle as H
 
@@ -368,7 +368,7 @@ def test_hunyuan13b_block_720p_129f_vs_oracle_rows(kind):
     assert out.shape[0] == n_img and torch.isfinite(out.float()).all()
     e = rel_l2(out[rows.cuda()], ref)
     record(f"Hunyuan-13B {kind} block at 118800 + 256 tokens", rows=len(rows), rel_l2_vs_oracle=e)
-    assert e <= 1e-2, f"Hunyuan-13B {kind} block at full size: relative L2 vs oracle {e:.3e}"
+    assert e <= 4e-3, f"Hunyuan-13B {kind} block at full size: relative L2 vs oracle {e:.3e}"  # measured on MI355X: 1.2e-3 (double) / 3.4e-4 (single)
 
 
 # ------------------------------------------------------------------------------------------------ config #4: a w8a8 block at full size
@@ -382,7 +382,10 @@ def test_wan14b_fp8_block_vs_oracle_rows(tokens, ref_rounding):
     Tolerance.  A w8a8 graph is far more sensitive to upstream rounding than the bf16 one: an activation that differs by one bf16 ulp lands on
     another e4m3 code (3 mantissa bits: a 6 % step) in ~7 % of the cases, and a GEMM passes that on undamped — so two correct implementations of the
     same w8a8 block that round their LayerNorm differently sit ~1e-2 apart (measured on MI355X: 1.10e-2 at both sizes, against 2.9e-3 for the
-    bf16 block), while the graph's own quantisation error is 2.6e-2.  Hence: <= 1.5e-2 and at most half of the quantisation error."""
+    bf16 block), while the graph's own quantisation error is 2.6e-2.  That claim is ANCHORED, not asserted: the fp32
+    evaluation of the unquantised block is the truth, and the HIP w8a8 block may be at most 1.25 x as far from it as the reference's w8a8 arithmetic
+    (the oracle inside `fp8_blocks()`) is — the same triangle every bf16 test carries — plus: at most half of the quantisation error away from the
+    w8a8 oracle itself."""
     from lightx2v_amd import scheduler, synth, wan
     from oracle import wan_oracle as O
 
@@ -399,6 +402,8 @@ def test_wan14b_fp8_block_vs_oracle_rows(tokens, ref_rounding):
     with O.fp8_blocks():
         ref = O.wan_block_rows(wd, 0, dims, grid, x_o, embed0_o, freqs, context_o, rows)
     ref_bf16 = O.wan_block_rows(wd, 0, dims, grid, x_o, embed0_o, freqs, context_o, rows)
+    with O.truth_precision(torch.float32):
+        tru = O.wan_block_rows(O.upcast(wd), 0, dims, grid, x_o.float(), embed0_o.float(), freqs, context_o.float(), rows)
     cfg = wan.default_config(dims, target_shape=ts, target_video_length=(ts[1] - 1) * 4 + 1, infer_steps=4, enable_cfg=False, hip_ref_rounding=ref_rounding,
                              mm_config={"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True})
     model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
@@ -413,9 +418,13 @@ def test_wan14b_fp8_block_vs_oracle_rows(tokens, ref_rounding):
     assert torch.isfinite(out.float()).all()
     got = out[rows.cuda()]
     e, e_q = rel_l2(got, ref), rel_l2(ref, ref_bf16)
-    record(f"Wan-14B w8a8 block S={S} (ref_rounding={ref_rounding})", rows=len(rows), rel_l2_vs_fp8_oracle=e, fp8_oracle_vs_bf16_oracle=e_q)
+    e_hip, e_ref = rel_l2(got, tru), rel_l2(ref, tru)
+    record(f"Wan-14B w8a8 block S={S} (ref_rounding={ref_rounding})", rows=len(rows), rel_l2_vs_fp8_oracle=e, fp8_oracle_vs_bf16_oracle=e_q, err_hip_w8a8_vs_fp32=e_hip,
+           err_oracle_w8a8_vs_fp32=e_ref)
+    # the triangle: the HIP w8a8 block is no further from the fp32 truth than the reference's w8a8 arithmetic is (x 1.25)
+    assert e_hip <= 1.25 * e_ref, f"w8a8 block at S={S}: {e_hip:.3e} from the fp32 truth, the w8a8 oracle {e_ref:.3e}"
     # the w8a8 graph sits e_q (quantisation error) away from the bf16 graph; the HIP block must match the w8a8 ORACLE much closer than that
-    assert e <= 1.5e-2 and e <= 0.5 * e_q, f"w8a8 block at S={S}: relative L2 vs the w8a8 oracle {e:.3e} (quantisation error of the graph itself: {e_q:.3e})"
+    assert e <= 0.5 * e_q, f"w8a8 block at S={S}: relative L2 vs the w8a8 oracle {e:.3e} (quantisation error of the graph itself: {e_q:.3e})"
 
 
 # ------------------------------------------------------------------------------------------------ config #2: the whole 30-layer forward at S = 20 280
@@ -453,41 +462,79 @@ def test_wan13b_config2_full_forward_vs_fp32_truth():
 
 
 # ------------------------------------------------------------------------------------------------ configs #3 / #4: the whole benched forward
-def test_wan14b_720p_full_forward_vs_fp32_truth():
-    """THE forward the benchmark times — Wan2.1-14B, all 40 layers, 720p x 81 frames = 75 600 tokens (pre-infer, 40 fused blocks with the staggered
-    16x16x32 attention launch, post-infer) — against the oracle's statements evaluated in fp32 through plain PyTorch on the same GPU
-    (`O.truth_precision(float32, device="cuda")`; attention exactly, in query chunks: the full fp32 score tensor would be 914 GB).  ~2 min of fp32
-    GEMMs.  Bound: 2e-2 relative L2 on the noise prediction; the anchored tests show both the HIP path and the reference's bf16 CPU path 1.2e-2 from the
-    fp32 graph after 30 layers at 1 280 tokens (and the HIP path 1.28e-2 at 20 280), so 40 layers at 75 600 tokens have head room without hiding a
-    broken layer (one wrong block moves the result by O(1))."""
-    from lightx2v_amd import scheduler, synth, wan
+@pytest.fixture(scope="module")
+def wan14b_720p():
+    """Weights (what bench.py builds: seed 0, generated on the device), inputs and — computed once for both tests below, ~100 s of fp32 GEMMs — the
+    fp32 TRUTH of the 40-layer conditional forward at 75 600 tokens: the oracle's statements through plain PyTorch on the same GPU
+    (`O.truth_precision(float32, device="cuda")`; attention exactly, in query chunks: the full fp32 score tensor would be 914 GB)."""
+    from lightx2v_amd import synth
     from oracle import wan_oracle as O
 
     dims = synth.WAN_DIMS["wan2.1-14b"]
     wl = synth.WORKLOADS["wan14b_720px81f"]
     ts = wl["target_shape"]
     assert synth.seq_len_of(ts) == S_WAN
-    wd = synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda")  # what bench.py builds
+    wd = synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda")
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     t = torch.tensor(500)
-    cfg = wan.default_config(dims, target_shape=ts, target_video_length=wl["frames"], infer_steps=4)
-    model = wan.WanModel(cfg, wd)
-    sch = scheduler.WanScheduler(cfg, device="cuda")
-    sch.prepare(latents=lat)
-    sch.timesteps[1] = 500
-    model.set_scheduler(sch)
-    sch.step_pre(1)
-    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
-    got = model._forward(inputs, True).float().cpu()
-    assert torch.isfinite(got).all()
-    del model
-    torch.cuda.empty_cache()
     with O.truth_precision(torch.float32, device="cuda"), torch.no_grad():
         wd32 = {k: v.float() for k, v in wd.items()}
-        del wd
         tru = O.wan_forward(wd32, dims, lat.to(torch.bfloat16).float().cuda(), t, O.upcast(ctx, device="cuda")).cpu()
-    del wd32
+        del wd32
     torch.cuda.empty_cache()
-    e = rel_l2(got, tru)
+    yield dict(dims=dims, wl=wl, ts=ts, wd=wd, lat=lat, ctx=ctx, ctx_null=ctx_null, t=t, tru=tru)
+    wd.clear()
+    torch.cuda.empty_cache()
+
+
+def _hip_forward(env, **cfg_extra):
+    from lightx2v_amd import scheduler, wan
+
+    cfg = wan.default_config(env["dims"], target_shape=env["ts"], target_video_length=env["wl"]["frames"], infer_steps=4, **cfg_extra)
+    model = wan.WanModel(cfg, env["wd"])
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=env["lat"])
+    sch.timesteps[1] = int(env["t"])
+    model.set_scheduler(sch)
+    sch.step_pre(1)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in env["ctx"]], "context_null": [c.cuda() for c in env["ctx_null"]]}}
+    got = model._forward(inputs, True).float().cpu()
+    del model
+    torch.cuda.empty_cache()
+    return got
+
+
+def test_wan14b_720p_full_forward_vs_fp32_truth(wan14b_720p):
+    """THE forward the benchmark times — Wan2.1-14B, all 40 layers, 720p x 81 frames = 75 600 tokens (pre-infer, 40 fused blocks with the staggered
+    16x16x32 attention launch, post-infer) — against the fp32 truth of the fixture above.  Bound: 2e-2 relative L2 on the noise prediction; the
+    anchored tests show both the HIP path and the reference's bf16 CPU path 1.2e-2 from the fp32 graph after 30 layers at 1 280 tokens (and the
+    HIP path 1.28e-2 at 20 280), so 40 layers at 75 600 tokens have head room without hiding a broken layer (one wrong block moves the result
+    by O(1))."""
+    env = wan14b_720p
+    got = _hip_forward(env)
+    assert torch.isfinite(got).all()
+    e = rel_l2(got, env["tru"])
     record("Wan-14B 40-layer forward at S=75600 (the benched forward) vs fp32 truth", err_hip_vs_fp32=e)
-    assert got.shape == tru.shape and e <= 2e-2, f"the benched forward is {e:.3e} from the fp32 graph"
+    assert got.shape == env["tru"].shape and e <= 2e-2, f"the benched forward is {e:.3e} from the fp32 graph"
+
+
+def test_wan14b_720p_w8a8_full_forward_anchored_to_fp32_truth(wan14b_720p):
+    """BASELINE config #4's forward in full depth and length: Wan2.1-14B with the w8a8 operator class in all 40 blocks
+    (mm_weight.py:236-245,287-319; LayerNorm fused with the per-token quantisation, fp8 MFMA GEMMs, bf16 attention) at 75 600 tokens, one
+    forward (config #4 has no CFG), in a triangle with the same fp32 truth:
+        err(HIP w8a8 forward vs truth)  <=  1.25 x err(the ORACLE's w8a8 forward vs truth).
+    The oracle's leg is `O.wan_forward` inside `O.fp8_blocks()` — the statements pinned bit-exactly to the reference's own w8a8 model
+    (tests/test_oracle_golden.py) — evaluated through plain PyTorch on this GPU (bf16 activations; `xq.float() @ wq.float().t()` in fp32 exactly as
+    written; torch's SDPA): on the CPU its attention alone would be 5e15 FLOP.  No library GEMM or attention of this repo is in that leg."""
+    from oracle import wan_oracle as O
+
+    env = wan14b_720p
+    got = _hip_forward(env, enable_cfg=False, mm_config={"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True})
+    assert torch.isfinite(got).all()
+    with O.fp8_blocks(), torch.no_grad():
+        ref = O.wan_forward(env["wd"], env["dims"], env["lat"].to(torch.bfloat16).cuda(), env["t"], [c.cuda() for c in env["ctx"]]).float().cpu()
+    torch.cuda.empty_cache()
+    e_hip, e_ref, e = rel_l2(got, env["tru"]), rel_l2(ref, env["tru"]), rel_l2(got, ref)
+    record("Wan-14B w8a8 40-layer forward at S=75600 (config #4) vs fp32 truth", err_hip_w8a8_vs_fp32=e_hip, err_oracle_w8a8_vs_fp32=e_ref, hip_vs_oracle_w8a8=e)
+    assert got.shape == env["tru"].shape
+    assert e_hip <= 1.25 * e_ref, f"w8a8 forward: {e_hip:.3e} from the fp32 truth, the oracle's w8a8 forward {e_ref:.3e}"
