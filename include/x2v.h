@@ -132,8 +132,11 @@ int x2v_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
 /* Same, selecting the kernel (tuning / validation hook).  variant & 0xff: 0 = by shape (what x2v_gemm_bf16 does:
  * the 256x256-tile ping-pong kernel of gemm256.hip when the grid fills the chip, else the 128x128 kernel of
  * gemm.hip), 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (two waves per SIMD; fp8's and mxfp8's large-shape kernel), 3 = 256x256
- * single-stream kernel (one software-pipelined wave per SIMD; bf16 only, its large-shape kernel); variant >> 8 = m-tiles per scheduling group of the
- * 256x256 kernel (0 = default). */
+ * single-stream kernel (one software-pipelined wave per SIMD; bf16 only, its large-shape kernel) in the form the dispatcher prefers, 4 = its
+ * one-output-tile-per-workgroup form (gemm256s.hip), 5 = its continuous-pipeline form (gemm256c.hip: persistent workgroups, the K loop runs on
+ * into the next output tile, epilogue straight from the accumulators; needs K a multiple of 128 and >= 256, N a multiple of 256, y blocks
+ * that are multiples of 128 columns and resid with y's row stride, else X2V_E_SHAPE; same bits as form 4); (variant >> 8) & 0xff = m-tiles per
+ * scheduling group of the 256x256 kernels (0 = default). */
 int x2v_gemm_bf16_variant(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* y, int64_t ldy, int64_t M, int N, int K,
                           int epilogue, const void* resid, int64_t ldr, const void* gate, int variant, void* stream);
 

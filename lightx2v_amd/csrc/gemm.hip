@@ -261,6 +261,10 @@ int gemm256_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, i
 int gemm256s_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
                       const void* resid, int64_t ldr, const void* gate, int gm_tiles, hipStream_t st, GemmBlocking gb);
 int gemm256s_vt_dispatch(const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int nk, hipStream_t st);
+// gemm256c.hip: the single-stream kernel as a continuous pipeline over output tiles (persistent workgroups, register-direct epilogue)
+bool gemm256c_ok(int nk, const GemmBlocking& gb);
+int gemm256c_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
+                      const void* resid, int64_t ldr, const void* gate, int gm_tiles, hipStream_t st, GemmBlocking gb);
 }  // namespace x2v
 
 using namespace x2v;
@@ -301,15 +305,19 @@ static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb, b
   return (fits256 && tiles256 >= 192 && nk >= 8) ? (fp8 ? 2 : X2V_GEMM256_BF16_KERNEL) : 1;
 }
 
-// variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel, 3 = 256x256 single-stream kernel (bf16); bits 8..15 = m-tiles per scheduling
-// group of the 256x256 kernel (0 = default)
+// variant: 0 = choose by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel, 3 = 256x256 single-stream kernel (bf16) in the form the
+// dispatcher prefers (continuous pipeline where the shape allows it), 4 = its one-output-tile-per-workgroup form (gemm256s.hip), 5 = its continuous
+// form (gemm256c.hip; X2V_E_SHAPE where it does not apply); bits 8..15 = m-tiles per scheduling group of the 256x256 kernel (0 = default).
+// X2V_GEMM_CONTINUOUS=0 in the environment turns the continuous form off for variants 0 / 3 (whole-model A/B runs).
 template <bool FP8>
 static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N,
                         int nk, const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int variant, hipStream_t st,
                         GemmBlocking gb = GemmBlocking()) {
-  const int kind = variant & 0xff;
+  int kind = variant & 0xff;
   const int gm_tiles = (variant >> 8) & 0xff;
   const bool fits256 = spans_fit_256(nk, ldxb, ldwb, gb);
+  const int form = (kind == 4 || kind == 5) ? kind : 0;  // a forced form of the single-stream kernel
+  if (form) kind = 3;
   if ((kind == 2 || kind == 3) && !fits256) {
     set_error("gemm: leading dimension / K-block span too large for the 256x256 kernels (32-bit tile addressing)");
     return X2V_E_SHAPE;
@@ -330,7 +338,18 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
       }
       return dispatch_epi<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, 2 | (gm_tiles << 8), st, gb);
     }
-    if (chosen == 3) return gemm256s_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
+    if (chosen == 3) {
+      // continuous form: its epilogue addresses the output / residual tile through descriptors of 2^31 bytes (offset 0x80000000 is the "no such
+      // row" mark), so the tile spans must stay below that
+      static const bool continuous_on = [] { const char* e = getenv("X2V_GEMM_CONTINUOUS"); return e == nullptr || atoi(e) != 0; }();
+      const bool can_c = gemm256c_ok(nk, gb) && N % 256 == 0 && (255 * ldy + y_cols_span) * 2 < 0x80000000ll && (resid == nullptr || (ldr == ldy && gb.y_cbw <= 0));  // residual tile addressed with y's offsets
+      if (form == 5 && !can_c) {
+        set_error("gemm: the continuous single-stream kernel needs an even number of K tiles >= 4, N %% 256 == 0, y blocks that are multiples of 128 columns and resid with y's row stride (nk=%d, N=%d)", nk, N);
+        return X2V_E_SHAPE;
+      }
+      if (form == 5 || (form == 0 && continuous_on && can_c)) return gemm256c_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
+      return gemm256s_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, gm_tiles, st, gb);
+    }
   }
   if (chosen == 2) {
     return gemm256_dispatch<FP8>(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st, gb);

@@ -323,3 +323,57 @@ def test_batched_attention_equals_per_sequence_launches(lib):
         assert torch.equal(out[rows], ref), f"sequence {b}: max |d| = {(out[rows].float() - ref.float()).abs().max().item():.3e}"
     o2 = lib.attention_batched(q, k, vt, H, B, Sp, S, all_rows_query=False)
     assert torch.equal(o2[:S], out[:S]) and torch.equal(o2[Sp : Sp + S], out[Sp : Sp + S])
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 256), (4100, 2560, 5120), (20280, 1536, 1536), (9450, 5120, 5120), (1000, 13824, 256), (66000, 256, 1024)])
+def test_gemm_continuous_pipeline_equals_one_tile_per_workgroup(M, K, N):
+    """gemm256c.hip (variant 5: persistent workgroups, the K loop running on into the next output tile, wave-private epilogue) against
+    gemm256s.hip (variant 4: one output tile per workgroup): same MFMA, same k order, same rounding points -> the SAME BITS, over one-tile and
+    multi-tile workgroups (2 / 340 / 480 / 740 tiles), 4 to 216 K tiles, ragged M, every epilogue, bias / gate absent, rows around the output
+    untouched, scheduling-group sizes, and blocked operands through the dispatcher's default form.  Also: shapes the continuous form does not
+    take are refused when forced and served by the other form otherwise (mm_weight.py:81-88 is the op both implement)."""
+    from lightx2v_amd import lib
+
+    lib.init()
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    gate = (torch.randn(N, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    for gm in (0, 1, 7):
+        for epi, kw in ((lib.EPI_NONE, {}), (lib.EPI_NONE, {"bias": None}), (lib.EPI_GELU_TANH, {}), (lib.EPI_SILU, {}), (lib.EPI_RESIDUAL, {"gate": gate}), (lib.EPI_RESIDUAL, {"gate": None})):
+            bias = kw.get("bias", b)
+            outs = []
+            for form in (4, 5):
+                if epi == lib.EPI_RESIDUAL:
+                    r = res.clone()
+                    lib.gemm(x, w, bias, epilogue=epi, resid=r, gate=kw["gate"], variant=form | (gm << 8))
+                    outs.append(r)
+                else:
+                    y = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")  # nothing may be written outside rows [1, M + 1)
+                    lib.gemm(x, w, bias, epilogue=epi, out=y[1 : M + 1], variant=form | (gm << 8))
+                    outs.append(y)
+            assert torch.equal(outs[0], outs[1]), (M, K, N, epi, gm, sorted(kw))
+            assert (outs[1][0] == 7).all() and (outs[1][-1] == 7).all() if epi != lib.EPI_RESIDUAL else True
+    nb = 2
+    if K % (nb * 64) == 0 and N % (nb * 128) == 0:
+        ref = lib.gemm(x, w, b, variant=4)
+        out = torch.full((nb, M + 3, N // nb), 7.0, dtype=torch.bfloat16, device="cuda")[:, 1 : M + 1]
+        lib.gemm(x, w, b, out=out)
+        assert torch.equal(out.transpose(0, 1).reshape(M, N), ref), "N-blocked y"
+        xb = x.view(M, nb, K // nb).transpose(0, 1).contiguous()
+        assert torch.equal(lib.gemm(xb, w, b), ref), "K-blocked x"
+        r1, r2 = res.clone(), res.clone()
+        lib.gemm(xb, w, b, epilogue=lib.EPI_RESIDUAL, resid=r1, gate=gate)
+        lib.gemm(x, w, b, epilogue=lib.EPI_RESIDUAL, resid=r2, gate=gate, variant=4)
+        assert torch.equal(r1, r2), "K-blocked x + residual"
+    # shapes outside the continuous form: an odd number of K tiles, N not a multiple of 256
+    xo = x[:, : K - 64] if K >= 256 + 64 else None
+    if xo is not None:
+        with pytest.raises(lib.X2VError):
+            lib.gemm(xo, w[:, : K - 64], b, variant=5)
+        assert torch.equal(lib.gemm(xo, w[:, : K - 64], b, variant=3), lib.gemm(xo, w[:, : K - 64], b, variant=4))
+    if N > 256:
+        with pytest.raises(lib.X2VError):
+            lib.gemm(x, w[: N - 128], b[: N - 128], variant=5)
