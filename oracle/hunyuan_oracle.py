@@ -24,9 +24,16 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from oracle.wan_oracle import layer_norm, mm, rms_norm
+from oracle.wan_oracle import _ACT, _sdpa_exact_chunked, layer_norm, mm, rms_norm
 
 BF16 = torch.bfloat16
+
+
+def _act():
+    """Activation dtype of the graph: bf16, or what `wan_oracle.truth_precision()` switched to (the same statements evaluated without the bf16
+    rounding points — the accuracy reference of the full-size model test).  Every tensor this module creates lives on its inputs' device, so the
+    statements also run through plain PyTorch on a GPU (tests/test_gpu_full_size.py: 119 056 tokens x 60 blocks are out of the host's reach)."""
+    return _ACT[-1]
 
 
 # ----------------------------------------------------------------------------- scheduler pieces
@@ -37,10 +44,10 @@ def set_timesteps_sigmas(num_inference_steps, shift, num_train_timesteps=1000):
     return (sigmas[:-1] * num_train_timesteps).to(torch.float32), sigmas
 
 
-def rope_tables(rope_sizes, rope_dim_list=(16, 56, 56), theta=256.0):
+def rope_tables(rope_sizes, rope_dim_list=(16, 56, 56), theta=256.0, dtype=BF16):
     """get_nd_rotary_pos_embed(use_real=True) (scheduler.py:18-63,66-108,111-172) as called by
     prepare_rotary_pos_embedding (:278-319): per axis a, freqs = 1/theta^(2j/d_a), cos/sin of pos*freqs with every value
-    repeated twice (interleaved pairs), axes concatenated → [T*H*W, 128] each, then rounded to bf16."""
+    repeated twice (interleaved pairs), axes concatenated → [T*H*W, 128] each, then rounded to bf16 (`dtype`: the truth evaluation keeps fp32)."""
     axes = [torch.linspace(0, n, n + 1, dtype=torch.float32)[:n] for n in rope_sizes]
     grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=0)
     cos, sin = [], []
@@ -49,7 +56,7 @@ def rope_tables(rope_sizes, rope_dim_list=(16, 56, 56), theta=256.0):
         f = torch.outer(grid[a].reshape(-1), freqs)
         cos.append(f.cos().repeat_interleave(2, dim=1))
         sin.append(f.sin().repeat_interleave(2, dim=1))
-    return torch.cat(cos, dim=1).to(BF16), torch.cat(sin, dim=1).to(BF16)
+    return torch.cat(cos, dim=1).to(dtype), torch.cat(sin, dim=1).to(dtype)
 
 
 def euler_step(latents, noise_pred, sigmas, step_index):
@@ -77,9 +84,12 @@ def varlen_attention(q, k, v, cu_seqlens):
     cu_seqlens built in pre_infer.py:50-56): dense non-causal attention inside each [cu[i], cu[i+1]) segment.
     q, k, v [L, H, D] → [L, H*D].  With an all-ones text mask the second segment is empty and this equals the
     `torch_sdpa` op's dense attention (the form the fixture was generated with)."""
-    out = torch.empty(q.shape[0], q.shape[1] * q.shape[2], dtype=q.dtype)
+    out = torch.empty(q.shape[0], q.shape[1] * q.shape[2], dtype=q.dtype, device=q.device)
     for a, b in zip(cu_seqlens[:-1].tolist(), cu_seqlens[1:].tolist()):
         if b > a:
+            if q.dtype != BF16 and (b - a) * (b - a) * q.shape[1] * q.element_size() > (32 << 30):
+                out[a:b] = _sdpa_exact_chunked(q[a:b], k[a:b], v[a:b])  # truth evaluation at a size whose score tensor does not fit in one piece
+                continue
             qs, ks, vs = (t[a:b].unsqueeze(0).transpose(1, 2) for t in (q, k, v))
             o = F.scaled_dot_product_attention(qs, ks, vs).transpose(1, 2)
             out[a:b] = o.reshape(b - a, -1)
@@ -272,11 +282,11 @@ class TeaCacheOracle:
 
 
 # ----------------------------------------------------------------------------- pre / post
-def _t_embed(t):
+def _t_embed(t, device=None):
     """pre_infer.py:62-64,73-75,147-149: cos|sin of t * exp(-ln(1e4) j / 128) in fp32, rounded to bf16; [1, 256]."""
     freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=128, dtype=torch.float32) / 128)
-    args = t.reshape(1, 1).float() * freqs[None]
-    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(BF16)
+    args = t.reshape(1, 1).float().cpu() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).to(_act()).to(device)
 
 
 def _mlp_silu(wd, a, b, x):
@@ -299,11 +309,12 @@ def token_refiner_block(wd, j, x, c, mask, heads):
 def pre_infer(wd, dims, latents, t, guidance, text_states, text_mask, text_states_2):
     """pre_infer.py:14-60 (t2v).  latents [1,16,T,H,W]; text_states [1,L,4096] bf16; text_mask [1,L] int; text_states_2
     [1,768] bf16.  Returns img [S, hidden], txt [L, hidden], vec [1, hidden], cu_seqlens_qkv, max_seqlen_qkv."""
-    time_out = _mlp_silu(wd, "time_in.mlp.0", "time_in.mlp.2", _t_embed(t))
+    dev = latents.device
+    time_out = _mlp_silu(wd, "time_in.mlp.0", "time_in.mlp.2", _t_embed(t, dev))
     img = F.conv3d(latents, wd["img_in.proj.weight"], wd["img_in.proj.bias"], stride=(1, 2, 2)).flatten(2).transpose(1, 2)[0]
     # text: timestep- and context-aware conditioning vector, input embedding, two refiner blocks
-    t_aware = _mlp_silu(wd, "txt_in.t_embedder.mlp.0", "txt_in.t_embedder.mlp.2", _t_embed(t))
-    mask_float = text_mask.float().unsqueeze(-1).to(BF16)
+    t_aware = _mlp_silu(wd, "txt_in.t_embedder.mlp.0", "txt_in.t_embedder.mlp.2", _t_embed(t, dev))
+    mask_float = text_mask.float().unsqueeze(-1).to(_act())
     ctx = (text_states * mask_float).sum(dim=1) / mask_float.sum(dim=1)
     c = t_aware + _mlp_silu(wd, "txt_in.c_embedder.linear_1", "txt_in.c_embedder.linear_2", ctx)
     x = _lin(wd, "txt_in.input_embedder", text_states[0])
@@ -314,7 +325,7 @@ def pre_infer(wd, dims, latents, t, guidance, text_states, text_mask, text_state
     for j in range(2):
         x = token_refiner_block(wd, j, x, c, mask, dims["heads"])
     vec = time_out + _mlp_silu(wd, "vector_in.in_layer", "vector_in.out_layer", text_states_2)
-    g_embed = _t_embed(guidance)
+    g_embed = _t_embed(guidance, dev)
     vec = vec + _mlp_silu(wd, "guidance_in.mlp.0", "guidance_in.mlp.2", g_embed)
     n_img = img.shape[0]
     s1 = int(text_mask.sum()) + n_img

@@ -538,3 +538,68 @@ def test_wan14b_720p_w8a8_full_forward_anchored_to_fp32_truth(wan14b_720p):
     record("Wan-14B w8a8 40-layer forward at S=75600 (config #4) vs fp32 truth", err_hip_w8a8_vs_fp32=e_hip, err_oracle_w8a8_vs_fp32=e_ref, hip_vs_oracle_w8a8=e)
     assert got.shape == env["tru"].shape
     assert e_hip <= 1.25 * e_ref, f"w8a8 forward: {e_hip:.3e} from the fp32 truth, the oracle's w8a8 forward {e_ref:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ config #5: the whole HunyuanVideo-13B forward
+def test_hunyuan13b_720p_129f_full_forward_anchored():
+    """BASELINE config #5's forward in full length — HunyuanVideo-13B at 720p x 129 frames: 118 800 image + 256 text tokens (200 valid: two attention
+    segments), pre-infer with the masked token refiner, double + single block stack, post-infer (hunyuan/infer/{pre,transformer,post}_infer.py) —
+    through `HunyuanModel.infer`, two legs:
+      A. FULL DEPTH, 20 double + 40 single blocks: against the ORACLE's own bf16 statements (`oracle.hunyuan_oracle.forward`, pinned bit-exactly to the
+         reference's classes at a reduced width) evaluated through plain PyTorch on this GPU — `torch.addmm`, torch's SDPA, bf16 elementwise ops: an
+         independent implementation of the same graph at a size (1.0e16 FLOP of attention) the host cannot run.  Two bf16 evaluations of a 60-block
+         stack that round differently: relative L2 <= 2.5e-2 on the noise prediction (measured on MI355X: 1.58e-2; at a fifth of the depth each sits
+         9.4e-3 from the fp32 graph and 8.2e-3 from the other, leg B).
+      B. TRUTH-ANCHORED at the same token count and a fifth of the depth (4 double + 8 single blocks, the first ones of the same checkpoint): the same
+         statements in fp32 (`O.truth_precision`, exact attention in query chunks) are the truth, and err(HIP vs truth) <= 1.5 x err(bf16 oracle
+         through PyTorch vs truth).  (The fp32 evaluation of all 60 blocks at 119 056 tokens is ~4 minutes of fp32 GEMMs per run.)"""
+    from lightx2v_amd import hunyuan as hy, synth
+    from oracle import hunyuan_oracle as H
+    from oracle import wan_oracle as O
+
+    dims = synth.HUNYUAN_DIMS["hunyuan-13b"]
+    wl = synth.HUNYUAN_WORKLOADS["hunyuan13b_720px129f"]
+    ts = wl["target_shape"]
+    wd = synth.synth_hunyuan_weights(dims, seed=0, device="cuda", gen_device="cuda")  # what tools/hunyuan_bench.py builds
+    lat, text_states, mask, ts2 = synth.synth_hunyuan_inputs(dims, ts, valid_text=200)
+    inputs = {"text_encoder_output": {"text_encoder_1_text_states": text_states.cuda(), "text_encoder_1_attention_mask": mask.cuda(), "text_encoder_2_text_states": ts2.cuda()}}
+
+    def hip_forward(d):
+        cfg = hy.default_config(d, infer_steps=50)
+        model = hy.HunyuanModel(cfg, wd)
+        sch = hy.HunyuanScheduler(cfg)
+        sch.prepare(lat)
+        model.set_scheduler(sch)
+        sch.step_pre(1)
+        model.infer(inputs)
+        out = sch.noise_pred.float().cpu()
+        meta = (sch.timesteps[1].cpu(), sch.guidance.cpu(), tuple(int(x) for x in (ts[2], ts[3] // 2, ts[4] // 2)))
+        del model
+        torch.cuda.empty_cache()
+        return out, meta
+
+    def oracle_forward(d, dtype):
+        cos, sin = H.rope_tables(list(grid), dtype=dtype)
+        w = wd if dtype == torch.bfloat16 else {k: v.to(dtype) for k, v in wd.items() if not k.startswith(("double_blocks.", "single_blocks.")) or
+                                                   int(k.split(".")[1]) < (d["double_blocks"] if k.startswith("double") else d["single_blocks"])}
+        with torch.no_grad():
+            out = H.forward(w, d, lat.to(torch.bfloat16).to(dtype).cuda(), t, guidance, text_states.to(dtype).cuda(), mask.cuda(), ts2.to(dtype).cuda(), (cos.cuda(), sin.cuda()))
+        out = out.float().cpu()
+        del w
+        torch.cuda.empty_cache()
+        return out
+
+    got, (t, guidance, grid) = hip_forward(dims)
+    assert grid[0] * grid[1] * grid[2] == 118800 and torch.isfinite(got).all()
+    ref = oracle_forward(dims, torch.bfloat16)
+    e_full = rel_l2(got, ref)
+    d_r = dict(dims, double_blocks=4, single_blocks=8)
+    got_r, _ = hip_forward(d_r)
+    ref_r = oracle_forward(d_r, torch.bfloat16)
+    with O.truth_precision(torch.float32):
+        tru_r = oracle_forward(d_r, torch.float32)
+    e_hip, e_ref = rel_l2(got_r, tru_r), rel_l2(ref_r, tru_r)
+    record("Hunyuan-13B forward at 118800 + 256 tokens (config #5)", full_depth_hip_vs_oracle_bf16_on_gpu=e_full, depth12_err_hip_vs_fp32=e_hip, depth12_err_oracle_vs_fp32=e_ref,
+           depth12_hip_vs_oracle=rel_l2(got_r, ref_r))
+    assert got.shape == ref.shape and e_full <= 2.5e-2, f"60-block forward: {e_full:.3e} from the oracle's bf16 evaluation"
+    assert e_hip <= 1.5 * e_ref + 1e-4, f"12-block forward: {e_hip:.3e} from the fp32 graph, the oracle's bf16 evaluation {e_ref:.3e}"

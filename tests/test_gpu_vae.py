@@ -222,6 +222,28 @@ def test_vae_decode_split_fp16_is_fp32_grade():
         out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
         lib.vae_conv16(buf, strides, w16.cuda(), out, T, H, W, bias=b.cuda())
         _check(out, ref, f"split conv {(kt, kh, kw)} Cin={Cin} Cout={Cout}", atol=2e-5, rel=2e-6)
+    # SMALL activations, the common case behind RMS-norm + SiLU: for |x| < 0.25 the middle plane hi * 2^-12 is an fp16 SUBNORMAL.  If the
+    # matrix unit flushed subnormal inputs, the xh.wl term would vanish for those pixels and the result would fall back to ~11 bits; it must stay
+    # fp32-grade (same bound as above) with activations in [1e-3, 0.25] and weights of the usual 1/sqrt(fan-in) scale
+    T, H, W, Cin, Cout, kt, kh, kw = 2, 8, 16, 96, 64, 3, 3, 3
+    x = (torch.rand(T, H, W, Cin, generator=g) * (0.25 - 1e-3) + 1e-3) * (torch.randint(0, 2, (T, H, W, Cin), generator=g) * 2 - 1)
+    w = torch.randn(Cout, Cin, kt, kh, kw, generator=g) / (kt * kh * kw * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = F.pad(x.permute(3, 0, 1, 2), (1, 1, 1, 1, kt - 1, 0))
+    ref = F.conv3d(xin.unsqueeze(0).double(), w.double(), b.double())[0].permute(1, 2, 3, 0).float()
+    cp = (3 * Cin + 63) // 64 * 64
+    buf = torch.zeros(kt - 1 + T, H + 2, W + 2, cp, dtype=torch.float16, device="cuda")
+    strides = ((H + 2) * (W + 2) * cp, (W + 2) * cp, cp)
+    lib.vae_prep(x.cuda(), buf[kt - 1 :, 1:, 1:], strides[:2], split=True)
+    mid = buf[kt - 1 :, 1 : 1 + H, 1 : 1 + W, Cin : 2 * Cin].float().abs()
+    assert ((mid > 0) & (mid < 2.0 ** -14)).float().mean().item() > 0.95, "this case must put the middle plane into the fp16 subnormal range"
+    wcl = w.permute(0, 2, 3, 4, 1).contiguous()
+    whi = wcl.half()
+    w16 = torch.zeros(Cout, kt, kh, kw, cp, dtype=torch.float16)
+    w16[..., :Cin], w16[..., Cin : 2 * Cin], w16[..., 2 * Cin : 3 * Cin] = whi, ((wcl - whi.float()) * 4096).half(), whi
+    out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
+    lib.vae_conv16(buf, strides, w16.cuda(), out, T, H, W, bias=b.cuda())
+    _check(out, ref, "split conv, activations in the subnormal range of the middle plane", atol=2e-5, rel=2e-6)
     # large-magnitude activations (beyond the fp16 range: hi saturates at 65504, lo carries the rest) against tiny weights (1e-3
     # scale: every unscaled lo half would be a subnormal) — still fp32-grade relative to the result's scale
     T, H, W, Cin, Cout, kt, kh, kw = 1, 8, 16, 64, 32, 1, 3, 3
