@@ -154,10 +154,9 @@ def test_cfg_form_by_size_rule():
 
     assert form("wan1.3b_480px49f") == "streams"      # 80 query blocks x 12 heads = 960 workgroups
     assert form("wan1.3b_480px81f") == "streams"      # 128 x 12 = 1536
-    assert form("wan1.3b_720px81f") == "sequential"   # 296 x 12 = 3552
+    assert form("wan1.3b_720px81f") == "pair"         # 296 x 12 = 3552
     assert form("wan14b_480px81f") == "pair"          # 128 x 40 = 5120
     assert form("wan14b_720px81f") == "pair"          # 296 x 40 = 11 840
     assert form("wan1.3b_256x256x17f") == "streams"
-    assert cfg_form_by_size(256 * 170, 12) == "streams" and cfg_form_by_size(256 * 171, 12) == "sequential"  # 2040 / 2052 workgroups
-    assert cfg_form_by_size(256 * 341, 12) == "sequential" and cfg_form_by_size(256 * 342, 12) == "pair"     # 4092 / 4104
-    assert cfg_form_by_size(256 * 341 + 1, 12) == "pair"  # a ragged last block counts
+    assert cfg_form_by_size(256 * 170, 12) == "streams" and cfg_form_by_size(256 * 171, 12) == "pair"  # 2040 / 2052 workgroups: the one threshold
+    assert cfg_form_by_size(256 * 170 + 1, 12) == "pair"  # a ragged last block counts

@@ -5,9 +5,9 @@ import os
 import sys
 from collections import defaultdict
 
-root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+files = [f for root in sys.argv[1:] for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True))]
+for f in files:
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "?")
@@ -20,3 +20,6 @@ for kern, ctrs in acc.items():
     for c, vals in sorted(ctrs.items()):
         # one row per (dispatch, counter[, dimension]); sum dimensions per dispatch is not recoverable here -> report mean and n
         print(f"   {c:34s} mean={sum(vals) / len(vals):.6g}  n={len(vals)}")
+    if "TCC_EA0_RDREQ_sum" in ctrs and "TCC_EA0_RDREQ_LEVEL_sum" in ctrs:  # mean fabric-side read latency in L2 clocks (TCC_EA0_RDREQ_LEVEL's own description)
+        rd, lvl = sum(ctrs["TCC_EA0_RDREQ_sum"]) / len(ctrs["TCC_EA0_RDREQ_sum"]), sum(ctrs["TCC_EA0_RDREQ_LEVEL_sum"]) / len(ctrs["TCC_EA0_RDREQ_LEVEL_sum"])
+        print(f"   -> mean EA read latency = LEVEL / RDREQ = {lvl / max(rd, 1):.1f} L2 clocks")
