@@ -119,7 +119,9 @@ int x2v_headnorm_rope_blocked_bf16(void* q, void* k, int64_t ld, int heads_per_b
  * (transformer_infer.py:402,468,503) for callers that do not fuse it into the GEMM epilogue. */
 int x2v_gate_residual_bf16(void* x, int64_t ldx, const void* y, int64_t ldy, const void* gate, int64_t M, int D, void* stream);
 
-/* y = act(x) elementwise on [n] bf16: act 1 = gelu-tanh (transformer_infer.py:492), 3 = silu (pre_infer.py:74,76). */
+/* y = act(x) elementwise on [n] bf16: act 1 = gelu-tanh (transformer_infer.py:492), 3 = silu (pre_infer.py:74,76), X2V_ACT_GELU_ERF = the exact
+ * GELU of the i2v CLIP-feature MLP (pre_infer.py:106: gelu(approximate="none")). */
+#define X2V_ACT_GELU_ERF 4
 int x2v_activation_bf16(const void* x, void* y, int64_t n, int act, void* stream);
 
 /* y[M,N] = epi(x[M,K] . W[N,K]^T + bias[N])   — replaces MMWeight.apply = torch.addmm(bias, x, W.t())

@@ -570,20 +570,27 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(unsigned short* __re
 }
 
 template <int ACT>
+__device__ __forceinline__ float act_f(float x) {
+  if constexpr (ACT == X2V_EPI_GELU_TANH) return gelu_tanh_f(x);
+  else if constexpr (ACT == X2V_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));  // torch gelu(approximate="none") on a bf16 tensor: fp32 math
+  else return silu_f(x);
+}
+
+template <int ACT>
 __global__ __launch_bounds__(256) void activation_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int64_t n) {
   const int64_t nv = n / 8;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
     float v[8];
     unpack8(reinterpret_cast<const uint4*>(x)[i], v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ACT == X2V_EPI_GELU_TANH ? gelu_tanh_f(v[j]) : silu_f(v[j]);
+    for (int j = 0; j < 8; ++j) v[j] = act_f<ACT>(v[j]);
     reinterpret_cast<uint4*>(y)[i] = pack8(v);
   }
   // tail (n % 8) handled by the first block
   if (blockIdx.x == 0) {
     for (int64_t i = nv * 8 + threadIdx.x; i < n; i += blockDim.x) {
       float f = bf2f(x[i]);
-      y[i] = f2bf(ACT == X2V_EPI_GELU_TANH ? gelu_tanh_f(f) : silu_f(f));
+      y[i] = f2bf(act_f<ACT>(f));
     }
   }
 }
@@ -897,13 +904,15 @@ extern "C" __attribute__((visibility("default"))) int x2v_gate_residual_bf16(voi
 
 extern "C" __attribute__((visibility("default"))) int x2v_activation_bf16(const void* x, void* y, int64_t n, int act, void* stream) {
   X2V_REQUIRE(x && y, X2V_E_ARG, "activation: null pointer");
-  X2V_REQUIRE(act == X2V_EPI_GELU_TANH || act == X2V_EPI_SILU, X2V_E_ARG, "activation: unknown act %d", act);
+  X2V_REQUIRE(act == X2V_EPI_GELU_TANH || act == X2V_EPI_SILU || act == X2V_ACT_GELU_ERF, X2V_E_ARG, "activation: unknown act %d", act);
   X2V_REQUIRE(aligned16(x) && aligned16(y), X2V_E_ALIGN, "activation: pointers must be 16-byte aligned");
   if (n <= 0) return X2V_OK;
   const int64_t nv = n / 8;
   const unsigned grid = (unsigned)((nv + 255) / 256 < 8192 ? ((nv + 255) / 256 > 0 ? (nv + 255) / 256 : 1) : 8192);
   if (act == X2V_EPI_GELU_TANH)
     hipLaunchKernelGGL((activation_kernel<X2V_EPI_GELU_TANH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
+  else if (act == X2V_ACT_GELU_ERF)
+    hipLaunchKernelGGL((activation_kernel<X2V_ACT_GELU_ERF>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
   else
     hipLaunchKernelGGL((activation_kernel<X2V_EPI_SILU>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
   X2V_LAUNCH_CHECK("activation launch");

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X2V_LIB_PATH") or os.path.join(_HERE, "libx2v_hip.so")  # X2V_LIB_PATH: an alternative build of the same sources (tools/build_variant.sh, A/B runs)
 
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL, EPI_SILU = 0, 1, 2, 3
+ACT_GELU_ERF = 4  # x2v.h X2V_ACT_GELU_ERF (activation() only: exact GELU of the i2v CLIP-feature MLP)
 ROUND_FP32, ROUND_REF = 0, 1
 
 _c_void_p, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float

@@ -392,6 +392,11 @@ class PatchEmbedConv3dHip(MMWeightHip):
         if w.dim() == 5 and tuple(w.shape[2:]) != self.stride:
             raise lib.X2VError(f"hip_patch: kernel {tuple(w.shape[2:])} != stride {self.stride}: not a patch embedding")
         super().load(weight_dict)
+        # the GEMM kernels advance K in 64-element tiles: a patch of C*pt*ph*pw values that is not a multiple of 64 (i2v: 36 channels x 4 = 144) is
+        # zero-padded on both operands — the padding adds exact zeros to the fp32 sums, the result does not change
+        self._k = self.weight.shape[1]
+        if self._k % 64:
+            self.weight = torch.nn.functional.pad(self.weight, (0, 64 - self._k % 64)).contiguous()
 
     def apply_tokens(self, input_tensor):
         """[1, C, T, H, W] → token-major [S, D] (what the fused driver consumes)."""
@@ -399,8 +404,10 @@ class PatchEmbedConv3dHip(MMWeightHip):
         _, c, t, h, w = input_tensor.shape
         pt, ph, pw = self.stride
         x = input_tensor.reshape(c, t // pt, pt, h // ph, ph, w // pw, pw).permute(1, 3, 5, 0, 2, 4, 6)
-        x = x.reshape((t // pt) * (h // ph) * (w // pw), c * pt * ph * pw).contiguous()
-        return lib.gemm(x, self.weight, self.bias)
+        x = x.reshape((t // pt) * (h // ph) * (w // pw), c * pt * ph * pw)
+        if x.shape[1] != self.weight.shape[1]:
+            x = torch.nn.functional.pad(x, (0, self.weight.shape[1] - x.shape[1]))
+        return lib.gemm(x.contiguous(), self.weight, self.bias)
 
     def apply(self, input_tensor):
         _, _, t, h, w = input_tensor.shape

@@ -17,6 +17,7 @@ WAN_DIMS = {
     "wan-tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_len=32, text_dim=64),
     # 8 heads: the smallest model a group of 8 ranks can share (Ulysses needs heads % N == 0); plumbing runs of the N-rank code paths
     "wan-tiny-h8": dict(dim=1024, ffn_dim=2048, num_heads=8, num_layers=2, text_len=32, text_dim=64),
+    "wan-tiny-i2v": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_len=32, text_dim=64, clip_dim=64, task="i2v"),
 }
 
 # BASELINE.json workloads: latent target_shape (C, T, H, W) (reference: wan_runner.py:260-280)
@@ -83,6 +84,50 @@ def synth_wan_weights(dims, seed=0, device="cpu", dtype=torch.bfloat16, gen_devi
     lin("head.head", out_dim * 4, D, std=1.0 / math.sqrt(D))
     wd["head.modulation"] = _randn((1, 2, D), 0.1, gen, device, dtype)
     return wd
+
+
+I2V_CLIP_TOKENS = 257  # CLIP ViT-H/14 tokens the i2v cross-attention sees (wan/infer/transformer_infer.py:406-407 splits the context there)
+
+
+def synth_wan_i2v_weights(dims, seed=0, device="cpu", dtype=torch.bfloat16, gen_device="cpu"):
+    """The i2v checkpoint (wan/weights/pre_weights.py:42-58, transformer_weights.py:285-312): the t2v tensors with a 36-channel patch embedding
+    (16 noise + 4 mask + 16 conditioning-latent channels), the CLIP-feature MLP `img_emb.proj.{0,1,3,4}` and per block `cross_attn.{k_img,v_img,
+    norm_k_img}`.  The extra tensors come from a second generator so that the base stream stays what `synth_wan_weights` draws."""
+    wd = synth_wan_weights(dims, seed=seed, device=device, dtype=dtype, gen_device=gen_device, in_dim=36)
+    D, L, C = dims["dim"], dims["num_layers"], dims.get("clip_dim", 1280)
+    gen = torch.Generator(device=gen_device)
+    gen.manual_seed(seed + 7777)
+
+    def lin(name, n, k):
+        wd[f"{name}.weight"] = _randn((n, k), 1.0 / math.sqrt(k), gen, device, dtype)
+        wd[f"{name}.bias"] = _randn((n,), 0.02, gen, device, dtype)
+
+    def ln(name, n):
+        wd[f"{name}.weight"] = (1.0 + _randn((n,), 0.05, gen, device, torch.float32)).to(dtype)
+        wd[f"{name}.bias"] = _randn((n,), 0.02, gen, device, dtype)
+
+    ln("img_emb.proj.0", C)
+    lin("img_emb.proj.1", C, C)
+    lin("img_emb.proj.3", D, C)
+    ln("img_emb.proj.4", D)
+    for i in range(L):
+        p = f"blocks.{i}.cross_attn"
+        lin(f"{p}.k_img", D, D)
+        lin(f"{p}.v_img", D, D)
+        wd[f"{p}.norm_k_img.weight"] = (1.0 + _randn((D,), 0.05, gen, device, torch.float32)).to(dtype)
+    return wd
+
+
+def synth_i2v_inputs(dims, target_shape, seed=42, device="cpu"):
+    """The image-encoder outputs the i2v path consumes (wan_runner.py:240-256): `clip_encoder_out` [257, clip_dim] bf16 (CLIP stand-in) and
+    `vae_encode_out` [4 + 16, T, H, W] bf16 (first-frame mask + VAE latents of the conditioning video)."""
+    g = torch.Generator().manual_seed(seed + 3)
+    clip = torch.randn(I2V_CLIP_TOKENS, dims.get("clip_dim", 1280), generator=g).to(torch.bfloat16)
+    _, t, h, w = target_shape
+    msk = torch.zeros(4, t, h, w)
+    msk[:, 0] = 1.0  # the first latent frame is given
+    y = torch.cat([msk, torch.randn(16, t, h, w, generator=g)]).to(torch.bfloat16)
+    return {"clip_encoder_out": clip.to(device), "vae_encode_out": y.to(device)}
 
 
 def synth_inputs(dims, target_shape, seed=42, device="cpu"):

@@ -76,7 +76,7 @@ class WanSelfAttention(WeightModule):
 
 
 class WanCrossAttention(WeightModule):
-    """reference: wan/weights/transformer_weights.py:218-313 (t2v)."""
+    """reference: wan/weights/transformer_weights.py:218-313 (t2v and i2v)."""
 
     def __init__(self, block_index, task, mm_type, config, lazy_load=False, lazy_load_file=None):
         super().__init__()
@@ -89,6 +89,11 @@ class WanCrossAttention(WeightModule):
         self.add_module("cross_attn_norm_q", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_q.weight", lazy_load, lazy_load_file))
         self.add_module("cross_attn_norm_k", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_k.weight", lazy_load, lazy_load_file))
         self.add_module("cross_attn_1", ATTN_WEIGHT_REGISTER[config["cross_attn_1_type"]]())
+        if task == "i2v":  # transformer_weights.py:285-312: K / V projections and k-norm of the 257 CLIP tokens, a second attention operator
+            for proj in ("k_img", "v_img"):
+                self.add_module(f"cross_attn_{proj}", MM_WEIGHT_REGISTER[mm_type](f"{p}.{proj}.weight", f"{p}.{proj}.bias", lazy_load, lazy_load_file))
+            self.add_module("cross_attn_norm_k_img", RMS_WEIGHT_REGISTER["sgl-kernel"](f"{p}.norm_k_img.weight", lazy_load, lazy_load_file))
+            self.add_module("cross_attn_2", ATTN_WEIGHT_REGISTER[_cfg(config, "cross_attn_2_type", config["cross_attn_1_type"])]())
 
 
 class WanFFN(WeightModule):
@@ -128,7 +133,7 @@ class WanTransformerWeights(WeightModule):
 
 
 class WanPreWeights(WeightModule):
-    """reference: wan/weights/pre_weights.py:9-64 (t2v)."""
+    """reference: wan/weights/pre_weights.py:9-64 (t2v and i2v)."""
 
     def __init__(self, config):
         super().__init__()
@@ -136,6 +141,11 @@ class WanPreWeights(WeightModule):
         self.add_module("patch_embedding", CONV3D_WEIGHT_REGISTER["hip_patch"]("patch_embedding.weight", "patch_embedding.bias", stride=(1, 2, 2)))
         for name in ("text_embedding.0", "text_embedding.2", "time_embedding.0", "time_embedding.2", "time_projection.1"):
             self.add_module(name.replace(".", "_"), MM_WEIGHT_REGISTER["Default"](f"{name}.weight", f"{name}.bias"))
+        if config["task"] == "i2v":  # pre_weights.py:42-58: the CLIP-feature MLP img_emb = LayerNorm, Linear, GELU, Linear, LayerNorm
+            self.add_module("proj_0", LN_WEIGHT_REGISTER["Default"]("img_emb.proj.0.weight", "img_emb.proj.0.bias"))
+            self.add_module("proj_1", MM_WEIGHT_REGISTER["Default"]("img_emb.proj.1.weight", "img_emb.proj.1.bias"))
+            self.add_module("proj_3", MM_WEIGHT_REGISTER["Default"]("img_emb.proj.3.weight", "img_emb.proj.3.bias"))
+            self.add_module("proj_4", LN_WEIGHT_REGISTER["Default"]("img_emb.proj.4.weight", "img_emb.proj.4.bias"))
 
 
 class WanPostWeights(WeightModule):
@@ -165,7 +175,7 @@ def rope_cos_sin_table(head_dim, device):
 
 
 class WanPreInfer:
-    """reference: wan/infer/pre_infer.py:6-120 (t2v path)."""
+    """reference: wan/infer/pre_infer.py:6-120 (t2v and i2v)."""
 
     def __init__(self, config):
         d = config["dim"] // config["num_heads"]
@@ -195,6 +205,8 @@ class WanPreInfer:
         context = inputs["text_encoder_output"]["context" if positive else "context_null"]
         seq_len = sch.seq_len
 
+        if self.task == "i2v":  # pre_infer.py:44-55: noise latents + [first-frame mask | conditioning latents] along the channel axis (36 channels)
+            latents = torch.cat([latents, inputs["image_encoder_output"]["vae_encode_out"].to(latents.dtype)], dim=0)
         x = weights.patch_embedding.apply(latents.unsqueeze(0))  # [1, D, T, H/2, W/2] (pre_infer.py:57)
         grid_sizes = torch.tensor([list(x.shape[2:])], dtype=torch.long)
         x = x.flatten(2).transpose(1, 2).squeeze(0)  # :59 — a view chain back onto the GEMM's contiguous [S, D]
@@ -210,8 +222,34 @@ class WanPreInfer:
         embed0 = lib.activation(embed, lib.EPI_SILU)
         embed0 = weights.time_projection_1.apply(embed0).unflatten(1, (6, self.dim))
 
-        context = self._text_context(weights, context)
+        context = self.full_context(weights, inputs, positive)
         return embed, grid_sizes, (x, embed0.squeeze(0), seq_lens, self.freqs, context)
+
+    I2V_CLIP_TOKENS = 257  # transformer_infer.py:406-407
+
+    def full_context(self, weights, inputs, positive):
+        """The cross-attention context of one CFG branch: the text MLP output (t2v), with the CLIP-feature MLP output in front of it for i2v
+        (pre_infer.py:100-113).  Both parts are step-invariant; with `cache_cross_kv` the SAME tensor object is returned on every step, which is
+        what lets the block stack reuse its cross-attention K / V (text and image) across the denoise loop."""
+        text = self._text_context(weights, inputs["text_encoder_output"]["context" if positive else "context_null"])
+        if self.task != "i2v":
+            return text
+        clip = inputs["image_encoder_output"]["clip_encoder_out"]
+        key = (id(weights), id(clip), id(text))
+        sig = _weight_signature(weights.proj_1, weights.proj_3)
+        hit = self._text_cache.get(key) if self.cache_text_context else None
+        if hit is not None and hit[3] is weights and hit[4] == sig and hit[0][0] is clip and hit[0][1] is text and hit[1] == clip._version:
+            return hit[2]
+        c = lib.layernorm(clip.to(text.dtype), weights.proj_0.weight, weights.proj_0.bias, eps=weights.proj_0.eps)
+        c = lib.activation(weights.proj_1.apply(c), lib.ACT_GELU_ERF)  # Linear, exact GELU (:104-106)
+        c = weights.proj_3.apply(c)
+        c = lib.layernorm(c, weights.proj_4.weight, weights.proj_4.bias, eps=weights.proj_4.eps)
+        out = torch.cat([c, text], dim=0)  # [257 + text_len, D]: once per prompt, not per step
+        if self.cache_text_context:
+            if len(self._text_cache) >= 8:
+                self._text_cache.pop(next(iter(self._text_cache)))
+            self._text_cache[key] = ((clip, text), clip._version, out, weights, sig)
+        return out
 
     def _text_context(self, weights, context):
         """pre_infer.py:86-96: pad the T5 rows to text_len, Linear + GELU-tanh + Linear.  The prompt embeddings do not change during a
@@ -361,48 +399,63 @@ class WanTransformerInfer:
         n3, mmkw = _ln_then_mm_input(weights.cross_attn_q, x, weights.norm3.weight, weights.norm3.bias, eps=weights.norm3.eps)
         q = weights.cross_attn_q.apply(n3, **mmkw)
         lib.rmsnorm(q, weights.cross_attn_norm_q.weight, weights.cross_attn_norm_q.eps, out=q, round_mode=self.round_mode)
+        i2v = self.task == "i2v"  # :405-407,437-455: the first 257 context rows are CLIP tokens with their own K / V projections and a second attention
+
+        def attend(qr, ctx, out=None):
+            k, v, vt = self._cross_kv(weights, ctx, "text" if i2v else None)
+            kw = dict(variant=lib.ATTN_FAST, vt=vt) if vt is not None else {}
+            a = self._timed("cross", lambda: lib.attention(qr, k, v, self.num_heads, self.head_dim, out=out, **kw))
+            if i2v:
+                k, v, vt = self._cross_kv(weights, ctx, "img")
+                kw = dict(variant=lib.ATTN_FAST, vt=vt) if vt is not None else {}
+                a_img = self._timed("cross", lambda: lib.attention(qr, k, v, self.num_heads, self.head_dim, **kw))
+                lib.gate_residual_(a, a_img)  # attn_out.add_(img_attn_out) (:451), in the activation dtype
+            return a
+
         if self._pair is not None:
             S, Sp = self._pair
             attn = torch.empty_like(q)
-            for b, ctx in enumerate(context):  # (conditional, unconditional) text contexts; every row of a forward's slot is a query
-                k, v, vt = self._cross_kv(weights, ctx)
+            for b, ctx in enumerate(context):  # (conditional, unconditional) contexts; every row of a forward's slot is a query
                 rows = slice(b * Sp, (b + 1) * Sp)
-                self._timed("cross", lambda: lib.attention(q[rows], k, v, self.num_heads, self.head_dim, variant=lib.ATTN_FAST, vt=vt, out=attn[rows]))
+                attend(q[rows], ctx, out=attn[rows])
             return weights.cross_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=None)
-        k, v, vt = self._cross_kv(weights, context)
-        if vt is not None:
-            attn = self._timed("cross", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=lib.ATTN_FAST, vt=vt))
-        else:
-            attn = self._timed("cross", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim))
-        return weights.cross_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=None)
+        return weights.cross_attn_o.apply(attend(q, context), epilogue=lib.EPI_RESIDUAL, resid=x, gate=None)
 
-    def _cross_kv(self, weights, context):
-        """k = RMSNorm(W_k context), v = W_v context (transformer_infer.py:419-424).  The text context and the weights do not change
+    def _cross_kv(self, weights, context, part=None):
+        """k = RMSNorm(W_k context), v = W_v context (transformer_infer.py:419-424); i2v (`part` "text" / "img"): of the context rows behind / in
+        front of the 257 CLIP tokens, the image part through k_img / v_img / norm_k_img (:437-440) — cached under the same context object.  The text context and the weights do not change
         between denoise steps, so with config `cache_cross_kv` (default on) each block's pair is computed once per context
         tensor OBJECT (WanPreInfer hands the same object over on every step) and reused — the same values the reference recomputes
         every step (0.8 GB for Wan-14B with CFG).  An entry pins its context tensor and its weights object (their ids cannot be recycled)
         and checks the context's version counter and the (data_ptr, version) of the k / v / norm_k weight tensors; contexts other than
         the two most recent ones (cond / uncond) are evicted, so a caller that passes fresh tensors every step gets the reference
         behaviour without growth.  `WanModel._init_weights` clears the cache as well."""
-        if not self.cache_cross_kv:
-            k = weights.cross_attn_k.apply(context)
-            lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
-            v = weights.cross_attn_v.apply(context)
+        n_clip = WanPreInfer.I2V_CLIP_TOKENS
+        if part == "img":
+            op_k, op_v, op_n, rows = weights.cross_attn_k_img, weights.cross_attn_v_img, weights.cross_attn_norm_k_img, slice(0, n_clip)
+        else:
+            op_k, op_v, op_n, rows = weights.cross_attn_k, weights.cross_attn_v, weights.cross_attn_norm_k, (slice(n_clip, None) if part == "text" else slice(None))
+
+        def compute():
+            src = context[rows]
+            k = op_k.apply(src)
+            lib.rmsnorm(k, op_n.weight, op_n.eps, out=k, round_mode=self.round_mode)
+            v = op_v.apply(src)
+            # V^T for the ping-pong attention kernel (0.96 vs 1.20 ms per launch at 14B 720p on the 512-key context)
             return k, v, (lib.transpose_heads(v, self.num_heads) if (self.round_mode == lib.ROUND_FP32 and v.is_cuda) else None)
+
+        if not self.cache_cross_kv:
+            return compute()
         per_ctx = self._cross_kv_cache.get(id(context))
         if per_ctx is None or per_ctx["ctx"] is not context or per_ctx["version"] != context._version:
             while len(self._cross_kv_cache) >= 2:
                 self._cross_kv_cache.pop(next(iter(self._cross_kv_cache)))
             per_ctx = self._cross_kv_cache[id(context)] = {"ctx": context, "version": context._version, "kv": {}}
-        sig = _weight_signature(weights.cross_attn_k, weights.cross_attn_v, weights.cross_attn_norm_k)
-        hit = per_ctx["kv"].get(id(weights))
+        sig = _weight_signature(op_k, op_v, op_n)
+        hit = per_ctx["kv"].get((id(weights), part))
         if hit is None or hit[2] is not weights or hit[3] != sig:  # the entry pins its weights object; tensors re-loaded / edited in place: recompute
-            k = weights.cross_attn_k.apply(context)
-            lib.rmsnorm(k, weights.cross_attn_norm_k.weight, weights.cross_attn_norm_k.eps, out=k, round_mode=self.round_mode)
-            v = weights.cross_attn_v.apply(context)
-            # cached with the pair: V^T for the ping-pong attention kernel (0.96 vs 1.20 ms per launch at 14B 720p on the 512-key context)
-            vt = lib.transpose_heads(v, self.num_heads) if (self.round_mode == lib.ROUND_FP32 and v.is_cuda) else None
-            hit = per_ctx["kv"][id(weights)] = (k, v, weights, sig, vt)
+            k, v, vt = compute()
+            hit = per_ctx["kv"][(id(weights), part)] = (k, v, weights, sig, vt)
         return hit[0], hit[1], hit[4]
 
     def clear_cross_kv(self):
@@ -581,7 +634,7 @@ class CfgBranchStreams:
         sa, sb = self._setup()
         cur = torch.cuda.current_stream()
         embed, grid_sizes, (x, embed0, seq_lens, freqs, ctx_c) = m.pre_infer.infer(m.pre_weight, inputs, positive=True)
-        ctx_u = m.pre_infer._text_context(m.pre_weight, inputs["text_encoder_output"]["context_null"])
+        ctx_u = m.pre_infer.full_context(m.pre_weight, inputs, False)
         xa = self._shard(x)
         xb = xa.clone()
         sa.wait_stream(cur)
@@ -704,7 +757,7 @@ class WanModel:
         S = x.shape[0]
         if int(seq_lens[0]) != S:
             return None  # token buffer padded beyond the grid: the separate forwards handle it
-        ctx_u = self.pre_infer._text_context(self.pre_weight, inputs["text_encoder_output"]["context_null"])
+        ctx_u = self.pre_infer.full_context(self.pre_weight, inputs, False)
         Sp = (S + 63) // 64 * 64  # a forward's slot: whole 64-token blocks of V^T
         X = torch.empty((2 * Sp, x.shape[1]), dtype=x.dtype, device=x.device)
         for b in range(2):

@@ -174,6 +174,51 @@ def gen_model(name="wan-tiny", workload="wan-tiny", steps=4):
     print(f"{name}_model.safetensors:", len(out), "tensors")
 
 
+def gen_model_i2v(name="wan-tiny-i2v", steps=3):
+    """The i2v branch of the same hot path (pre_infer.py:44-55,100-113; transformer_infer.py:405-455 — the only configuration the reference publishes
+    numbers for): the reference's own pre / transformer / post infer objects built with task = "i2v" (36-channel patch embedding, img_emb MLP, per-block
+    k_img / v_img / norm_k_img and the second cross-attention), pre-infer outputs, block 0 phase by phase, and a 3-step CFG denoise loop."""
+    ref_import.patch_and_import()
+    from lightx2v.models.schedulers.wan.scheduler import WanScheduler
+
+    dims = synth.WAN_DIMS[name]
+    ts, frames = (16, 3, 8, 8), 9
+    wd = synth.synth_wan_i2v_weights(dims, seed=0)
+    latents, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    image = synth.synth_i2v_inputs(dims, ts)
+    cfg = ref_import.make_config(dims, task="i2v", in_dim=36, target_shape=ts, target_video_length=frames, infer_steps=steps, lat_h=ts[2], lat_w=ts[3])
+    R = ref_import.build_reference_wan(cfg, wd)
+    sch = WanScheduler(cfg)
+    sch.device = torch.device("cpu")
+    sch.prepare(image_encoder_output=image)
+    sch.latents = latents.clone()
+    for m in ("pre", "post"):
+        R[m].set_scheduler(sch)
+    inputs = {"text_encoder_output": {"context": ctx, "context_null": ctx_null}, "image_encoder_output": image}
+    out = dict(latents0=latents, weights_checksum=weights_checksum(wd), clip_encoder_out=image["clip_encoder_out"], vae_encode_out=image["vae_encode_out"])
+    sch.step_pre(0)
+    embed, grid_sizes, (x, embed0, seq_lens, freqs, context) = R["pre"].infer(R["pre_w"], inputs, positive=True)
+    out.update(pre_x=x.clone(), pre_embed0=embed0.clone(), pre_context=context.clone())
+    tr, blk = R["tr"], R["tr_w"].blocks[0]
+    mods = tr.infer_modulation(blk.compute_phases[0], embed0)
+    xb = x.clone()
+    y_out = tr.infer_self_attn(blk.compute_phases[1], grid_sizes, xb, seq_lens, freqs, mods[0], mods[1])
+    xb, attn_out = tr.infer_cross_attn(blk.compute_phases[2], xb, context, y_out, mods[2])
+    out.update(b0_x_after_self=xb.clone(), b0_cross_attn_out=attn_out.clone())
+    y = tr.infer_ffn(blk.compute_phases[3], xb, attn_out, mods[3], mods[4])
+    xb = tr.post_process(xb, y, mods[5])
+    out.update(b0_x_out=xb.clone())
+    for i in range(steps):
+        sch.step_pre(i)
+        cond = _ref_model_infer(R, sch, cfg, inputs)
+        if i == 0:
+            out.update(step0_cond=cond.clone(), step0_noise_pred=sch.noise_pred.clone())
+        sch.step_post()
+        out[f"latents_after_step{i}"] = sch.latents.clone()
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(GOLDEN, f"{name}_model.safetensors"))
+    print(f"{name}_model.safetensors:", len(out), "tensors")
+
+
 def gen_scheduler_only():
     """Scheduler known-answer fixture at the real step counts (50 steps shift 8; 4 steps shift 8) with a
     synthetic, deterministic `noise_pred` (so it pins UniPC without needing the DiT)."""
@@ -605,6 +650,8 @@ if __name__ == "__main__":
         gen_ops()
     if "model" in which:
         gen_model()
+    if "model_i2v" in which or "model" in which:
+        gen_model_i2v()
     if "sched" in which:
         gen_scheduler_only()
     if "vae" in which:

@@ -374,3 +374,66 @@ def test_cfg_pair_pass_is_bit_identical_to_separate_forwards(fp8):
         assert torch.equal(outs[True][1], outs[False][1]), "latents after 3 steps differ"
         assert torch.equal(outs["streams"][0], outs[False][0]) and torch.equal(outs["streams"][1], outs[False][1]), "two-stream CFG branches changed the result"
         assert model._cfg_interleave._streams is not None, "the two-stream path was not taken"
+
+
+@pytest.mark.parametrize("ref_rounding", [True, False])
+def test_i2v_branch_vs_reference_fixture(ref_rounding):
+    """The i2v branch (pre_infer.py:44-55,100-113; transformer_infer.py:405-455 — the configuration the reference publishes its numbers for) on the HIP
+    path against the fixture the reference's own i2v objects produced (tests/golden/wan-tiny-i2v_model.safetensors, oracle/gen_golden.py::gen_model_i2v):
+    pre-infer (36-channel patch embedding = a K = 144 GEMM zero-padded to 192, the CLIP-feature MLP with its exact GELU in front of the text context),
+    block 0 from the reference's inputs (second cross-attention over the 257 image tokens, added in bf16), the conditional forward and the 3-step CFG
+    loop; then the three CFG forms (pair pass / two streams / sequential) must stay bit-identical with the image K / V caches in play."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from lightx2v_amd import scheduler, synth, wan
+    from lightx2v_amd.scheduler import run_denoise_loop
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wan-tiny-i2v_model.safetensors"))
+    dims = synth.WAN_DIMS["wan-tiny-i2v"]
+    ts, frames = (16, 3, 8, 8), 9
+    wd = _to_dev(synth.synth_wan_i2v_weights(dims, seed=0))
+    lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
+    image = {k: v.cuda() for k, v in synth.synth_i2v_inputs(dims, ts).items()}
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}, "image_encoder_output": image}
+
+    def build(**kw):
+        cfg = wan.default_config(dims, task="i2v", in_dim=36, cross_attn_2_type="hip_flash", target_shape=ts, target_video_length=frames, infer_steps=3,
+                                 hip_ref_rounding=ref_rounding, **kw)
+        model = wan.WanModel(cfg, wd)
+        sch = scheduler.WanScheduler(cfg, device="cuda")
+        sch.prepare(latents=lat)
+        model.set_scheduler(sch)
+        return model, sch
+
+    model, sch = build()
+    sch.step_pre(0)
+    embed, grid_sizes, (x, embed0, seq_lens, freqs, context) = model.pre_infer.infer(model.pre_weight, inputs, positive=True)
+    assert context.shape[0] == 257 + dims["text_len"]
+    assert_rel(x, g["pre_x"], 1e-2, "i2v patch embedding (36 channels)")
+    assert_rel(context[:257], g["pre_context"][:257], 1e-2, "CLIP-feature MLP")
+    assert_rel(context[257:], g["pre_context"][257:], 1e-2, "text embedding")
+    assert model.pre_infer.infer(model.pre_weight, inputs, positive=True)[2][4] is context, "the context object must be reused across steps (cross K/V caches key on it)"
+    tr, blk = model.transformer_infer, model.transformer_weights.blocks[0]
+    xb, e0, ctx_ref = g["pre_x"].cuda().clone(), g["pre_embed0"].cuda(), g["pre_context"].cuda()
+    mods = tr.infer_modulation(blk.compute_phases[0], e0)
+    xb = tr.infer_self_attn(blk.compute_phases[1], grid_sizes, xb, seq_lens, freqs, mods[0], mods[1], mods[2])
+    assert_rel(xb, g["b0_x_after_self"], 1e-2, "x after self-attention")
+    xb = tr.infer_cross_attn(blk.compute_phases[2], xb, ctx_ref)
+    xb = tr.infer_ffn(blk.compute_phases[3], xb, mods[3], mods[4], mods[5])
+    assert_rel(xb, g["b0_x_out"], 1e-2, "i2v block output")
+    assert_rel(model._forward(inputs, True), g["step0_cond"], 2e-2, "i2v conditional forward")
+    outs = {}
+    for form, kw in (("pair", dict(cfg_pair=True)), ("streams", dict(cfg_pair=False, cfg_branch_streams=True)), ("sequential", dict(cfg_pair=False, cfg_branch_streams=False))):
+        if ref_rounding and form == "pair":
+            continue  # the pair pass needs the fp32-statistics mode
+        m, s = build(**kw)
+        errs = []
+        run_denoise_loop(m, s, inputs, step_callback=lambda i: errs.append(rel_l2(s.latents, g[f"latents_after_step{i}"])))
+        assert max(errs) <= 3e-2, (form, errs)
+        outs[form] = s.latents.clone()
+        record(f"i2v 3-step CFG loop ({form}, ref_rounding={ref_rounding})", worst_rel_l2_vs_reference_fixture=max(errs))
+    ref_form = outs["sequential"]
+    for form, o in outs.items():
+        assert torch.equal(o, ref_form), f"CFG form {form} changed the i2v result"
