@@ -31,6 +31,12 @@
 
 namespace x2v {
 
+#ifndef C_STORE_AUX
+#define C_STORE_AUX 0  // cache policy of the output stores (A/B builds: 2 = non-temporal)
+#endif
+#ifndef C_DMA_AUX_A
+#define C_DMA_AUX_A 0  // cache policy of the x-operand LDS-DMA (A/B builds)
+#endif
 constexpr int C_M = 256, C_N = 256;
 constexpr int C_OP_BYTES = 256 * 128;          // one operand tile of one stage
 constexpr int C_STAGE_BYTES = 2 * C_OP_BYTES;  // W tile | x tile
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                (CUR_).kw + (unsigned)(i_ >> 1) * w_j, 0, 0);                                                   \
     else                                                                                                                                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds((CUR_).ra, (c_lds_ptr_t)(smem + (STAGE_) * C_STAGE_BYTES + C_OP_BYTES + wid * 8192 + i_ * 1024), 16,              \
-                                               a_voff[i_ & 1], (CUR_).ka + (unsigned)(i_ >> 1) * a_j, 0, 0);                                   \
+                                               a_voff[i_ & 1], (CUR_).ka + (unsigned)(i_ >> 1) * a_j, 0, C_DMA_AUX_A);                         \
   }
 
   // ---- fragment addresses (16x16x32: row r16 of a 16-row block, 16-byte chunk ks*4 + g16), block offsets travel as immediates
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef X2V_C_PROBE_NOSTORE  // timing probe (results invalid): what the epilogue's stores cost
     if (yv4.x == 0x12345678u && yv4.y == 0x9abcdef0u)
 #endif
-    __builtin_amdgcn_raw_buffer_store_b128(yv4, r_y, row_voff(16 * xb + 4 * i), s_col + (unsigned)(16 * xb + 4 * i) * y_row, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(yv4, r_y, row_voff(16 * xb + 4 * i), s_col + (unsigned)(16 * xb + 4 * i) * y_row, C_STORE_AUX);
   };
   auto epilogue = [&]() {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' results before the accumulator reads below
