@@ -1,6 +1,6 @@
 // y[M,N] = epi(x[M,K] . W[N,K]^T + bias), bf16 — gemm256s.hip's single-stream 256x256 kernel as a CONTINUOUS pipeline over output tiles.
 // Same contract, operand layouts, epilogues, rounding points, MFMA and k order as gemm.hip / gemm256.hip / gemm256s.hip: bit-equal results
-// (asserted in tests/test_gpu_ops.py against the one-tile-per-workgroup kernel).
+// (asserted in tests/test_gpu_bench_shapes.py::test_gemm_continuous_pipeline_equals_one_tile_per_workgroup against the one-tile-per-workgroup kernel).
 //
 // Bound: MFMA (bf16 dense peak ~2.5 PFLOP/s; at this board's 1400 W limit a bare 16x16x32 MFMA loop with GEMM-like LDS traffic sustains
 // ~1.8 PFLOP/s, tools/probes/mfma_power_probe.hip).  Algorithmic work 2*M*N*K FLOP per launch.
@@ -18,6 +18,9 @@
 //   * the per-column epilogue operands (bias, gate) and the first residual chunks are requested inside the LAST K tile's slot stream (one buffer
 //     load in an otherwise empty slot), the following residual chunks one x block ahead of their use;
 //   * the first k-step of an output tile issues its 64 MFMAs with C = 0 (inline constant) instead of 256 v_accvgpr_write.
+// Measured (profiles/r04_gemm_continuous_ab.txt): +5..12 % at K = 1536 (a 25 us tile), -0.3..+1.8 % at K = 5120 / 13824, where the board's power cap and
+// not the per-tile overhead sets the rate.  The first form of the epilogue — 8-byte stores straight from the accumulator layout, four partial writes per
+// 128-byte line — was 5 % (K = 5120) to 13 % (K = 1536) slower than not storing at all; hence the transposition strip.
 // Slot plan of a K tile: gemm256s.hip's (constants below), LDS images and swizzle: gemm256s.hip's.  Needs an even number of K tiles >= 4 (every
 // output tile then starts in LDS stage 0) and N a multiple of 256; other shapes, the V^T output mode and y blocks that are not multiples of a
 // wave's 128 columns stay on gemm256s.
