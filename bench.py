@@ -494,8 +494,8 @@ def main():
     traffic, traffic_note = None, "no PMC summary for this shape under profiles/"
     # PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py: this very command under --pmc FETCH_SIZE / WRITE_SIZE, the rows of this
     # kernel instantiation averaged per launch); the summary they wrote for THIS launch form is reported, never one of another form
-    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_attn_traffic.json")
-    if world == 1 and os.path.exists(pmc_path):
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_attn_traffic.json") for r in (4, 3)) if os.path.exists(q)), None)  # the newest round's passes
+    if world == 1 and pmc_path is not None:
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         if pmc.get("tokens") == S and pmc.get("heads") == heads_local and abs(pmc.get("forwards_per_launch", 0) - forwards_per_launch) < 1e-6:
