@@ -64,3 +64,27 @@ def test_multi_gpu_launch_contract(script):
         assert p.returncode != 0 and ("rank 0 needs cuda:0" in text or "rank 1 needs cuda:1" in text)
     p = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert p.returncode != 0 and "--nproc-per-node must equal --gpus" in (p.stderr + p.stdout)
+
+
+def test_watchdog_exits_124_when_no_progress_arrives(tmp_path):
+    """bench.Watchdog (first-contact insurance of the multi-GPU run): no tick for `limit` seconds -> the stage and every thread's stack on stderr, exit
+    code 124; regular ticks keep the process alive.  Run in a child process (the watchdog ends its process with os._exit)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import importlib.util, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('bench_module', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "w = m.Watchdog(1, 3)\n"
+        "for _ in range(4):\n"
+        "    time.sleep(0.5); w.tick('alive')\n"
+        "print('TICKED', flush=True)\n"
+        "w.tick('stuck in the exchange')\n"
+        "time.sleep(30)\n"
+        "print('NOT REACHED')\n"
+    )
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert p.returncode == 124, (p.returncode, p.stderr[-500:])
+    assert "TICKED" in p.stdout and "NOT REACHED" not in p.stdout
+    assert "rank 3 made no progress" in p.stderr and "stuck in the exchange" in p.stderr
