@@ -331,6 +331,49 @@ def test_wan14b_block_720p_pair_pass_vs_oracle_rows():
         assert e_hip <= 1.5 * e_ref + 1e-4, f"{name}: err vs fp32 truth {e_hip:.3e} > 1.5 x the bf16 oracle's {e_ref:.3e}"
 
 
+def test_wan14b_i2v_block_720p_vs_oracle_rows():
+    """The i2v block at the size the reference publishes its numbers for (Wan2.1-I2V-14B 720p: 75 600 tokens, 40 heads, 257 CLIP + 512 text context rows)
+    — `infer_block` with the second cross-attention over the image tokens and the cached image K / V — vs `O.wan_block_rows` on sampled rows, with the fp32
+    evaluation as truth (err(HIP) <= 1.5 x err(bf16 oracle)).  Block-boundary inputs come from the oracle's i2v pre-infer (36-channel patch embedding,
+    CLIP-feature MLP); the HIP pre-infer at this size is checked against them too."""
+    from lightx2v_amd import scheduler, synth, wan
+    from oracle import wan_oracle as O
+
+    dims = dict(synth.WAN_DIMS["wan2.1-14b"], num_layers=1, task="i2v", clip_dim=1280)
+    wl = synth.WORKLOADS["wan14b_720px81f"]
+    ts = wl["target_shape"]
+    S = synth.seq_len_of(ts)
+    wd = synth.synth_wan_i2v_weights(dims, seed=33)
+    lat, ctx, _ = synth.synth_inputs(dims, ts)
+    image = synth.synth_i2v_inputs(dims, ts)
+    t = torch.tensor(640)
+    embed_o, grid, x_o, embed0_o, _, context_o = O.wan_pre_infer(wd, dims, lat.to(torch.bfloat16), t, ctx, image=image)
+    assert context_o.shape[0] == 257 + 512 and x_o.shape[0] == S
+    freqs = O.rope_freqs_table(128)
+    rows = sample_rows(S, 96, seed=15)
+    ref = O.wan_block_rows(wd, 0, dims, grid, x_o, embed0_o, freqs, context_o, rows)
+    with O.truth_precision(torch.float32):
+        tru = O.wan_block_rows(O.upcast(wd), 0, dims, grid, x_o.float(), embed0_o.float(), freqs, context_o.float(), rows)
+    cfg = wan.default_config(dims, task="i2v", in_dim=36, cross_attn_2_type="hip_flash", target_shape=ts, target_video_length=wl["frames"], infer_steps=4, enable_cfg=False)
+    model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
+    sch = scheduler.WanScheduler(cfg, device="cuda")
+    sch.prepare(latents=lat)
+    sch.timesteps[1] = 640
+    model.set_scheduler(sch)
+    sch.step_pre(1)
+    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": []}, "image_encoder_output": {k: v.cuda() for k, v in image.items()}}
+    embed, grid_sizes, (x, embed0, seq_lens, rope, context) = model.pre_infer.infer(model.pre_weight, inputs, positive=True)
+    assert rel_l2(x, x_o) <= 1e-2 and rel_l2(context[:257], context_o[:257]) <= 1e-2 and rel_l2(context[257:], context_o[257:]) <= 1e-2
+    tr = model.transformer_infer
+    out = tr.infer_block(model.transformer_weights.blocks[0], grid_sizes, embed_o.cuda(), x_o.cuda().clone(), embed0_o.cuda(), torch.tensor([S]), rope, context_o.cuda())
+    assert torch.isfinite(out.float()).all()
+    got = out[rows.cuda()]
+    e, e_hip, e_ref = rel_l2(got, ref), rel_l2(got, tru), rel_l2(ref, tru)
+    record("Wan-14B i2v block S=75600", rows=len(rows), rel_l2_vs_oracle=e, err_hip_vs_fp32=e_hip, err_oracle_vs_fp32=e_ref)
+    assert e <= 1e-2, f"i2v block: relative L2 vs oracle {e:.3e}"
+    assert e_hip <= 1.5 * e_ref + 1e-4, f"i2v block: err vs fp32 truth {e_hip:.3e} > 1.5 x the bf16 oracle's {e_ref:.3e}"
+
+
 # ------------------------------------------------------------------------------------------------ HunyuanVideo blocks at config #5's size
 @pytest.mark.parametrize("kind", ["double", "single"])
 def test_hunyuan13b_block_720p_129f_vs_oracle_rows(kind):

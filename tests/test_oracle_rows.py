@@ -36,6 +36,24 @@ def test_block_rows_equals_block():
     assert rel_l2(pair[1], O.wan_block(wd, 0, dims, grid, x.clone(), embed0, freqs, ctx2)[rows]) <= 5e-3
 
 
+def test_block_rows_equals_block_i2v():
+    """Same for the i2v block (second cross-attention over the 257 CLIP tokens, transformer_infer.py:405-455)."""
+    dims = dict(synth.WAN_DIMS["wan-tiny-i2v"], num_layers=1)
+    ts = (16, 3, 8, 8)
+    wd = synth.synth_wan_i2v_weights(dims, seed=3)
+    lat, ctx, _ = synth.synth_inputs(dims, ts)
+    image = synth.synth_i2v_inputs(dims, ts)
+    embed, grid, x, embed0, s, context = O.wan_pre_infer(wd, dims, lat.to(torch.bfloat16), torch.tensor(600), ctx, image=image)
+    freqs = O.rope_freqs_table(128)
+    full = O.wan_block(wd, 0, dims, grid, x.clone(), embed0, freqs, context)
+    S = x.shape[0]
+    rows = torch.tensor([0, 1, 31, 32, S // 2, S - 2, S - 1, 7])
+    got = O.wan_block_rows(wd, 0, dims, grid, x, embed0, freqs, context, rows)
+    assert rel_l2(got, full[rows]) <= 5e-3
+    t2v = O.wan_block_rows(wd, 0, dict(dims, task="t2v"), grid, x, embed0, freqs, context[O.I2V_CLIP_TOKENS :], rows)
+    assert rel_l2(got, t2v) > 1e-3, "the image branch must contribute"
+
+
 def test_attention_rows():
     gen = torch.Generator().manual_seed(0)
     q, k, v = (torch.randn(300, 3, 128, generator=gen).to(torch.bfloat16) for _ in range(3))
