@@ -368,7 +368,12 @@ class HunyuanTransformerInferTeaCaching(HunyuanTransformerInfer):
         pair = torch.stack([(modulated - prev).abs().float().sum(), prev.abs().float().sum()]).double()
         if dist.get_backend(group) != "nccl":
             pair = pair.cpu()
-        dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+
+        def reduce():
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+            return pair
+
+        pair = pa.on_comm(reduce, pair) if hasattr(pa, "on_comm") else reduce()  # like every collective of the driver: on the one communication stream
         return (pair[0] / pair[1]).item()
 
     def infer(self, weights, img, txt, vec, cu_seqlens_qkv, max_seqlen_qkv, freqs_cis, token_replace_vec=None, frist_frame_token_num=None):
