@@ -3,7 +3,8 @@ collectives cannot be RCCL; the process group is gloo and the two collective ent
 wrapped (here, in the test only) to stage device tensors through host memory.  Everything else — the HIP
 kernels, the sharded RoPE offsets, head splitting, padding, stream joins — is the product path.
 Checks: the Ulysses-sharded Wan CFG step against the CPU ORACLE's noise prediction for the same weights and inputs (wan/model.py:197-226
-restated; tolerance of tests/test_gpu_model.py's CFG step), and — a tighter second leg, not a substitute — against the single-GPU HIP forward."""
+restated; tolerance of tests/test_gpu_model.py's CFG step), the conditional forward alone against the oracle's forward at the model-level 2e-2 (the
+tight oracle leg: no CFG amplification), and — a further leg, not a substitute — against the single-GPU HIP forward."""
 import os
 import sys
 
@@ -46,7 +47,7 @@ def main():
     wd = synth.synth_wan_weights(dims, seed=3)
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
-    outs = {}
+    outs, conds = {}, {}
     for mode in ("single", "ulysses", "ulysses-sequential"):
         cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=None if mode == "single" else "ulysses",
                                  cfg_branch_streams=(mode == "ulysses"))
@@ -55,6 +56,8 @@ def main():
         sch.prepare(latents=lat)
         model.set_scheduler(sch)
         sch.step_pre(0)
+        if mode != "ulysses-sequential":
+            conds[mode] = model._forward(inputs, True).float().cpu()  # one branch, no CFG amplification: the TIGHT oracle leg below
         model.infer(inputs)
         outs[mode] = sch.noise_pred.float().cpu()
         if mode.startswith("ulysses"):
@@ -72,6 +75,12 @@ def main():
     for mode in ("single", "ulysses"):
         e = ((outs[mode] - ref).norm() / ref.norm()).item()
         assert e <= 5e-2, f"rank {r}: {mode} vs oracle relative L2 {e:.3e}"  # guide scale 6 amplifies the per-branch 1e-2 (as in smoke())
+    # the tight oracle leg: the conditional forward alone — sharded over the ranks and on one GPU — against the oracle's forward
+    # at the model-level forward tolerance (2e-2), and the sharded one no further from the oracle than the single-GPU one (x 1.25)
+    ref_c = O.wan_forward(wd, dims, lat.to(torch.bfloat16), sch.timesteps[0].cpu(), ctx)
+    ec = {m: ((conds[m] - ref_c).norm() / ref_c.norm()).item() for m in ("single", "ulysses")}
+    assert ec["ulysses"] <= 2e-2 and ec["single"] <= 2e-2, f"rank {r}: conditional forward vs oracle {ec}"
+    assert ec["ulysses"] <= 1.25 * ec["single"] + 1e-3, f"rank {r}: sharded conditional forward further from the oracle than the single-GPU one {ec}"
     a, b = outs["single"], outs["ulysses"]
     rel = ((a - b).norm() / a.norm()).item()
     # same kernels on re-partitioned rows: the GEMM/attention tiles see different row groupings, not different math
