@@ -501,6 +501,8 @@ def main():
         if pmc.get("tokens") == S and pmc.get("heads") == heads_local and abs(pmc.get("forwards_per_launch", 0) - forwards_per_launch) < 1e-6:
             traffic = pmc["hbm_bytes_per_launch"]
             traffic_note = pmc["note"]
+            if "true, true" in str(pmc.get("kernel", "")) and not wan.SELF_ATTN_STAGGER:
+                traffic_note += "  (Counters taken on the staggered-walk instantiation of this launch form; the walk's starting tile changes when a tile is fetched, not what is fetched.)"
     model_label = {"wan2.1-14b": "Wan2.1-14B", "wan2.1-1.3b": "Wan2.1-1.3B"}.get(wl["model"], wl["model"])
     res_label = {"wan14b_720px81f": "720p 81f", "wan1.3b_480px49f": "480p 49f", "wan1.3b_256x256x17f": "256x256 17f"}.get(args.workload, args.workload)
     fast_attn = not args.ref_rounding
@@ -542,7 +544,8 @@ def main():
             "step_frac_of_bf16_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
         },
         "roofline": {
-            "kernel": ("x2v::attn_fwd_v9_kernel<8, 8, true, true> (ping-pong on 16x16x32 MFMA, q prescaled, staggered key walk; self-attention launches"
+            "kernel": ((f"x2v::attn_fwd_v9_kernel<8, 8, true, {'true' if wan.SELF_ATTN_STAGGER else 'false'}> (ping-pong on 16x16x32 MFMA, q prescaled, "
+                        f"{'staggered key walk' if wan.SELF_ATTN_STAGGER else 'key walk from tile 0'}; self-attention launches")
                        + ("; one launch = both CFG forwards of a layer)" if abs(forwards_per_launch - 2.0) < 1e-6 else ")") if fast_attn
                        else "x2v::attn_fwd_pipe_kernel<8, 8> (reference-rounding mode; self-attention launches)"),
             "bound": "mfma",

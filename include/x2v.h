@@ -189,7 +189,8 @@ int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt,
  * self-attention (transformer_infer.py:369-379): V^T is staged by LDS-DMA and read as plain 16-byte fragments, the softmax scale * log2(e)
  * lives in q.  flags: X2V_ATTN_VT_PRESCALED — q already carries scale*log2(e) (x2v_rmsnorm_rope_scaled_bf16 / x2v_headnorm_rope_bf16 folded it
  * into q's one rounding; without it the kernel multiplies and re-rounds q itself); X2V_ATTN_VT_STAGGER — query block b starts its walk over the
- * key tiles (b mod 8) tiles in (the online softmax does not care where the walk starts; the L2 does: +1.3 % at Wan-14B 720p).  The result of a
+ * key tiles (b mod 8) tiles in (the online softmax does not care where the walk starts; the L2 does: +1.3 % at Wan-14B 720p in 2-step runs, but
+ * -0.9 % at sustained load, profiles/r04_call12_*: the fused drivers stopped setting it in round 4).  The result of a
  * query row then depends on which 256-row block of the launch it sits in (another fp32 summation order, same tolerance): callers that compare
  * bits across differently partitioned launches (the Ulysses driver) leave it off. */
 #define X2V_ATTN_VT_PRESCALED 1

@@ -220,8 +220,12 @@ class HunyuanTransformerInfer:
         if self.parallel_attention is not None:  # Ulysses (reference hook: transformer_infer.py:130-144,358-369)
             n_img, n_valid, n_txt = self._sp_lens
             return self.parallel_attention(q, k, v, n_img, (n_valid, n_txt), self.heads_num, out, variant=variant)
-        for a, b in self._segs:  # single GPU: staggered key walk (x2v.h X2V_ATTN_VT_STAGGER)
-            lib.attention(q[a:b], k[a:b], v[a:b], self.heads_num, 128, out=out[a:b], variant=variant | (lib.ATTN_STAGGER if variant else 0))
+        # single GPU: the key walk starts at tile 0 (round 4: the staggered walk, x2v.h X2V_ATTN_VT_STAGGER, measured slower at sustained load — Wan-14B
+        # -0.9 % A-B-A-B, this model 8821 vs 8889 ms per step; wan.SELF_ATTN_STAGGER is the one switch for both drivers)
+        from .wan import SELF_ATTN_STAGGER
+
+        for a, b in self._segs:
+            lib.attention(q[a:b], k[a:b], v[a:b], self.heads_num, 128, out=out[a:b], variant=variant | (lib.ATTN_STAGGER if (variant and SELF_ATTN_STAGGER) else 0))
 
     def infer_double_block(self, weights, x, n_img, vec_silu, freqs_cis, ws):
         """transformer_infer.py:81-310 on the joint buffer x = [img ; txt]."""

@@ -190,7 +190,7 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
 
 
 ATTN_Q_PRESCALED = 0x100
-ATTN_STAGGER = 0x200  # x2v.h X2V_ATTN_VT_STAGGER: query block b starts its key walk (b mod 8) tiles in (single-GPU self-attention of the fused drivers)
+ATTN_STAGGER = 0x200  # x2v.h X2V_ATTN_VT_STAGGER: query block b starts its key walk (b mod 8) tiles in (an opt-in; wan.SELF_ATTN_STAGGER decides for the Wan drivers)
 ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
 #                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128

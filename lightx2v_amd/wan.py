@@ -278,6 +278,14 @@ class WanPreInfer:
         self._text_cache.clear()
 
 
+# Staggered key walk of the single-GPU self-attention launches (x2v.h X2V_ATTN_VT_STAGGER: query block b starts its walk (b mod 8) tiles in).  Round 3
+# measured it +1.3 % at Wan-14B 720p in 2-step runs and turned it on; at SUSTAINED load (6-8 timed steps, A-B-A-B on one box, round 4:
+# profiles/r04_call12_stagger_abab_sustained.txt) it is 0.9 % SLOWER — 9400.6 / 9417.4 ms per step without it, 9488.4 / 9485.7 with it (attention 164.3-164.7
+# vs 166.5 ms per paired launch) — so the fused Wan drivers no longer set it.  One switch for every single-GPU launch form (pair pass, two streams,
+# sequential), which keeps them bit-identical to each other; the flag stays in the C-ABI.
+SELF_ATTN_STAGGER = False
+
+
 class WanTransformerInfer:
     """reference: wan/infer/transformer_infer.py:12-508 (no-offload path).  `parallel_attention`
     (set by lightx2v_amd.ulysses.parallelize_wan) replaces the local self-attention exactly where the
@@ -367,7 +375,7 @@ class WanTransformerInfer:
             for b in range(2):  # token b*Sp + i of either forward sits at grid position i
                 rows = slice(b * Sp, b * Sp + S)
                 lib.rmsnorm_rope_(q[rows], k[rows], weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, **rope_args)
-            attn = lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True, stagger=True, timed=lambda fn: self._timed("self", fn))
+            attn = lib.attention_batched(q, k, vt, self.num_heads, 2, Sp, S, prescaled=True, stagger=SELF_ATTN_STAGGER, timed=lambda fn: self._timed("self", fn))
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)
         if pa is None and fast and not mmkw and hasattr(weights.self_attn_v, "apply_vt"):
             v, vt = None, weights.self_attn_v.apply_vt(n1, self.num_heads)  # V^T from the v projection's epilogue (the attention kernel's operand)
@@ -381,8 +389,8 @@ class WanTransformerInfer:
             # the ping-pong kernel reads V^T; transposed outside the timed launch so the hook times the attention kernel alone
             if vt is None and fast:
                 vt = lib.transpose_heads(v, self.num_heads)
-            # single GPU: the staggered key walk (x2v.h X2V_ATTN_VT_STAGGER); the pair pass sets it too, so the two stay bit-identical
-            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant | (lib.ATTN_STAGGER if fast else 0), vt=vt))
+            # single GPU: the same key-walk form as the pair pass (SELF_ATTN_STAGGER above), so the launch forms stay bit-identical
+            attn = self._timed("self", lambda: lib.attention(q, k, v, self.num_heads, self.head_dim, variant=variant | (lib.ATTN_STAGGER if (fast and SELF_ATTN_STAGGER) else 0), vt=vt))
         else:
             attn = pa(q=q, k=k, v=v if v_pending is None else v_pending, num_heads=self.num_heads, head_dim=self.head_dim, timer=self._timed, variant=variant)
         return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)

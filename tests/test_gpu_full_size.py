@@ -114,7 +114,7 @@ def test_attention_wan14b_720p_full_size(lib):
     _plant(q32, k, 0, S, PLANTS)
     q_pre = (q32 * lib.ATTN_PRESCALE).to(torch.bfloat16)
     vt = lib.transpose_heads(v, H)
-    var = lib.ATTN_FAST | lib.ATTN_Q_PRESCALED | lib.ATTN_STAGGER  # exactly what WanTransformerInfer.infer_self_attn passes on one GPU
+    var = lib.ATTN_FAST | lib.ATTN_Q_PRESCALED | lib.ATTN_STAGGER  # the staggered walk (what the drivers passed through round 3); the walk from tile 0 — what they pass now — is `out0` below
     out = lib.attention(q_pre, k, None, H, variant=var, vt=vt)
     assert torch.isfinite(out.float()).all()
     rows = sample_rows(S, 192, must=[r for r, _ in PLANTS])
@@ -155,6 +155,15 @@ def test_attention_cfg_pair_launch_full_size(lib):
     vt = lib.transpose_heads(v, H)
     out = lib.attention_batched(q_pre, k, vt, H, B, Sp, S, prescaled=True, stagger=True)
     assert torch.isfinite(out.float()).all(), "padding rows must be written"
+    # the form the fused driver launches since round 4 (wan.SELF_ATTN_STAGGER = False: the walk starts at tile 0 for every block): the same values up to
+    # the fp32 summation order, identical where the staggered walk starts at tile 0 too (query block 0 of either sequence)
+    out_ns = lib.attention_batched(q_pre, k, vt, H, B, Sp, S, prescaled=True, stagger=False)
+    assert rel_l2(out_ns, out) <= 5e-3 and torch.isfinite(out_ns.float()).all()
+    for b in range(B):
+        assert torch.equal(out_ns[b * Sp : b * Sp + 256], out[b * Sp : b * Sp + 256])
+        for r, j in PLANTS[b::2]:
+            assert (out_ns[b * Sp + r, :128].float() - v[b * Sp + j, :128].float()).abs().max().item() <= 2 ** -6, (b, r, j)
+    del out_ns
     for b in range(B):
         rows = sample_rows(S, 96, seed=10 + b, must=[r for r, _ in PLANTS[b::2]])
         sl = slice(b * Sp, b * Sp + S)
