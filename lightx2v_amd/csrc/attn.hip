@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   const int nt = (int)((Sk + AT_KV - 1) / AT_KV);
   // Key-tile walk.  With ROT (flag X2V_ATTN_VT_STAGGER) query block b starts (b mod 8) tiles in: co-resident workgroups then ask for a tile at
   // slightly different times (one takes the L2 miss, its followers hit) instead of all at the same instant: +1.3 % on the plain grid at Wan-14B
-  // 720p.  Only the first nt - 1 (full) tiles rotate — logical tile t < nt - 1 is physical tile (t + rot) mod (nt - 1) — and the physical last
+  // 720p in 2-step runs, -0.9 % at sustained load (round 4, A-B-A-B step times): opt-in, no driver sets it now.  Only the first nt - 1 (full) tiles rotate — logical tile t < nt - 1 is physical tile (t + rot) mod (nt - 1) — and the physical last
   // tile, the one that may hold fewer than 64 keys, stays last, so the key mask lives in the final softmax only (a mask test in every tile's
   // softmax costs 37 spilled SGPRs).  The walk is kept as running byte offsets of the next K / V^T tile to fetch.  rot depends on (qblk, nt)
   // only: a query row's result does not depend on how a launch is batched or mapped, but it does on which 256-row block of the launch it is in.
@@ -722,8 +722,8 @@ static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk
   //     only PAYS while the K / V^T streams of the 8 heads then in flight fit the 256 MB Infinity Cache (Ulysses rank of Wan-14B 720p, 5 heads:
   //     +4 %; Wan-1.3B 480p: +1.5 %); with 40 heads at 720p (8 x 38.7 MB in flight) it is 4-8 % SLOWER than the plain grid, whatever the
   //     rotation — there the plain grid, which keeps all XCDs on the same ~2 heads, stays.
-  //   * the stagger of the walk (rot mode 1) is worth +1.3 % on the plain grid; it changes the summation order per query block, so it is
-  //     opt-in per call (flag X2V_ATTN_VT_STAGGER) and the drivers that promise partition-independent bits (Ulysses) do not set it.
+  //   * the stagger of the walk (rot mode 1) was worth +1.3 % on the plain grid in 2-step runs and costs 0.9 % at sustained load
+  //     (profiles/r04_call12_*); it changes the summation order per query block; opt-in per call (flag X2V_ATTN_VT_STAGGER), no driver sets it.
   // X2V_ATTN_MAP / X2V_ATTN_ROT force a mode (A/B runs).
   const int plan = attn_vt_plan(Sq, Sk, H, B, stagger, NW * 32);
   const int rot_mode = plan & 0x100;
