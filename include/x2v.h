@@ -232,7 +232,11 @@ int x2v_layernorm_quant_fp8(const void* x, int64_t ldx, const void* w, const voi
 int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                  int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, void* stream);
 
-/* Same with the kernel selector of x2v_gemm_bf16_variant. */
+/* Same with the kernel selector of x2v_gemm_bf16_variant: 0 = by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (gemm256.hip, the large-shape
+ * default), 5 = the continuous single-stream pipeline (gemm256c8.hip: gemm256c's structure on v_mfma_scale_f32_32x32x64_f8f6f4; needs K a multiple
+ * of 256 and >= 512, N a multiple of 256, y blocks that are multiples of 128 columns and resid with y's row stride, else X2V_E_SHAPE; meant to give
+ * variant 2's bits).  Variant 5 is opt-in (X2V_GEMM_FP8_CONTINUOUS=1 makes variant 0 prefer it) until tools/gemm_fp8_continuous_check.py has
+ * confirmed it on a GPU.  3 / 4 are bf16 only (X2V_E_ARG). */
 int x2v_gemm_fp8_variant(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                          int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, int variant,
                          void* stream);

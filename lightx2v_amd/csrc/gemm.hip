@@ -265,6 +265,9 @@ int gemm256s_vt_dispatch(const void* x, int64_t ldxb, const void* w, int64_t ldw
 bool gemm256c_ok(int nk, const GemmBlocking& gb);
 int gemm256c_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
                       const void* resid, int64_t ldr, const void* gate, int gm_tiles, hipStream_t st, GemmBlocking gb);
+// gemm256c8.hip: the same continuous pipeline for the w8a8 operator (e4m3 operands, per-token / per-channel scales)
+int gemm256c8_dispatch(int epilogue, const void* x, int64_t ldxb, const void* w, int64_t ldwb, const void* bias, void* y, int64_t ldy, int64_t M, int N, int nk,
+                       const void* resid, int64_t ldr, const void* gate, const float* sx, const float* sw, int gm_tiles, hipStream_t st, GemmBlocking gb);
 }  // namespace x2v
 
 using namespace x2v;
@@ -322,11 +325,30 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
     set_error("gemm: leading dimension / K-block span too large for the 256x256 kernels (32-bit tile addressing)");
     return X2V_E_SHAPE;
   }
-  if (kind == 3 && FP8) {
-    set_error("gemm: the single-stream 256x256 kernel is bf16 only");
+  if (kind == 3 && FP8 && form != 5) {
+    set_error("gemm: the one-tile-per-workgroup single-stream 256x256 kernel is bf16 only (fp8: variant 2 = ping-pong, 5 = continuous single-stream)");
     return X2V_E_ARG;
   }
   const int chosen = kind == 0 ? choose_kernel(M, N, nk, ldxb, ldwb, FP8, gb) : kind;
+  if constexpr (FP8) {
+    // gemm256c8.hip: the continuous single-stream pipeline for w8a8 — bit-equal with gemm256.hip's fp8 mode in 84 / 84 cases at first contact and
+    // +2..5 % (plain), +1.5..2.5 % (GELU), +4..10 % (residual) at the w8a8 step's shapes (profiles/r04_call16_*).  Variant 0 takes it where the shape
+    // allows and the operands are not block-strided (the blocked fp8 path has not met a GPU yet: X2V_GEMM_FP8_CONTINUOUS=2 turns it on there too,
+    // =0 turns the continuous form off — whole-model A/B runs); variant 5 forces it, variant 2 forces the ping-pong kernel.
+    if (form == 5 || chosen == 2) {
+      static const int fp8_continuous_mode = [] { const char* e = getenv("X2V_GEMM_FP8_CONTINUOUS"); return e == nullptr ? 1 : atoi(e); }();
+      const bool unblocked = gb.a_kpb <= 0 && gb.y_cbw <= 0;
+      const bool fp8_continuous_on = fp8_continuous_mode >= 2 || (fp8_continuous_mode == 1 && unblocked);
+      const int64_t y_cols_span = gb.y_cbw > 0 ? (int64_t)((N - 1) / gb.y_cbw) * gb.y_cbs + gb.y_cbw : (int64_t)N;
+      const bool can_c = gemm256c_ok(nk, gb) && N % 256 == 0 && (255 * ldy + y_cols_span) * 2 < 0x80000000ll && (resid == nullptr || (ldr == ldy && gb.y_cbw <= 0));
+      if (form == 5 && !can_c) {
+        set_error("gemm_fp8: the continuous single-stream kernel needs an even number of K tiles >= 4, N %% 256 == 0, y blocks that are multiples of 128 columns and resid with y's row stride (nk=%d, N=%d)", nk, N);
+        return X2V_E_SHAPE;
+      }
+      if (form == 5 || (kind == 0 && fp8_continuous_on && can_c))
+        return gemm256c8_dispatch(epilogue, x, ldxb, w, ldwb, bias, y, ldy, M, N, nk, resid, ldr, gate, sx, sw, gm_tiles, st, gb);
+    }
+  }
   if constexpr (!FP8) {
     // the single-stream kernel addresses its output (and residual) tile with 32-bit offsets from the tile's first row
     const int64_t y_cols_span = gb.y_cbw > 0 ? (int64_t)((N - 1) / gb.y_cbw) * gb.y_cbs + gb.y_cbw : (int64_t)N;

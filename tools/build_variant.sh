@@ -6,11 +6,11 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 out=tools/probes/ab/$tag
 mkdir -p $out/obj
-for s in x2v_api norm gemm gemm256 gemm256s gemm256c attn quant_fp8 conv3d vae mx sched probe; do
+for s in x2v_api norm gemm gemm256 gemm256s gemm256c gemm256c8 attn quant_fp8 conv3d vae mx sched probe; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I include -I lightx2v_amd/csrc "$@" -c lightx2v_amd/csrc/$s.hip -o $out/obj/$s.o &
 done
 wait
-for s in x2v_api norm gemm gemm256 gemm256s gemm256c attn quant_fp8 conv3d vae mx sched probe; do [ -f $out/obj/$s.o ] || { echo "compile of $s.hip failed"; exit 1; }; done
+for s in x2v_api norm gemm gemm256 gemm256s gemm256c gemm256c8 attn quant_fp8 conv3d vae mx sched probe; do [ -f $out/obj/$s.o ] || { echo "compile of $s.hip failed"; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libx2v_hip.so $out/obj/*.o
 rm -rf $out/obj
 ls -la $out/libx2v_hip.so
