@@ -160,8 +160,9 @@ int x2v_gemm_bf16_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kb
 int x2v_gemm_bf16_vt(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int K, void* stream);
 
 /* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape: 1 = the
- * 128x128 kernel, 2 = the 256x256 ping-pong kernel (fp8), 3 = the 256x256 single-stream kernel (bf16) (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it
- * compared with the oracle is the one the dispatcher takes for a model's shapes. */
+ * 128x128 kernel, 2 = the 256x256 fp8 kernels (continuous single-stream form where the shape allows, else ping-pong: same bits), 3 = the
+ * 256x256 single-stream kernel (bf16) (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it compared with the
+ * oracle is the one the dispatcher takes for a model's shapes. */
 int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8);
 
 /* Dense non-causal attention, head_dim 128: o[Sq, H*128] = softmax(q k^T * scale) v per head —
@@ -235,8 +236,9 @@ int x2v_gemm_fp8(const void* xq, int64_t ldx, const float* sx, const void* wq, i
 /* Same with the kernel selector of x2v_gemm_bf16_variant: 0 = by shape, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (gemm256.hip, the large-shape
  * default), 5 = the continuous single-stream pipeline (gemm256c8.hip: gemm256c's structure on v_mfma_scale_f32_32x32x64_f8f6f4; needs K a multiple
  * of 256 and >= 512, N a multiple of 256, y blocks that are multiples of 128 columns and resid with y's row stride, else X2V_E_SHAPE; meant to give
- * variant 2's bits).  Variant 5 is opt-in (X2V_GEMM_FP8_CONTINUOUS=1 makes variant 0 prefer it) until tools/gemm_fp8_continuous_check.py has
- * confirmed it on a GPU.  3 / 4 are bf16 only (X2V_E_ARG). */
+ * variant 2's bits: 84 / 84 cases equal on MI355X, tools/gemm_fp8_continuous_check.py).  Variant 0 takes the continuous form where the shape
+ * allows and the operands are row-major (X2V_GEMM_FP8_CONTINUOUS=0: never, =2: also for x2v_gemm_fp8_blocked's operands).  3 / 4 are bf16 only
+ * (X2V_E_ARG). */
 int x2v_gemm_fp8_variant(const void* xq, int64_t ldx, const float* sx, const void* wq, int64_t ldw, const float* sw, const void* bias, void* y,
                          int64_t ldy, int64_t M, int N, int K, int epilogue, const void* resid, int64_t ldr, const void* gate, int variant,
                          void* stream);

@@ -402,7 +402,7 @@ def gemm_vt(x, weight_nk, bias, num_heads):
 
 
 def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False):
-    """1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (fp8), 3 = 256x256 single-stream kernel (bf16): what variant 0 launches for
+    """1 = 128x128 kernel, 2 = the 256x256 fp8 kernels (continuous / ping-pong, same bits), 3 = 256x256 single-stream kernel (bf16): what variant 0 launches for
     this shape (x2v_gemm_kernel_choice)."""
     rc = _lib.x2v_gemm_kernel_choice(M, N, K, K if ldx is None else ldx, K if ldw is None else ldw, int(fp8))
     if rc < 0:

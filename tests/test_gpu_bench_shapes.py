@@ -377,3 +377,49 @@ def test_gemm_continuous_pipeline_equals_one_tile_per_workgroup(M, K, N):
     if N > 256:
         with pytest.raises(lib.X2VError):
             lib.gemm(x, w[: N - 128], b[: N - 128], variant=5)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 512, 256), (4100, 2560, 5120), (9450, 5120, 5120), (1000, 13824, 256), (33000, 512, 1024)])
+def test_gemm_fp8_continuous_pipeline_equals_ping_pong(M, K, N):
+    """gemm256c8.hip (variant 5 of the w8a8 operator: gemm256c's continuous single-stream pipeline on v_mfma_scale_f32_32x32x64_f8f6f4, dequantisation in
+    the accumulator layout, wave-private transposition strip) against gemm256.hip's fp8 mode (variant 2): same MFMA, same k order, same rounding
+    points -> the SAME BITS, over one-tile and multi-tile workgroups, 4 to 108 K tiles, ragged M, every epilogue, bias / gate absent, rows around the
+    output untouched, scheduling-group sizes; the dispatcher's natural choice (variant 0) gives those bits too (mm_weight.py:287-319 is the op both
+    implement; the statements of tools/gemm_fp8_continuous_check.py, profiles/r04_call16_*)."""
+    from lightx2v_amd import lib
+
+    lib.init()
+    g = torch.Generator(device="cuda").manual_seed(M + K + N + 1)
+    x = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
+    xq, sx = lib.quant_fp8_rowwise(x)
+    wq, sw = lib.quant_fp8_rowwise(w)
+    b = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    gate = (torch.randn(N, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    natural = lib.gemm_kernel_choice(M, N, K, fp8=True) == 2  # else variant 0 is the 128x128 kernel (another k order inside the MFMA: other bits)
+    for gm in (0, 7):
+        for epi, kw in ((lib.EPI_NONE, {}), (lib.EPI_NONE, {"bias": None}), (lib.EPI_GELU_TANH, {}), (lib.EPI_SILU, {}), (lib.EPI_RESIDUAL, {"gate": gate}), (lib.EPI_RESIDUAL, {"gate": None})):
+            bias = kw.get("bias", b)
+            outs = []
+            for form in (2, 5, 0) if natural else (2, 5):
+                if epi == lib.EPI_RESIDUAL:
+                    r = res.clone()
+                    lib.gemm_fp8(xq, sx, wq, sw, bias, epilogue=epi, resid=r, gate=kw["gate"], variant=form | (gm << 8))
+                    outs.append(r)
+                else:
+                    y = torch.full((M + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")  # nothing may be written outside rows [1, M + 1)
+                    lib.gemm_fp8(xq, sx, wq, sw, bias, epilogue=epi, out=y[1 : M + 1], variant=form | (gm << 8))
+                    outs.append(y)
+            assert torch.equal(outs[0], outs[1]), (M, K, N, epi, gm, sorted(kw))
+            if natural:
+                assert torch.equal(outs[0], outs[2]), ("natural dispatch", M, K, N, epi, gm, sorted(kw))
+            if epi != lib.EPI_RESIDUAL:
+                assert (outs[1][0] == 7).all() and (outs[1][-1] == 7).all()
+    # a shape outside the continuous form (an odd number of K tiles) is refused when forced and served by the ping-pong kernel otherwise
+    if K >= 512 + 128:
+        xo, wo = xq[:, : K - 128], wq[:, : K - 128]
+        with pytest.raises(lib.X2VError):
+            lib.gemm_fp8(xo, sx, wo, sw, b, variant=5)
+        if lib.gemm_kernel_choice(M, N, K - 128, fp8=True) == 2:
+            assert torch.equal(lib.gemm_fp8(xo, sx, wo, sw, b), lib.gemm_fp8(xo, sx, wo, sw, b, variant=2))
