@@ -1,6 +1,7 @@
 // y[M,N] = epi((xq[M,K] . Wq[N,K]^T) * sx[m] * sw[n] + bias), e4m3 operands with per-token / per-channel fp32 scales (w8a8) — gemm256c.hip's CONTINUOUS
 // single-stream pipeline for the fp8 operator.  Same contract, operand layouts, epilogues, rounding points, MFMA (v_mfma_scale_f32_32x32x64_f8f6f4 with
-// unit block scales) and k order as the fp8 instantiation of gemm256.hip: results are meant to be bit-equal (tools/gemm_fp8_continuous_check.py).
+// unit block scales) and k order as the fp8 instantiation of gemm256.hip: bit-equal results (tools/gemm_fp8_continuous_check.py,
+// tests/test_gpu_bench_shapes.py::test_gemm_fp8_continuous_pipeline_equals_ping_pong).
 // Replaces the cutlass_scaled_mm / fp8_scaled_mm call of common/ops/mm/mm_weight.py:287-319 at the large shapes, behind x2v_gemm_fp8[_variant|_blocked].
 //
 // Bound: MFMA (fp8 dense peak ~5 PFLOP/s; at the board's 1400 W limit a bare 32x32x64 loop with this LDS fragment traffic sustains ~3.9 PFLOP/s,
@@ -21,8 +22,9 @@
 //     scales + 8 x 4 bf16 bias) have to be requested while the fragment registers are still in use: the first half's ride in the LAST K tile's slots, the second half's
 //     are requested when the epilogue starts and arrive under the first half's work.
 // Shapes: as gemm256c (even number of K tiles >= 4, N a multiple of 256, y blocks multiples of 128 columns, residual with y's row stride); the rest
-// stays on gemm256.hip.  OFF by default until a GPU run has confirmed bit-equality and a gain: variant 5 of x2v_gemm_fp8_variant forces it,
-// X2V_GEMM_FP8_CONTINUOUS=1 makes the dispatcher prefer it (whole-model A/B runs).
+// stays on gemm256.hip.  First contact on MI355X (profiles/r04_call16_*): 84 / 84 equality cases bit-equal, +2..5 % plain, +1.5..2.5 % GELU, +4..10 %
+// residual at the w8a8 step's shapes (2.55-2.87 PFLOP/s).  The dispatcher's default for row-major operands; block-strided operands (Ulysses buffers) keep
+// the ping-pong kernel until that path has met a GPU (X2V_GEMM_FP8_CONTINUOUS=2; =0: never).  Variant 5 of x2v_gemm_fp8_variant forces this kernel.
 // AUDIT after every edit (the accumulator half is invisible to the compiler): `hipcc -S` must show .vgpr_spill_count 0,
 // .private_segment_fixed_size 0 and no v_accvgpr_* / a[..] operand outside ;;#ASMSTART / ;;#ASMEND.
 #include <type_traits>

@@ -607,6 +607,53 @@ def gemm_fp8(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, resid=None, gate=N
     return out2
 
 
+def gemm_fp8_blocked(xq, sx, wq_nk, sw, bias=None, epilogue=EPI_NONE, out=None, resid=None, gate=None):
+    """x2v_gemm_fp8_blocked: the w8a8 GEMM on block-strided operands (see gemm_blocked).  `xq`: e4m3 codes [M, K] or K-blocked [B, M, K/B]
+    (the codes of the ROW's quantisation, `sx` [M] stays per row); `out`: None / [M, N] or N-blocked [B', M, N/B'] (preallocated); the residual
+    epilogue needs a row-major `resid` (= the output).  Returns the output tensor."""
+    if wq_nk.dtype != torch.float8_e4m3fn or xq.dtype != torch.float8_e4m3fn or wq_nk.dim() != 2 or wq_nk.stride(1) != 1 or not wq_nk.is_cuda or not xq.is_cuda:
+        raise X2VError("gemm_fp8_blocked: operands must be float8_e4m3fn device tensors (weight [N, K] with unit inner stride)")
+    N, K = wq_nk.shape
+    if xq.dim() == 3:
+        kb, kbs, ldx = _blocks3d(xq, "xq")
+        M = xq.shape[1]
+        if kb * xq.shape[0] != K:
+            raise X2VError(f"gemm_fp8_blocked: xq blocks {tuple(xq.shape)} do not make K={K}")
+    else:
+        if xq.dim() != 2 or xq.stride(1) != 1 or xq.shape[1] != K:
+            raise X2VError(f"gemm_fp8_blocked: xq {tuple(xq.shape)} vs weight [{N},{K}]")
+        kb, kbs, ldx, M = 0, 0, xq.stride(0), xq.shape[0]
+    r2 = None
+    if epilogue == EPI_RESIDUAL:
+        if resid is None:
+            raise X2VError("gemm_fp8_blocked: residual epilogue needs resid")
+        r2 = _row2d(_bf16(resid, "resid"), "resid")
+        out = resid if out is None else out
+        gate = _vec(gate, "gemm_fp8_blocked gate", N)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    if out.dim() == 3:
+        nb, nbs, ldy = _blocks3d(_bf16(out, "out"), "out")
+        if nb * out.shape[0] != N or out.shape[1] != M:
+            raise X2VError(f"gemm_fp8_blocked: out blocks {tuple(out.shape)} do not make [{M}, {N}]")
+    else:
+        o2 = _row2d(_bf16(out, "out"), "out")
+        nb, nbs, ldy = 0, 0, o2.stride(0)
+        if tuple(o2.shape) != (M, N):
+            raise X2VError(f"gemm_fp8_blocked: out is {tuple(o2.shape)}, expected {(M, N)}")
+    sw, sx = _vec(sw, "gemm_fp8_blocked weight scales", N, torch.float32), _vec(sx, "gemm_fp8_blocked activation scales", M, torch.float32)
+    bias = _vec(bias, "gemm_fp8_blocked bias", N)
+    init()
+    if M == 0:
+        return out
+    _check(
+        _lib.x2v_gemm_fp8_blocked(_p(xq), ldx, kb, kbs, _p(sx), _p(wq_nk), wq_nk.stride(0), _p(sw), _p(bias), _p(out), ldy, nb, nbs, M, N, K, epilogue, _p(r2),
+                                  0 if r2 is None else r2.stride(0), _p(gate) if epilogue == EPI_RESIDUAL else None, _stream()),
+        "gemm_fp8_blocked",
+    )
+    return out
+
+
 def sinusoid_embed(t, dim):
     t = t.reshape(-1).to(torch.int64)
     out = torch.empty((t.numel(), dim), dtype=torch.bfloat16, device=t.device)

@@ -69,6 +69,15 @@ def test_argument_validation_needs_no_gpu():
     assert L.x2v_layernorm_bf16(a, 16, None, None, a, None, a, 16, 1, 16, 1e-6, None) == -5  # scale without shift
     assert L.x2v_causal_conv3d_f32(a, None, 1, a, None, a, 1, 4, 4, 16, 16, 3, 3, 3, None) == -5  # cache frames without cache
     assert L.x2v_gemm_fp8(a, 128, a, a, 128, a, None, a, 64, 4, 64, 64, 0, None, 0, None, None) == -1  # K % 128
+    # x2v_gemm_fp8_blocked(xq, ldx, x_kblock, x_kblock_stride, sx, wq, ldw, sw, bias, y, ldy, y_nblock, y_nblock_stride, M, N, K, epilogue, resid, ldr, gate, stream)
+    assert L.x2v_gemm_fp8_blocked(a, 256, 64, 4096, a, a, 256, a, None, a, 64, 0, 0, 4, 64, 256, 0, None, 0, None, None) == -1  # K block of 64 e4m3 (not k * 128)
+    assert b"K-block" in L.x2v_last_error()
+    assert L.x2v_gemm_fp8_blocked(a, 256, 0, 0, a, a, 256, a, None, a, 32, 32, 4096, 4, 64, 256, 2, a, 64, None, None) == -5  # residual epilogue with an N-blocked y
+    assert L.x2v_gemm_fp8_blocked(a, 256, 0, 0, None, a, 256, a, None, a, 64, 0, 0, 4, 64, 256, 0, None, 0, None, None) == -5  # null sx
+    # the forced continuous form of the w8a8 GEMM refuses shapes it does not take (odd number of K tiles) before any launch
+    assert L.x2v_gemm_fp8_variant(a, 384, a, a, 384, a, None, a, 256, 300, 256, 384, 0, None, 0, None, 5, None) == -1
+    assert b"continuous" in L.x2v_last_error()
+    assert L.x2v_gemm_fp8_variant(a, 512, a, a, 512, a, None, a, 256, 300, 256, 512, 0, None, 0, None, 4, None) == -5  # 3 / 4 are bf16 only
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
