@@ -88,15 +88,28 @@ __device__ __forceinline__ void c8_for(F&& f) {  // f(integral_constant<int, i>)
   }
 }
 
+#ifndef C8_NOSCALE
+#define C8_NOSCALE 0  // A/B builds: 1 = the unscaled encoding v_mfma_f32_32x32x64_f8f6f4 (8 bytes instead of 16; same bits expected, not yet measured)
+#endif
 // accumulator tile I (= x block * 4 + W block, 32 x 32) is a[16 I : 16 I + 15]; `one` = four e8m0 2^0 block scales (what gemm256.hip's builtin passes)
 template <int I>
 __device__ __forceinline__ void c8_mfma(const i32x8_t& wf, const i32x8_t& xf, int one) {
+#if C8_NOSCALE
+  (void)one;
+  asm volatile("v_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(16 * I), "i"(16 * I + 15) : C8_AGPRS);
+#else
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c3:%c4], %0, %1, a[%c3:%c4], %2, %2 op_sel_hi:[0,0,0]" ::"v"(wf), "v"(xf), "v"(one), "i"(16 * I), "i"(16 * I + 15)
                : C8_AGPRS);
+#endif
 }
 template <int I>
 __device__ __forceinline__ void c8_mfma_first(const i32x8_t& wf, const i32x8_t& xf, int one) {  // first k-step of an output tile: C = 0
+#if C8_NOSCALE
+  (void)one;
+  asm volatile("v_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, 0" ::"v"(wf), "v"(xf), "i"(16 * I), "i"(16 * I + 15) : C8_AGPRS);
+#else
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c3:%c4], %0, %1, 0, %2, %2 op_sel_hi:[0,0,0]" ::"v"(wf), "v"(xf), "v"(one), "i"(16 * I), "i"(16 * I + 15) : C8_AGPRS);
+#endif
 }
 template <int R>
 __device__ __forceinline__ float c8_acc_read() {

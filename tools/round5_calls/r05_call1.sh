@@ -3,7 +3,8 @@
 #   1. w8a8 step (config #4) with the continuous fp8 GEMM (default) vs the ping-pong kernel (X2V_GEMM_FP8_CONTINUOUS=0), a/b/a/b, + rocprofv3 kernel stats
 #   2. x2v_gemm_fp8_blocked (never run on a GPU so far): bit-equality with the row-major operator, on the ping-pong kernel and (X2V_GEMM_FP8_CONTINUOUS=2) the continuous one
 #   3. bf16 continuous GEMM with the epilogue walk software-pipelined (variant build C_EPI_PIPELINED=1): bit-equality + timings vs today's
-# Before the call, HERE (hipcc, no GPU needed):   tools/build_variant.sh epipipe -DC_EPI_PIPELINED=1
+#   4. the continuous fp8 GEMM with the unscaled MFMA encoding (variant build C8_NOSCALE=1): bit-equality + timings
+# Before the call, HERE (hipcc, no GPU needed):   tools/build_variant.sh epipipe -DC_EPI_PIPELINED=1; tools/build_variant.sh noscale -DC8_NOSCALE=1
 set +e
 OUT=gpurun_out/r05_call1
 mkdir -p "$OUT"
@@ -30,6 +31,21 @@ for tag in ("today", "epipipe"):
         print(tag, "equality_cases", d["equality_cases"], "mismatches", d["n_mismatches"])
         for r in d.get("timing", []):
             print("  ", r["M"], r["K"], r["N"], {k: v for k, v in r.items() if "continuous" in k})
+    except Exception as e:
+        print(tag, "unreadable:", e)
+PY
+fi
+if [ -f tools/probes/ab/noscale/libx2v_hip.so ]; then  # 4. the unscaled MFMA encoding in the continuous fp8 GEMM (tools/build_variant.sh noscale -DC8_NOSCALE=1): same bits? faster?
+  timeout 90 python tools/gemm_fp8_continuous_check.py > "$OUT/fp8_scaled.jsonl" 2> "$OUT/fp8_scaled.err"; echo "fp8 continuous (scaled encoding) rc=$?" | tee -a "$OUT/summary.txt"
+  X2V_LIB_PATH=tools/probes/ab/noscale/libx2v_hip.so timeout 90 python tools/gemm_fp8_continuous_check.py > "$OUT/fp8_noscale.jsonl" 2> "$OUT/fp8_noscale.err"; echo "fp8 continuous (unscaled encoding) rc=$?" | tee -a "$OUT/summary.txt"
+  head -1 "$OUT/fp8_noscale.jsonl" | cut -c1-300 >> "$OUT/summary.txt"
+  python - >> "$OUT/summary.txt" <<'PY'
+import json
+for tag in ("scaled", "noscale"):
+    try:
+        for line in open(f"gpurun_out/r05_call1/fp8_{tag}.jsonl").read().strip().splitlines()[1:]:
+            r = json.loads(line)
+            print(tag, r["M"], r["K"], r["N"], {k: v for k, v in r.items() if "continuous" in k})
     except Exception as e:
         print(tag, "unreadable:", e)
 PY
