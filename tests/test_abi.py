@@ -90,6 +90,11 @@ def test_product_path_fails_loudly_without_gpu():
         lib.gemm(x, w)
     with pytest.raises(lib.X2VError):
         lib.rmsnorm(x, w[0])
+    xq, wq = torch.zeros(8, 256, dtype=torch.float8_e4m3fn), torch.zeros(256, 256, dtype=torch.float8_e4m3fn)
+    with pytest.raises(lib.X2VError):
+        lib.gemm_fp8(xq, torch.ones(8, 1), wq, torch.ones(256, 1))
+    with pytest.raises(lib.X2VError):
+        lib.gemm_fp8_blocked(xq.view(8, 2, 128).transpose(0, 1).contiguous(), torch.ones(8, 1), wq, torch.ones(256, 1))
 
 
 def test_missing_library_is_an_error(tmp_path):
