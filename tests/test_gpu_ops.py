@@ -15,7 +15,7 @@ import math
 import pytest
 import torch
 
-from tests.util import assert_bf16_close, assert_rel
+from tests.util import assert_bf16_close
 
 pytestmark = pytest.mark.gpu
 
