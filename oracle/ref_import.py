@@ -69,6 +69,7 @@ def patch_and_import():
             torch.cuda.synchronize = lambda *a, **k: None
             torch.cuda.empty_cache = lambda *a, **k: None
         _patched = True
+        print(f"oracle.ref_import: unmodified reference imported from {REFERENCE_ROOT}" + (" (the staged copy)" if REFERENCE_ROOT == _STAGED else ""), file=sys.stderr)
     import lightx2v  # noqa: F401
     import lightx2v.common.ops  # noqa: F401  (populates the operator registries)
 

@@ -2,6 +2,7 @@
 per Wan block and forward GEMM = 12 S D^2 + 4 Lc D^2 + 4 S D F, ATTN = 4 S^2 D + 4 S Lc D; step = L x (GEMM + ATTN) x forwards."""
 import importlib.util
 import os
+import sys
 
 import pytest
 
@@ -88,3 +89,26 @@ def test_watchdog_exits_124_when_no_progress_arrives(tmp_path):
     assert p.returncode == 124, (p.returncode, p.stderr[-500:])
     assert "TICKED" in p.stdout and "NOT REACHED" not in p.stdout
     assert "rank 3 made no progress" in p.stderr and "stuck in the exchange" in p.stderr
+
+
+def test_reference_cpu_baseline_script_reproduces_the_golden_latents():
+    """bench.py's cpu_baseline leg (kind "reference") runs oracle/ref_cpu_baseline.py in a subprocess with the GPUs hidden: the UNMODIFIED
+    reference's WanModel + WanScheduler in DefaultRunner.run's loop.  On the wan-tiny plumbing model its final latents must be the ones
+    tests/golden/wan-tiny_model.safetensors holds (written by oracle/gen_golden.py from the same reference) — the baseline script times what the
+    fixtures pin, with the thread sweep and the timing marks in between."""
+    import json
+    import subprocess
+
+    from safetensors.torch import load_file
+
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout not present")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "oracle.ref_cpu_baseline", "--tiny", "--threads", "1,2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["kind"] == "reference" and rec["threads"] in (1, 2) and len(rec["ms_per_step"]) == 4
+    gold = load_file(os.path.join(ROOT, "tests", "golden", "wan-tiny_model.safetensors"))["latents_after_step3"]
+    assert rec["latents_abs_sum"] == float(gold.double().abs().sum())
