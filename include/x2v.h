@@ -49,6 +49,12 @@ const char* x2v_last_error(void);
 const char* x2v_version(void);
 int x2v_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 
+/* The process-wide A/B switches this library reads ONCE from the environment, as "NAME=value NAME=value ..." (effective values, defaults
+ * included): X2V_GEMM_CONTINUOUS, X2V_GEMM_FP8_CONTINUOUS (kernel forms, same bits), X2V_ATTN_MAP, X2V_ATTN_ROT (launch forms of
+ * x2v_attn_fwd_bf16_vt; ROT changes the key-walk order, i.e. low bits).  The reference has no counterpart (its kernel choice is the config
+ * string, utils/registry_factory.py:47-56); bench.py prints the string into its JSON line so that a stray variable on a rank is visible. */
+int x2v_switches(char* buf, int buf_len);
+
 /* y[M,D] = x * rsqrt(mean(x^2) + eps) * w     — replaces RMSWeight/RMSWeightSgl.apply
  * (common/ops/norm/rms_norm_weight.py:53-118; sgl_kernel.rmsnorm :102-108).  D % 8 == 0, D <= 16384.
  * y may alias x. */
@@ -159,10 +165,12 @@ int x2v_gemm_bf16_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kb
  * x2v_attn_fwd_bf16_vt without the transposing pass.  Only for shapes that x2v_gemm_kernel_choice maps to kernel 3 (else X2V_E_SHAPE). */
 int x2v_gemm_bf16_vt(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* vt, int64_t ldvt, int64_t M, int N, int K, void* stream);
 
-/* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape: 1 = the
- * 128x128 kernel, 2 = the 256x256 fp8 kernels (continuous single-stream form where the shape allows, else ping-pong: same bits), 3 = the
- * 256x256 single-stream kernel (bf16) (negative = X2V_E_SHAPE).  Host-only; lets a parity test assert that the kernel it compared with the
- * oracle is the one the dispatcher takes for a model's shapes. */
+/* Which kernel variant 0 of x2v_gemm_bf16_variant (fp8 = 0) / x2v_gemm_fp8_variant (fp8 = 1) launches for this shape.  Low byte = tile family:
+ * 1 = the 128x128 kernel, 2 = the 256x256 fp8 kernels, 3 = the 256x256 single-stream kernel (bf16).  Bit 8 (0x100) = the CONTINUOUS-pipeline
+ * form of that family (gemm256c.hip / gemm256c8.hip) for a row-major y and a residual of y's stride; clear = one output tile per workgroup
+ * (gemm256s.hip) / the ping-pong kernel (gemm256.hip) — same bits either way, asserted by the equality tests.  Negative = X2V_E_SHAPE.
+ * Host-only; lets a parity test and the bench line record WHICH kernel was compared with the oracle / timed (the X2V_GEMM_*CONTINUOUS
+ * switches are folded in). */
 int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8);
 
 /* Dense non-causal attention, head_dim 128: o[Sq, H*128] = softmax(q k^T * scale) v per head —
@@ -219,6 +227,13 @@ int x2v_attn_fwd_bf16_vt_batched(const void* q, int64_t ldq, int64_t q_bstride, 
  * vllm ops.scaled_fp8_quant(use_per_token_if_dynamic=True) / sgl_kernel.sgl_per_token_quant_fp8
  * (mm_weight.py:236-245).  xq [M,K] bytes (ld = ldq), scale fp32 [M]. */
 int x2v_quant_fp8_rowwise(const void* x, int64_t ldx, void* xq, int64_t ldq, float* scale, int64_t M, int K, void* stream);
+
+/* x2v_quant_fp8_rowwise reading a K-BLOCKED x (element k of row m at x[(k / x_kblock) * x_kblock_stride + m * ldx + k % x_kblock]: the Ulysses
+ * head->seq receive buffer [N_ranks][S/N][(H/N) d], attentions/distributed/ulysses/attn.py:82-91 after its transposing copy) and writing ROW-MAJOR
+ * codes — the quantisation pass reads every element once anyway, so under w8a8 the de-blocking costs nothing and the output projection
+ * (mm_weight.py:236-245 + :287-319) runs the plain row-major x2v_gemm_fp8.  x_kblock = 0: plain row-major x (= x2v_quant_fp8_rowwise). */
+int x2v_quant_fp8_rowwise_blocked(const void* x, int64_t ldx, int x_kblock, int64_t x_kblock_stride, void* xq, int64_t ldq, float* scale, int64_t M, int K,
+                                  void* stream);
 
 /* x2v_layernorm_bf16 fused with x2v_quant_fp8_rowwise on its output: xq [M,D] e4m3 codes (ld = ldq) and sx [M] fp32 scales of the
  * normalised (+affine, +modulated) row, bit-identical to the two calls in sequence — the w8a8 path's LayerNorm -> scaled_fp8_quant in front

@@ -699,9 +699,18 @@ static int launch_attn_pipe(const void* q, int64_t ldq, const void* k, int64_t l
 // The launch form of the pre-transposed-V kernel for a shape: bit 0 = XCD-aware head-major work mapping, bit 8 = staggered key walk.
 // Host-only and deterministic in its arguments (plus the X2V_ATTN_MAP / X2V_ATTN_ROT overrides for A/B runs); exported as
 // x2v_attn_vt_launch_plan so that a parity test can assert WHICH kernel branch the shape it compared with the oracle took.
+namespace x2v {
+int attn_map_switch() {
+  static const int v = [] { const char* e = getenv("X2V_ATTN_MAP"); return e ? atoi(e) : -1; }();
+  return v;
+}
+int attn_rot_switch() {
+  static const int v = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
+  return v;
+}
+}  // namespace x2v
 static int attn_vt_plan(int64_t Sq, int64_t Sk, int H, int B, bool stagger, int q_rows_per_wg) {
-  static const int map_env = [] { const char* e = getenv("X2V_ATTN_MAP"); return e ? atoi(e) : -1; }();
-  static const int rot_env = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
+  const int map_env = attn_map_switch(), rot_env = attn_rot_switch();
   const uint64_t nwg = (uint64_t)((Sq + q_rows_per_wg - 1) / q_rows_per_wg) * (uint64_t)H * (uint64_t)B;
   const int64_t heads_in_flight = (int64_t)H * B < 8 ? (int64_t)H * B : 8;
   const bool mall_resident = heads_in_flight * Sk * (2 * AT_D * 2) <= (224ll << 20);

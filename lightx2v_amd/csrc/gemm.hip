@@ -302,6 +302,15 @@ static bool spans_fit_256(int nk, int64_t ldxb, int64_t ldwb, const GemmBlocking
   return ldxb < (1 << 24) && ldwb < (1 << 24) && 255 * ldxb + a_span < (1ll << 32) && 255 * ldwb + (int64_t)nk * 128 < (1ll << 32);
 }
 
+int x2v::gemm_continuous_switch() {
+  static const int v = [] { const char* e = getenv("X2V_GEMM_CONTINUOUS"); return e == nullptr ? 1 : (atoi(e) != 0 ? 1 : 0); }();
+  return v;
+}
+int x2v::gemm_fp8_continuous_switch() {
+  static const int v = [] { const char* e = getenv("X2V_GEMM_FP8_CONTINUOUS"); return e == nullptr ? 2 : atoi(e); }();
+  return v;
+}
+
 static int choose_kernel(int64_t M, int N, int nk, int64_t ldxb, int64_t ldwb, bool fp8, const GemmBlocking& gb = GemmBlocking()) {
   const bool fits256 = spans_fit_256(nk, ldxb, ldwb, gb);
   const int64_t tiles256 = ((M + 255) / 256) * (int64_t)((N + 255) / 256);
@@ -333,10 +342,11 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
   if constexpr (FP8) {
     // gemm256c8.hip: the continuous single-stream pipeline for w8a8 — bit-equal with gemm256.hip's fp8 mode in 84 / 84 cases at first contact and
     // +2..5 % (plain), +1.5..2.5 % (GELU), +4..10 % (residual) at the w8a8 step's shapes (profiles/r04_call16_*).  Variant 0 takes it where the shape
-    // allows and the operands are not block-strided (the blocked fp8 path has not met a GPU yet: X2V_GEMM_FP8_CONTINUOUS=2 turns it on there too,
-    // =0 turns the continuous form off — whole-model A/B runs); variant 5 forces it, variant 2 forces the ping-pong kernel.
+    // allows, block-strided (Ulysses) operands included since round 5 (23 / 23 blocked cases bit-equal with the ping-pong kernel on both kernels,
+    // profiles/r05_call1_*; tests/test_gpu_bench_shapes.py::test_gemm_fp8_blocked_*).  X2V_GEMM_FP8_CONTINUOUS=1 keeps blocked operands on the
+    // ping-pong kernel, =0 turns the continuous form off (whole-model A/B runs); variant 5 forces it, variant 2 forces the ping-pong kernel.
     if (form == 5 || chosen == 2) {
-      static const int fp8_continuous_mode = [] { const char* e = getenv("X2V_GEMM_FP8_CONTINUOUS"); return e == nullptr ? 1 : atoi(e); }();
+      const int fp8_continuous_mode = gemm_fp8_continuous_switch();
       const bool unblocked = gb.a_kpb <= 0 && gb.y_cbw <= 0;
       const bool fp8_continuous_on = fp8_continuous_mode >= 2 || (fp8_continuous_mode == 1 && unblocked);
       const int64_t y_cols_span = gb.y_cbw > 0 ? (int64_t)((N - 1) / gb.y_cbw) * gb.y_cbs + gb.y_cbw : (int64_t)N;
@@ -363,7 +373,7 @@ static int dispatch_epi(int epilogue, const void* x, int64_t ldxb, const void* w
     if (chosen == 3) {
       // continuous form: its epilogue addresses the output / residual tile through descriptors of 2^31 bytes (offset 0x80000000 is the "no such
       // row" mark), so the tile spans must stay below that
-      static const bool continuous_on = [] { const char* e = getenv("X2V_GEMM_CONTINUOUS"); return e == nullptr || atoi(e) != 0; }();
+      const bool continuous_on = gemm_continuous_switch() != 0;
       const bool can_c = gemm256c_ok(nk, gb) && N % 256 == 0 && (255 * ldy + y_cols_span) * 2 < 0x80000000ll && (resid == nullptr || (ldr == ldy && gb.y_cbw <= 0));  // residual tile addressed with y's offsets
       if (form == 5 && !can_c) {
         set_error("gemm: the continuous single-stream kernel needs an even number of K tiles >= 4, N %% 256 == 0, y blocks that are multiples of 128 columns and resid with y's row stride (nk=%d, N=%d)", nk, N);
@@ -502,5 +512,11 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_bf16_vt(const voi
 
 extern "C" __attribute__((visibility("default"))) int x2v_gemm_kernel_choice(int64_t M, int N, int K, int64_t ldx, int64_t ldw, int fp8) {
   if (M <= 0 || N <= 0 || K <= 0) return X2V_E_SHAPE;
-  return fp8 ? choose_kernel(M, N, K / 128, ldx, ldw, true) : choose_kernel(M, N, K / GB_K, ldx * 2, ldw * 2, false);
+  const int nk = fp8 ? K / 128 : K / GB_K;
+  const int tile = fp8 ? choose_kernel(M, N, nk, ldx, ldw, true) : choose_kernel(M, N, nk, ldx * 2, ldw * 2, false);
+  // bit 8: variant 0 runs the CONTINUOUS-pipeline form of that tile family (gemm256c.hip / gemm256c8.hip) for a row-major y (ldy == N) and a
+  // residual of y's stride — what the parity tests and the bench line record (the two forms used to be indistinguishable here)
+  const bool cont = (tile == 3 && !fp8 && gemm_continuous_switch() != 0) || (tile == 2 && fp8 && gemm_fp8_continuous_switch() >= 1);
+  const bool can_c = gemm256c_ok(nk, GemmBlocking()) && N % 256 == 0 && (255 * (int64_t)N + N) * 2 < 0x80000000ll;
+  return tile | ((cont && can_c) ? 0x100 : 0);
 }

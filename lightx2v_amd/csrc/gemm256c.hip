@@ -40,9 +40,6 @@ namespace x2v {
 #ifndef C_DMA_AUX_A
 #define C_DMA_AUX_A 0  // cache policy of the x-operand LDS-DMA (A/B builds)
 #endif
-#ifndef C_EPI_PIPELINED
-#define C_EPI_PIPELINED 0  // A/B builds: 1 = the epilogue walk software-pipelined by one x block (gemm256c8.hip's form; not yet measured for bf16)
-#endif
 constexpr int C_M = 256, C_N = 256;
 constexpr int C_OP_BYTES = 256 * 128;          // one operand tile of one stage
 constexpr int C_STAGE_BYTES = 2 * C_OP_BYTES;  // W tile | x tile
@@ -348,21 +345,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<c_u32x2_t*>(strip + wa) = c_u32x2_t{pack_bf2(vv[0], vv[1]), pack_bf2(vv[2], vv[3])};
   };
   // Phase B, instruction i of x block xb: local rows 16 xb + 4 i + (lane >> 4), this lane's 8 columns 8 (lane & 15)..: strip -> (residual) -> memory
-#if C_EPI_PIPELINED
-  c_u32x4_t e_raw[4];
-  auto epi_read_b = [&](auto ic) {  // the four strip reads of an x block back to back: one LDS round trip per block, not four
-    constexpr int i = decltype(ic)::value;
-    e_raw[i] = *reinterpret_cast<const c_u32x4_t*>(strip + (4 * i + l4) * 256 + ((c16 ^ (4 * i + l4)) << 4));
-  };
-#endif
   auto epi_phase_b = [&](auto xbc, auto ic) {
     constexpr int xb = decltype(xbc)::value, i = decltype(ic)::value;
-#if C_EPI_PIPELINED
-    c_u32x4_t yv4 = e_raw[i];
-#else
     const int ra = (4 * i + l4) * 256 + ((c16 ^ (4 * i + l4)) << 4);
     c_u32x4_t yv4 = *reinterpret_cast<const c_u32x4_t*>(strip + ra);
-#endif
     if constexpr (RES) {
       float yv[8], xv[8], gv[8], ov[8];
       unpack8(__builtin_bit_cast(uint4, yv4), yv);
@@ -382,29 +368,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (RES) {
       if (gate == nullptr) e_gate4 = c_u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};  // x + y: gate 1.0 gives the same bits (y is already bf16)
     }
-#if C_EPI_PIPELINED
-    // A(0) R(0) | A(1) B(0) R(1) | .. | A(7) B(6) R(7) | B(7): phase A of block xb is issued under the strip reads of block xb - 1 (LDS executes a
-    // wave's instructions in order, so those reads return the old contents); the residual chunks of block xb + 1 are requested behind B(xb - 1),
-    // the last reader of their buffer
-    c_for<0, 9>([&](auto xbc) {
-      constexpr int xb = decltype(xbc)::value;
-      if constexpr (xb < 8) {
-        c_for<0, 8>([&](auto wbc) { epi_phase_a(std::integral_constant<int, xb * 8 + decltype(wbc)::value>{}); });
-        C_SB();
-      }
-      if constexpr (xb > 0) {
-        c_for<0, 4>([&](auto ic) { epi_phase_b(std::integral_constant<int, xb - 1>{}, ic); });
-        C_SB();
-      }
-      if constexpr (xb < 8) {
-        if constexpr (RES && xb < 7) {
-          c_for<0, 4>([&](auto ic) { res_load(std::integral_constant<int, xb + 1>{}, ic); });
-        }
-        c_for<0, 4>([&](auto ic) { epi_read_b(ic); });
-        C_SB();
-      }
-    });
-#else
+    // (The walk software-pipelined by one x block — gemm256c8.hip's form: A(xb + 1) under the strip reads of block xb — was measured in round 5 and is
+    //  a wash in bf16: 5120->13824 plain +1..2 %, GELU -1 %, 13824->5120 +0.8 %, K = 1536 inside the noise; profiles/r05_call1_*.  Not kept.)
     c_for<0, 8>([&](auto xbc) {
       constexpr int xb = decltype(xbc)::value;
       if constexpr (RES && xb < 7) {  // the next x block's residual chunks fly under this block's arithmetic
@@ -415,7 +380,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       c_for<0, 4>([&](auto ic) { epi_phase_b(xbc, ic); });
       C_SB();
     });
-#endif
   };
 
   // ---- pipeline start: K tile 0 of the first output tile and the first C_EARLY pieces of its K tile 1 in flight, tile 0 landed, k-step 0 in registers

@@ -88,28 +88,17 @@ __device__ __forceinline__ void c8_for(F&& f) {  // f(integral_constant<int, i>)
   }
 }
 
-#ifndef C8_NOSCALE
-#define C8_NOSCALE 0  // A/B builds: 1 = the unscaled encoding v_mfma_f32_32x32x64_f8f6f4 (8 bytes instead of 16; same bits expected, not yet measured)
-#endif
-// accumulator tile I (= x block * 4 + W block, 32 x 32) is a[16 I : 16 I + 15]; `one` = four e8m0 2^0 block scales (what gemm256.hip's builtin passes)
+// accumulator tile I (= x block * 4 + W block, 32 x 32) is a[16 I : 16 I + 15].  The UNSCALED encoding v_mfma_f32_32x32x64_f8f6f4 (8 bytes; both
+// operands e4m3 by its default cbsz / blgp): per-channel w8a8 has no block scales, and the scaled encoding with unit e8m0 scales (16 bytes + a
+// scale register read per MFMA; what gemm256.hip's builtin emits) gives the same bits — 84 / 84 equality cases — and is 0.5-1.0 % slower at every
+// shape and epilogue measured (profiles/r05_call1_*: 13824->5120 plain 2905 -> 2933 TFLOP/s).
 template <int I>
-__device__ __forceinline__ void c8_mfma(const i32x8_t& wf, const i32x8_t& xf, int one) {
-#if C8_NOSCALE
-  (void)one;
+__device__ __forceinline__ void c8_mfma(const i32x8_t& wf, const i32x8_t& xf) {
   asm volatile("v_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(16 * I), "i"(16 * I + 15) : C8_AGPRS);
-#else
-  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c3:%c4], %0, %1, a[%c3:%c4], %2, %2 op_sel_hi:[0,0,0]" ::"v"(wf), "v"(xf), "v"(one), "i"(16 * I), "i"(16 * I + 15)
-               : C8_AGPRS);
-#endif
 }
 template <int I>
-__device__ __forceinline__ void c8_mfma_first(const i32x8_t& wf, const i32x8_t& xf, int one) {  // first k-step of an output tile: C = 0
-#if C8_NOSCALE
-  (void)one;
+__device__ __forceinline__ void c8_mfma_first(const i32x8_t& wf, const i32x8_t& xf) {  // first k-step of an output tile: C = 0
   asm volatile("v_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, 0" ::"v"(wf), "v"(xf), "i"(16 * I), "i"(16 * I + 15) : C8_AGPRS);
-#else
-  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c3:%c4], %0, %1, 0, %2, %2 op_sel_hi:[0,0,0]" ::"v"(wf), "v"(xf), "v"(one), "i"(16 * I), "i"(16 * I + 15) : C8_AGPRS);
-#endif
 }
 template <int R>
 __device__ __forceinline__ float c8_acc_read() {
@@ -140,8 +129,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
   const int fl = lane & 31, fh = lane >> 5;
-  int one;
-  asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(one));
 
   // ---- this workgroup's output tiles (gemm256c.hip): positions v, v + vstep, .. < vend of the grouped tile order; XCD x (= blockIdx % 8) owns the
   //      contiguous chunk x of that order, its workgroups take the chunk's positions round-robin
@@ -343,8 +330,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int m = n >> 2, ks = m >> 4, xb = (m >> 2) & 3, wb = m & 3;
         const i32x8_t wf = __builtin_shufflevector(fw[ks][wb][0], fw[ks][wb][1], 0, 1, 2, 3, 4, 5, 6, 7);
         const i32x8_t xf = __builtin_shufflevector(fx[ks][xb][0], fx[ks][xb][1], 0, 1, 2, 3, 4, 5, 6, 7);
-        if constexpr (FIRST && ks == 0) c8_mfma_first<xb * 4 + wb>(wf, xf, one);
-        else c8_mfma<xb * 4 + wb>(wf, xf, one);
+        if constexpr (FIRST && ks == 0) c8_mfma_first<xb * 4 + wb>(wf, xf);
+        else c8_mfma<xb * 4 + wb>(wf, xf);
       }
       if constexpr (n < 32 && (n & 1) == 0) C8_READ(n >> 1, ST, 1)  // k-step 1 of this tile
       // the last 16 - C8_EARLY pieces of tile t+1 (its stage was freed by the previous tile's first barrier)

@@ -51,6 +51,14 @@ extern "C" __attribute__((visibility("default"))) const char* x2v_last_error(voi
 
 extern "C" __attribute__((visibility("default"))) const char* x2v_version(void) { return "x2v-hip 0.1.0 (gfx950)"; }
 
+extern "C" __attribute__((visibility("default"))) int x2v_switches(char* buf, int buf_len) {
+  X2V_REQUIRE(buf != nullptr && buf_len > 0, X2V_E_ARG, "x2v_switches: no buffer");
+  const int n = snprintf(buf, (size_t)buf_len, "X2V_GEMM_CONTINUOUS=%d X2V_GEMM_FP8_CONTINUOUS=%d X2V_ATTN_MAP=%d X2V_ATTN_ROT=%d", gemm_continuous_switch(),
+                         gemm_fp8_continuous_switch(), attn_map_switch(), attn_rot_switch());
+  X2V_REQUIRE(n > 0 && n < buf_len, X2V_E_ARG, "x2v_switches: buffer of %d bytes too small", buf_len);
+  return X2V_OK;
+}
+
 extern "C" __attribute__((visibility("default"))) int x2v_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len) {
   hipDeviceProp_t prop;
   int rc = check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");

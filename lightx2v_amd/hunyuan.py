@@ -207,7 +207,7 @@ class HunyuanTransformerInfer:
         Needs operators that take block-strided operands (the bf16 class) and head blocks that are whole K tiles."""
         pa = self.parallel_attention
         return (pa is not None and hasattr(pa, "attend_blocked") and self._qs != 1.0 and pa.blocked_ok(self.hidden_size, self.mlp_hidden_dim)
-                and all(getattr(o, "accepts_blocked", False) for o in ops))
+                and all(getattr(o, "accepts_blocked", False) and not hasattr(o, "quantize_input") for o in ops))  # bf16 class only: the fused-QKV / cat layouts are not wired for w8a8
 
     def _attend_blocked(self, bufs, qkv_txt):
         D = self.hidden_size
@@ -361,7 +361,9 @@ class HunyuanTransformerInferTeaCaching(HunyuanTransformerInfer):
         """Under Ulysses every rank holds its own image shard, and a decision taken from the local shard can differ between ranks right at the
         threshold — one rank would skip the block stack (no all-to-all) while the others wait in it: a hang (the reference, whose ranks decide
         locally in feature_caching/transformer_infer.py:21-50, has the same hazard).  Here the numerator and denominator of the relative L1 change
-        are summed over the sequence-parallel group first, so all ranks see one number (shards are equal-sized: ratio of sums = ratio of means).
+        are summed over the sequence-parallel group first, so all ranks see one number: the ratio of the GLOBAL sums, which is the ratio of the global
+        means whatever the shard sizes are (both sums run over the same element count).  It is the fp32 form of the single-GPU bf16 mean ratio: a
+        decision within bf16 rounding of the threshold may differ from the single-GPU run's (tests/test_dist_cpu.py pins decisions on a fixture).
         None when not sharded (the single-GPU arithmetic, pinned to the reference fixture, stays as it is)."""
         import torch.distributed as dist
 

@@ -27,6 +27,8 @@ PROTOTYPES = {
     "x2v_last_error": [],
     "x2v_version": [],
     "x2v_device_info": [_i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32],
+    "x2v_switches": [ctypes.c_char_p, _i32],
+    "x2v_quant_fp8_rowwise_blocked": [_c_void_p, _i64, _i32, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p],
     "x2v_rmsnorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
     "x2v_layernorm_bf16": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
     "x2v_layernorm_bf16_variant": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _f32, _i32, _c_void_p],
@@ -103,6 +105,13 @@ _inited = set()
 
 def version():
     return _lib.x2v_version().decode()
+
+
+def switches():
+    """The library's process-wide A/B switches (effective values, latched from the environment at first use) as a dict — x2v_switches."""
+    buf = ctypes.create_string_buffer(256)
+    _check(_lib.x2v_switches(buf, 256), "x2v_switches")
+    return {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split())}
 
 
 def _check(rc, what):
@@ -393,7 +402,7 @@ def gemm_vt(x, weight_nk, bias, num_heads):
     if w2.shape[1] != K or N != num_heads * 128:
         raise X2VError(f"gemm_vt: x [M,{K}] vs weight [{N},{w2.shape[1]}] for {num_heads} heads of 128")
     init()
-    if M == 0 or _lib.x2v_gemm_kernel_choice(M, N, K, x2.stride(0), w2.stride(0), 0) != 3:
+    if M == 0 or (_lib.x2v_gemm_kernel_choice(M, N, K, x2.stride(0), w2.stride(0), 0) & 0xff) != 3:
         return transpose_heads(gemm(x2, w2, bias), num_heads)
     ldvt = (M + 63) // 64 * 64
     vt = torch.empty((num_heads, ldvt // 64, 128, 64), dtype=torch.bfloat16, device=x.device)
@@ -401,13 +410,14 @@ def gemm_vt(x, weight_nk, bias, num_heads):
     return vt
 
 
-def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False):
-    """1 = 128x128 kernel, 2 = the 256x256 fp8 kernels (continuous / ping-pong, same bits), 3 = 256x256 single-stream kernel (bf16): what variant 0 launches for
-    this shape (x2v_gemm_kernel_choice)."""
+def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False, with_form=False):
+    """Tile family variant 0 launches for this shape (x2v_gemm_kernel_choice): 1 = 128x128 kernel, 2 = the 256x256 fp8 kernels, 3 = the 256x256
+    single-stream kernel (bf16).  with_form: (family, continuous) — continuous = the continuous-pipeline form (gemm256c / gemm256c8) runs for a
+    row-major y, else one tile per workgroup / ping-pong (same bits)."""
     rc = _lib.x2v_gemm_kernel_choice(M, N, K, K if ldx is None else ldx, K if ldw is None else ldw, int(fp8))
     if rc < 0:
         raise X2VError(f"gemm_kernel_choice: bad shape M={M} N={N} K={K}")
-    return rc
+    return (rc & 0xff, bool(rc & 0x100)) if with_form else rc & 0xff
 
 
 def attn_vt_launch_plan(Sq, Sk, num_heads, batch=1, stagger=False):
@@ -482,14 +492,21 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
 
 
 def quant_fp8_rowwise(x):
-    x2 = _row2d(_bf16(x, "x"), "x")
-    M, K = x2.shape
+    """(e4m3 codes [M, K] row-major, fp32 scales [M, 1]) of a bf16 x [M, K] — or of a K-blocked x [B, M, K/B] (the Ulysses head->seq receive
+    buffer; x2v_quant_fp8_rowwise_blocked: the codes come out row-major, the de-blocking rides in the quantisation pass)."""
+    if x.dim() == 3:
+        kb, kbs, ldx = _blocks3d(_bf16(x, "x"), "x")
+        M, K = x.shape[1], kb * x.shape[0]
+        x2 = x
+    else:
+        x2 = _row2d(_bf16(x, "x"), "x")
+        (M, K), kb, kbs, ldx = x2.shape, 0, 0, x2.stride(0)
     xq = torch.empty((M, K), dtype=torch.float8_e4m3fn, device=x.device)
     s = torch.empty((M, 1), dtype=torch.float32, device=x.device)
     init()
     if M == 0:
         return xq, s
-    _check(_lib.x2v_quant_fp8_rowwise(_p(x2), x2.stride(0), _p(xq), xq.stride(0), _p(s), M, K, _stream()), "quant_fp8_rowwise")
+    _check(_lib.x2v_quant_fp8_rowwise_blocked(_p(x2), ldx, kb, kbs, _p(xq), xq.stride(0), _p(s), M, K, _stream()), "quant_fp8_rowwise")
     return xq, s
 
 

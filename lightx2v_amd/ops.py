@@ -102,6 +102,9 @@ class MMWeightFp8Hip(_Movable):
     or `weight_auto_quant` from bf16 (:167-173); per-token dynamic activation quant (:236-245); scaled GEMM."""
 
     _tensor_attrs = ("weight", "weight_scale", "bias")
+    # apply() takes the Ulysses exchange buffers in place (round 5): an N-blocked 3-D `out` goes to x2v_gemm_fp8_blocked, a K-blocked 3-D bf16
+    # input is de-blocked by its quantisation pass (lib.quant_fp8_rowwise -> x2v_quant_fp8_rowwise_blocked) and multiplied row-major
+    accepts_blocked = True
 
     def __init__(self, weight_name, bias_name, lazy_load=False, lazy_load_file=None):
         self.weight_name, self.bias_name = weight_name, bias_name
@@ -145,6 +148,8 @@ class MMWeightFp8Hip(_Movable):
         w, sw, b = self.weight, self.weight_scale, self.bias
         if row_slice is not None:
             w, sw, b = w[row_slice], sw[row_slice], (None if b is None else b[row_slice])
+        if out is not None and out.dim() == 3:  # N-blocked y: a seq->head send buffer [N, S/N, (H/N) d]
+            return lib.gemm_fp8_blocked(xq, sx, w, sw, b, epilogue=epilogue, out=out)
         return lib.gemm_fp8(xq, sx, w, sw, b, epilogue=epilogue, resid=resid, gate=gate, out=out)
 
     def state_dict(self, destination=None):
@@ -394,9 +399,16 @@ class PatchEmbedConv3dHip(MMWeightHip):
         super().load(weight_dict)
         # the GEMM kernels advance K in 64-element tiles: a patch of C*pt*ph*pw values that is not a multiple of 64 (i2v: 36 channels x 4 = 144) is
         # zero-padded on both operands — the padding adds exact zeros to the fp32 sums, the result does not change
-        self._k = self.weight.shape[1]
+        self._k, self._ckpt_shape = self.weight.shape[1], tuple(w.shape)
         if self._k % 64:
             self.weight = torch.nn.functional.pad(self.weight, (0, 64 - self._k % 64)).contiguous()
+
+    def state_dict(self, destination=None):
+        """The checkpoint's tensor back: the K padding of `load` is an operand detail of the GEMM, not part of the parameter — without this
+        an i2v round trip exported [D, 192] under patch_embedding.weight instead of [D, 36, 1, 2, 2]."""
+        destination = super().state_dict(destination)
+        destination[self.weight_name] = destination[self.weight_name][:, : self._k].reshape(self._ckpt_shape).contiguous()
+        return destination
 
     def apply_tokens(self, input_tensor):
         """[1, C, T, H, W] → token-major [S, D] (what the fused driver consumes)."""

@@ -17,6 +17,9 @@ WAN_DIMS = {
     "wan-tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_len=32, text_dim=64),
     # 8 heads: the smallest model a group of 8 ranks can share (Ulysses needs heads % N == 0); plumbing runs of the N-rank code paths
     "wan-tiny-h8": dict(dim=1024, ffn_dim=2048, num_heads=8, num_layers=2, text_len=32, text_dim=64),
+    # Wan2.1-I2V-14B (the configuration the reference publishes its numbers for, docs/EN/source/getting_started/benchmark_source.md:29-57): the 14B
+    # DiT with the 36-channel patch embedding, the CLIP ViT-H/14 feature MLP (1280 -> D) and per block k_img / v_img / norm_k_img
+    "wan2.1-14b-i2v": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, text_len=512, text_dim=4096, clip_dim=1280, task="i2v"),
     "wan-tiny-i2v": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_len=32, text_dim=64, clip_dim=64, task="i2v"),
 }
 
@@ -29,6 +32,10 @@ WORKLOADS = {
     "wan14b_480px81f": dict(model="wan2.1-14b", target_shape=(16, 21, 60, 104), frames=81),
     "wan1.3b_720px81f": dict(model="wan2.1-1.3b", target_shape=(16, 21, 90, 160), frames=81),
     "wan1.3b_480px81f": dict(model="wan2.1-1.3b", target_shape=(16, 21, 60, 104), frames=81),  # 32 760 tokens x 12 heads: 1536 attention workgroups
+    # the reference's published benchmark (configs/bench/lightx2v_2.json: I2V-14B, 81 frames, 40 steps, CFG scale 5, shift 5) at its two resolutions
+    "wan14b_i2v_720px81f": dict(model="wan2.1-14b-i2v", target_shape=(16, 21, 90, 160), frames=81, infer_steps=40, sample_guide_scale=5.0, sample_shift=5.0),
+    "wan14b_i2v_480px81f": dict(model="wan2.1-14b-i2v", target_shape=(16, 21, 60, 104), frames=81, infer_steps=40, sample_guide_scale=5.0, sample_shift=5.0),
+    "wan-tiny-i2v": dict(model="wan-tiny-i2v", target_shape=(16, 3, 8, 8), frames=9),
     "wan-tiny": dict(model="wan-tiny", target_shape=(16, 3, 8, 8), frames=9),
     "wan-tiny-h8": dict(model="wan-tiny-h8", target_shape=(16, 3, 16, 12), frames=9),  # 144 tokens: divisible by 8
 }
@@ -361,3 +368,21 @@ def synth_hunyuan_vae_weights(cfg, seed=0, device="cpu"):
     norm("decoder.conv_norm_out", cfg["block_out_channels"][0])
     conv("decoder.conv_out.conv", 3, cfg["block_out_channels"][0], 3, gain=0.5)
     return sd
+
+
+def workload_setup(name, seed=0, device="cuda"):
+    """Everything bench.py / tools/e2e.py need for a named workload: (dims, config overrides, weight dict, latents, inputs dict).  t2v: seeded
+    weights + text context; i2v (dims["task"] == "i2v"): the i2v checkpoint, the config keys of configs/bench/lightx2v_2.json and the seeded
+    CLIP / VAE-encode stand-ins of `synth_i2v_inputs` (the encoders are out of scope, SURVEY §2.1: their outputs are inputs here)."""
+    wl = WORKLOADS[name]
+    dims = WAN_DIMS[wl["model"]]
+    i2v = dims.get("task") == "i2v"
+    gen_device = device if str(device).startswith("cuda") else "cpu"
+    wd = (synth_wan_i2v_weights if i2v else synth_wan_weights)(dims, seed=seed, device=device, gen_device=gen_device)
+    lat, ctx, ctx_null = synth_inputs(dims, wl["target_shape"])
+    inputs = {"text_encoder_output": {"context": [c.to(device) for c in ctx], "context_null": [c.to(device) for c in ctx_null]}}
+    overrides = {k: wl[k] for k in ("sample_guide_scale", "sample_shift") if k in wl}
+    if i2v:
+        overrides.update(task="i2v", in_dim=36, cross_attn_2_type="hip_flash")
+        inputs["image_encoder_output"] = {k: v.to(device) for k, v in synth_i2v_inputs(dims, wl["target_shape"]).items()}
+    return dims, overrides, wd, lat, inputs

@@ -354,10 +354,10 @@ class WanTransformerInfer:
         if pa is not None and hasattr(pa, "attend_blocked") and x.is_cuda and self.blocked_exchange and self._blocked_ok(weights):
             # Ulysses without layout copies: the exchange buffers [N, S/N, (H/N)d] are kernel operands (ulysses.py)
             b = pa.buffers(s_local, x.shape[1], x.dtype, x.device)
-            weights.self_attn_v.apply(n1, out=b["sv"])  # v needs no norm / RoPE: projected first, straight into its send buffer,
+            weights.self_attn_v.apply(n1, out=b["sv"], **mmkw)  # v needs no norm / RoPE: projected first, straight into its send buffer,
             v_pending = pa.begin_exchange_blocked(b["sv"], b["rv"])  # and exchanged under the q / k projections and the norm+RoPE kernel
-            q = weights.self_attn_q.apply(n1)
-            k = weights.self_attn_k.apply(n1)
+            q = weights.self_attn_q.apply(n1, **mmkw)
+            k = weights.self_attn_k.apply(n1, **mmkw)
             lib.rmsnorm_rope_blocked(q, k, weights.self_attn_norm_q.weight, weights.self_attn_norm_k.weight, freqs, grid, self.num_heads, b["sq"], b["sk"], **rope_args)
             attn = pa.attend_blocked(b, self.num_heads, self.head_dim, timer=self._timed, variant=variant, v_pending=v_pending)
             return weights.self_attn_o.apply(attn, epilogue=lib.EPI_RESIDUAL, resid=x, gate=gate_msa)  # K-blocked x
@@ -399,7 +399,7 @@ class WanTransformerInfer:
 
     @staticmethod
     def _blocked_ok(weights):
-        """The copy-free Ulysses path needs operator objects whose apply() takes block-strided operands (the bf16 class)."""
+        """The copy-free Ulysses path needs operator objects whose apply() takes block-strided operands (the bf16 and the w8a8 classes)."""
         return all(getattr(getattr(weights, n), "accepts_blocked", False) for n in ("self_attn_v", "self_attn_o"))
 
     def infer_cross_attn(self, weights, x, context):

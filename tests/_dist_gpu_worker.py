@@ -48,9 +48,13 @@ def main():
     lat, ctx, ctx_null = synth.synth_inputs(dims, ts)
     inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
     outs, conds = {}, {}
+    # X2V_WORKER_FP8=1: the same run with the w8a8 operator class (mm_weight.py:287-319 restated): its N-blocked output (x2v_gemm_fp8_blocked) writes the
+    # seq->head send buffers, its quantisation pass de-blocks the head->seq receive buffer (x2v_quant_fp8_rowwise_blocked) — the copy-free path, round 5
+    fp8 = os.environ.get("X2V_WORKER_FP8") == "1"
+    extra = {"mm_config": {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}} if fp8 else {}
     for mode in ("single", "ulysses", "ulysses-sequential"):
         cfg = wan.default_config(dims, target_shape=ts, target_video_length=9, infer_steps=4, parallel_attn_type=None if mode == "single" else "ulysses",
-                                 cfg_branch_streams=(mode == "ulysses"))
+                                 cfg_branch_streams=(mode == "ulysses"), **extra)
         model = wan.WanModel(cfg, {k: v.cuda() for k, v in wd.items()})
         sch = scheduler.WanScheduler(cfg, device="cuda")
         sch.prepare(latents=lat)
@@ -69,6 +73,17 @@ def main():
         assert torch.isfinite(sch.latents).all()
     # the two CFG branches interleaved on two compute streams (the default) against the sequential order: same kernels on the same operands
     assert torch.equal(outs["ulysses"], outs["ulysses-sequential"]), "CFG-branch interleave changed the result"
+    if fp8:
+        # per-token activation scales and per-channel weight scales do not depend on how rows are partitioned: the sharded w8a8 forward is the
+        # single-GPU one on re-grouped tiles (the w8a8 forward itself is compared with the oracle in tests/test_gpu_model.py / test_gpu_full_size.py)
+        rel = ((outs["single"] - outs["ulysses"]).norm() / outs["single"].norm()).item()
+        relc = ((conds["single"] - conds["ulysses"]).norm() / conds["single"].norm()).item()
+        assert rel < 5e-3 and relc < 5e-3, f"rank {r}: w8a8 ulysses vs single-GPU relative L2 {rel:.3e} (conditional forward {relc:.3e})"
+        dist.barrier()
+        if r == 0:
+            print(f"DIST_GPU_OK rel={rel:.2e} (w8a8)")
+        dist.destroy_process_group()
+        return
     from oracle import wan_oracle as O
 
     ref = O.wan_model_infer(wd, dims, lat.to(torch.bfloat16), sch.timesteps[0].cpu(), ctx, ctx_null, cfg["sample_guide_scale"])

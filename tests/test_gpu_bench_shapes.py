@@ -423,3 +423,107 @@ def test_gemm_fp8_continuous_pipeline_equals_ping_pong(M, K, N):
             lib.gemm_fp8(xo, sx, wo, sw, b, variant=5)
         if lib.gemm_kernel_choice(M, N, K - 128, fp8=True) == 2:
             assert torch.equal(lib.gemm_fp8(xo, sx, wo, sw, b), lib.gemm_fp8(xo, sx, wo, sw, b, variant=2))
+
+
+@pytest.mark.parametrize("M,K,N,nb", [(300, 512, 256, 2), (4100, 2560, 5120, 4), (9450, 5120, 5120, 8), (9450, 5120, 13824, 8), (9450, 13824, 5120, 8)])
+def test_gemm_fp8_blocked_equals_row_major_and_the_oracle(M, K, N, nb):
+    """x2v_gemm_fp8_blocked (the entry had argument-validation tests only): the w8a8 GEMM on the Ulysses exchange buffers'
+    layouts — N-blocked y (what MMWeightFp8Hip.apply(out=3-D) launches for the q / k / v projections), K-blocked x codes, K-blocked x + gated
+    residual — at a 128x128-kernel shape, a mid shape and the 8-GPU rank shape M = 9450 of the three Wan-14B projections.  Legs: (1) the SAME BITS as
+    the row-major operator on the ping-pong kernel (variant 2), which is what the dispatcher's natural choice — the continuous kernel gemm256c8 since
+    round 5 — must reproduce on block-strided operands (profiles/r05_call1_*: 23 / 23 on both kernels at first contact); (2) the oracle's restated
+    mm_weight.py:236-245 + :310-318 on a row sample (<= 1 bf16 ulp on all but 0.2 % of the elements, the tolerance of test_gpu_full_size's w8a8 leg);
+    (3) rows around the blocks untouched; (4) which kernel ran is asserted through x2v_gemm_kernel_choice's form bit."""
+    from lightx2v_amd import lib
+    from oracle import wan_oracle as O
+    from tests.util import assert_bf16_close
+
+    lib.init()
+    g = torch.Generator(device="cuda").manual_seed(11 + M + N)
+    x = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
+    xq, sx = lib.quant_fp8_rowwise(x)
+    wq, sw = lib.quant_fp8_rowwise(w)
+    b = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    res = torch.randn(M, N, generator=g, device="cuda").to(torch.bfloat16)
+    gate = (torch.randn(N, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    family, continuous = lib.gemm_kernel_choice(M, N, K, fp8=True, with_form=True)
+    assert continuous == (family == 2 and (K // 128) % 2 == 0 and K // 128 >= 4 and N % 256 == 0 and lib.switches()["X2V_GEMM_FP8_CONTINUOUS"] >= 1)
+    forced = 2 if family == 2 else 1
+    ref = lib.gemm_fp8(xq, sx, wq, sw, b, variant=forced)
+    ref_g = lib.gemm_fp8(xq, sx, wq, sw, b, epilogue=lib.EPI_GELU_TANH, variant=forced)
+    # leg 2 first: the row-major reference output itself against the oracle (codes are the HIP quantiser's: its own oracle leg is test_gpu_ops.py)
+    rows = torch.randperm(M, generator=torch.Generator().manual_seed(1))[:64]
+    want = ((xq[rows.cuda()].float().cpu() @ wq.float().cpu().t()) * sx[rows.cuda()].cpu() * sw.cpu().t() + b.float().cpu()).to(torch.bfloat16)
+    assert_bf16_close(ref[rows.cuda()], want, ulps=1, atol=2e-3, bad_frac=2e-3, name=f"gemm_fp8 {M}x{K}x{N} vs oracle arithmetic")
+    assert_bf16_close(lib.gemm_fp8(*lib.quant_fp8_rowwise(x[rows.cuda()]), wq, sw, b), O.mm_fp8(x[rows.cuda()].cpu(), wq.cpu(), sw.cpu(), b.cpu()), ulps=1, atol=2e-3, bad_frac=2e-3,
+                      name=f"quant + gemm_fp8 {K}->{N} vs O.mm_fp8")
+    out = torch.full((nb, M + 3, N // nb), 7.0, dtype=torch.bfloat16, device="cuda")
+    lib.gemm_fp8_blocked(xq, sx, wq, sw, b, out=out[:, 1 : M + 1])
+    assert torch.equal(out[:, 1 : M + 1].transpose(0, 1).reshape(M, N), ref), "N-blocked y"
+    assert (out[:, 0] == 7).all() and (out[:, M + 1 :] == 7).all(), "N-blocked y: rows around the blocks written"
+    out2 = torch.empty((nb, M, N // nb), dtype=torch.bfloat16, device="cuda")
+    lib.gemm_fp8_blocked(xq, sx, wq, sw, b, epilogue=lib.EPI_GELU_TANH, out=out2)
+    assert torch.equal(out2.transpose(0, 1).reshape(M, N), ref_g), "N-blocked y + gelu"
+    if K % (nb * 128) == 0:
+        xb = xq.view(torch.uint8).view(M, nb, K // nb).transpose(0, 1).contiguous().view(torch.float8_e4m3fn)
+        assert torch.equal(lib.gemm_fp8_blocked(xb, sx, wq, sw, b), ref), "K-blocked x"
+        r1, r2 = res.clone(), res.clone()
+        lib.gemm_fp8_blocked(xb, sx, wq, sw, b, epilogue=lib.EPI_RESIDUAL, resid=r1, gate=gate)
+        lib.gemm_fp8(xq, sx, wq, sw, b, epilogue=lib.EPI_RESIDUAL, resid=r2, gate=gate, variant=forced)
+        assert torch.equal(r1, r2), "K-blocked x + gate-residual"
+    # the de-blocking quantisation pass (x2v_quant_fp8_rowwise_blocked): a K-blocked bf16 x gives the codes and scales of the row-major x
+    xbb = x.view(M, nb, K // nb).transpose(0, 1).contiguous()
+    q2, s2 = lib.quant_fp8_rowwise(xbb)
+    assert torch.equal(q2.view(torch.uint8), xq.view(torch.uint8)) and torch.equal(s2, sx)
+    pad = torch.zeros(nb, M + 2, K // nb + 8, dtype=torch.bfloat16, device="cuda")  # strided blocks: row stride and block stride both padded
+    pad[:, 1 : M + 1, : K // nb] = xbb
+    q3, s3 = lib.quant_fp8_rowwise(pad[:, 1 : M + 1, : K // nb])
+    assert torch.equal(q3.view(torch.uint8), xq.view(torch.uint8)) and torch.equal(s3, sx)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_gemm_continuous_forms_on_strided_operands(fp8):
+    """the equality tests of the continuous kernels used contiguous operands only.  Here ldx > K (x a column slice of a wider tensor: the
+    fused-QKV / cat views of the drivers), ldw > K and ldy > N (y a column slice: what a projection writing into a wider buffer does), for every
+    epilogue, bf16 and w8a8: continuous form (variant 5) == one-tile / ping-pong form (variant 4 / 2), columns around y untouched, and the residual
+    epilogue with ldr == ldy > N (the only residual layout the continuous form takes) equal as well."""
+    from lightx2v_amd import lib
+
+    lib.init()
+    M, K, N = 4100, 2560, 5120
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xw = torch.randn(M, K + 256, generator=g, device="cuda").to(torch.bfloat16)
+    ww = (torch.randn(N, K + 128, generator=g, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
+    x, w = xw[:, 128 : 128 + K], ww[:, :K]
+    b = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    gate = (torch.randn(N, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    resw = torch.randn(M, N + 512, generator=g, device="cuda").to(torch.bfloat16)
+    if fp8:
+        xq_c, sx = lib.quant_fp8_rowwise(x.contiguous())
+        wq_c, sw = lib.quant_fp8_rowwise(w.contiguous())
+        xqw = torch.zeros(M, K + 256, dtype=torch.uint8, device="cuda")
+        xqw[:, 128 : 128 + K] = xq_c.view(torch.uint8)
+        wqw = torch.zeros(N, K + 128, dtype=torch.uint8, device="cuda")
+        wqw[:, :K] = wq_c.view(torch.uint8)
+        xo, wo = xqw.view(torch.float8_e4m3fn)[:, 128 : 128 + K], wqw.view(torch.float8_e4m3fn)[:, :K]
+        run = lambda form, **kw: lib.gemm_fp8(xo, sx, wo, sw, b, variant=form, **kw)  # noqa: E731
+        forms = (2, 5, 0)
+    else:
+        run = lambda form, **kw: lib.gemm(x, w, b, variant=form, **kw)  # noqa: E731
+        forms = (4, 5, 0)
+    for epi in (lib.EPI_NONE, lib.EPI_GELU_TANH, lib.EPI_SILU):
+        outs = []
+        for form in forms:
+            yw = torch.full((M + 2, N + 512), 7.0, dtype=torch.bfloat16, device="cuda")
+            run(form, epilogue=epi, out=yw[1 : M + 1, 256 : 256 + N])
+            outs.append(yw)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (fp8, epi)
+        assert (outs[1][:, :256] == 7).all() and (outs[1][:, 256 + N :] == 7).all() and (outs[1][0] == 7).all() and (outs[1][-1] == 7).all()
+    outs = []
+    for form in forms:
+        r = resw.clone()
+        run(form, epilogue=lib.EPI_RESIDUAL, resid=r[:, 256 : 256 + N], gate=gate)
+        outs.append(r)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (fp8, "residual")
+    assert torch.equal(outs[1][:, :256], resw[:, :256]) and torch.equal(outs[1][:, 256 + N :], resw[:, 256 + N :])

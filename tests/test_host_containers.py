@@ -160,3 +160,20 @@ def test_cfg_form_by_size_rule():
     assert form("wan1.3b_256x256x17f") == "streams"
     assert cfg_form_by_size(256 * 170, 12) == "streams" and cfg_form_by_size(256 * 171, 12) == "pair"  # 2040 / 2052 workgroups: the one threshold
     assert cfg_form_by_size(256 * 170 + 1, 12) == "pair"  # a ragged last block counts
+
+
+def test_patch_embedding_state_dict_returns_the_checkpoint_tensor():
+    """ADVICE r4: PatchEmbedConv3dHip zero-pads its [D, C*4] GEMM operand to a multiple of 64 columns at load (i2v: 36 channels x 4 = 144 -> 192);
+    state_dict() must still export the checkpoint's [D, C, 1, 2, 2] tensor (conv3d.py:29-75 / weight_module.py:47-56 round trip)."""
+    import torch
+
+    from lightx2v_amd import ops
+
+    for c in (16, 36):
+        w = torch.randn(32, c, 1, 2, 2).to(torch.bfloat16)
+        b = torch.randn(32).to(torch.bfloat16)
+        op = ops.PatchEmbedConv3dHip("patch_embedding.weight", "patch_embedding.bias", stride=(1, 2, 2))
+        op.load({"patch_embedding.weight": w, "patch_embedding.bias": b})
+        assert op.weight.shape[1] % 64 == 0
+        sd = op.state_dict()
+        assert sd["patch_embedding.weight"].shape == w.shape and torch.equal(sd["patch_embedding.weight"], w) and torch.equal(sd["patch_embedding.bias"], b)

@@ -20,7 +20,8 @@ from lightx2v_amd import lib, scheduler, synth, vae, wan  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="wan14b_720px81f")
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=0, help="0 = the workload's own schedule length (50; 40 for the i2v benchmark workloads)")
+    ap.add_argument("--i2v", action="store_true", help="--workload wan14b_i2v_720px81f: the reference's published benchmark (I2V-14B, 40 steps, CFG 5, shift 5; configs/bench/lightx2v_2.json)")
     ap.add_argument("--fp8", action="store_true")
     ap.add_argument("--mxfp8", action="store_true")
     ap.add_argument("--distill", action="store_true", help="4-step distilled schedule, no CFG (BASELINE config #4)")
@@ -44,9 +45,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib.init(local_rank)
+    if a.i2v:
+        a.workload = "wan14b_i2v_720px81f"
     wl = synth.WORKLOADS[a.workload]
     dims = synth.WAN_DIMS[wl["model"]]
-    steps = 4 if a.distill else a.steps
+    steps = 4 if a.distill else (a.steps or wl.get("infer_steps", 50))
     extra = {}
     if a.fp8:
         extra["mm_config"] = {"mm_type": "W-fp8-channel-sym-A-fp8-channel-sym-dynamic-Hip", "weight_auto_quant": True}
@@ -63,13 +66,14 @@ def main():
         if dims["num_heads"] % world:
             raise SystemExit(f"Ulysses needs num_heads % N == 0 ({dims['num_heads']} heads, N={world})")
         extra["parallel_attn_type"] = "ulysses"
+    _, overrides, wd, lat, inputs = synth.workload_setup(a.workload, seed=0, device="cuda")  # i2v: the i2v checkpoint + seeded CLIP / VAE-encode stand-ins
+    extra = {**overrides, **extra}
     cfg = wan.default_config(dims, target_shape=wl["target_shape"], target_video_length=wl["frames"], infer_steps=steps, **extra)
-    model = wan.WanModel(cfg, synth.synth_wan_weights(dims, seed=0, device="cuda", gen_device="cuda"))
-    lat, ctx, ctx_null = synth.synth_inputs(dims, wl["target_shape"])
+    model = wan.WanModel(cfg, wd)
+    del wd
     sch = (scheduler.WanStepDistillScheduler if a.distill else scheduler.WanScheduler)(cfg, device="cuda")
     sch.prepare(latents=lat)
     model.set_scheduler(sch)
-    inputs = {"text_encoder_output": {"context": [c.cuda() for c in ctx], "context_null": [c.cuda() for c in ctx_null]}}
     decoder = vae.WanVAE(synth.synth_wan_vae_weights(dim=96, seed=0), dim=96, conv16=(True if a.vae16 else False if a.vae32 else "split"), parallel=world > 1)
     # warm-up outside the clock: one step on a scratch scheduler state (allocator pools, lazy tables) and a short decode
     sch.step_pre(0)
@@ -96,7 +100,7 @@ def main():
     t2 = time.perf_counter()
     assert torch.isfinite(video).all() and torch.isfinite(sch.latents).all()
     frames = wl["frames"]
-    rec = {"workload": a.workload, "n_gpus": world, "parallelism": f"ulysses-sp{world} + decode_dist" if world > 1 else "single", "steps": steps, "cfg": bool(cfg["enable_cfg"]), "gemm_dtype": "mxfp8" if a.mxfp8 else "fp8" if a.fp8 else "bf16",
+    rec = {"workload": a.workload, "task": dims.get("task", "t2v"), "guide_scale": cfg["sample_guide_scale"], "sample_shift": cfg["sample_shift"], "n_gpus": world, "parallelism": f"ulysses-sp{world} + decode_dist" if world > 1 else "single", "steps": steps, "cfg": bool(cfg["enable_cfg"]), "gemm_dtype": "mxfp8" if a.mxfp8 else "fp8" if a.fp8 else "bf16",
            "teacache_thresh": a.teacache, "vae_conv_operands": "fp16" if a.vae16 else "fp32" if a.vae32 else "fp16 hi/lo split (fp32-grade)", "denoise_s": t1 - t0, "ms_per_step": (t1 - t0) * 1e3 / steps, "vae_decode_s": t2 - t1, "total_s": t2 - t0,
            "frames": frames, "video_shape": list(video.shape), "fps_denoise_only": frames / (t1 - t0), "fps_with_vae": frames / (t2 - t0),
            "hbm_gb_peak": torch.cuda.max_memory_allocated() / 1e9, "data": "synthetic weights / latents / text embeddings"}
