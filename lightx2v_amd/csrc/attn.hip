@@ -368,12 +368,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   VTp += (int64_t)seq * bs.vt;
   O += (int64_t)seq * bs.o;
   constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
-  constexpr int DEPTH = 4;
+#ifndef X2V_A9_DEPTH
+#define X2V_A9_DEPTH 4  // fragment reads in flight ahead of their MFMAs (A/B builds)
+#endif
+#ifndef X2V_A9_PRIO
+#define X2V_A9_PRIO 0  // A/B builds: 0 = s_setprio 1 around every matrix half-step (what ships), 1 = no priority changes, 2 = static priority 1 for
+                       // the second-dispatched half of the waves (MI355X_MICROARCH.md "Two waves per SIMD" item 4), 3 = static for the first half
+#endif
+  constexpr int DEPTH = X2V_A9_DEPTH;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, qd = lane >> 4;
   const int64_t q0 = (int64_t)qblk * (NW * 32) + wid * 32;
+#if X2V_A9_PRIO == 2
+  if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#elif X2V_A9_PRIO == 3
+  if (wid < NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   const unsigned short* Kh = Kp + (int64_t)head * AT_D;
   const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;
 
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   {                                                                                                                      \
     const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                                  \
     const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    if (X2V_A9_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                                 \
     bf16x8_t fr[DEPTH];                                                                                                  \
     _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                        \
     _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                              \
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
       if (n + DEPTH < (N1_)) fr[(n - (N0_)) % DEPTH] = A9_FRAG(n + DEPTH);                                               \
       A9_SB();                                                                                                           \
     }                                                                                                                    \
-    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    if (X2V_A9_PRIO == 0) __builtin_amdgcn_s_setprio(0);                                                                 \
   }
   // vector half-step: softmax of the tile in sc -> packed bf16 P in pw.  Register r of sc[kt][g] is key 32 (kt >> 1) + 8 qd + 4 (kt & 1) + r.
 #define A9_SOFTMAX(LAST_)                                                                                                \
