@@ -475,13 +475,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #define A9_FRAG(N_)                                                                                                      \
   ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + (((N_) & 3) >> 1) * 8192 + ((N_) & 1) * 1024 + kbase[(N_) >> 2]) \
              : *reinterpret_cast<const bf16x8_t*>(vb + (((N_) - 16) & 7) * 2048 + vbase[((N_) - 16) >> 3]))
-#define A9_MATRIX(N0_, N1_, VB_, KB_)                                                                                    \
+#ifndef X2V_A9_LATE_PREFETCH
+#define X2V_A9_LATE_PREFETCH 1  // the late waves read their first DEPTH fragments BEFORE the barrier in front of their matrix half-step (0: A/B builds)
+#endif
+  // The first DEPTH fragment reads of a matrix half-step.  A half-step's operands are proven landed by the barrier behind the odd half-step
+  // (the issuing waves' vmcnt(0)): for the EARLY waves that is the barrier right in front of their matrix half-step — their first MFMA waits a
+  // full LDS latency behind it — but the LATE waves' matrix half-step starts one barrier later, so they issue these reads at the end of their
+  // vector half-step (A9_PREFETCH, in front of the even barrier; the buffers they read are not written during that half-step) and enter
+  // the matrix half-step with the fragments in registers.
+  bf16x8_t fr[DEPTH];
+#define A9_PREFETCH(N0_, VB_, KB_)                                                                                       \
+  {                                                                                                                      \
+    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                                  \
+    const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                                 \
+    _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                        \
+    A9_SB();                                                                                                             \
+  }
+#define A9_MATRIX_(N0_, N1_, VB_, KB_, PRE_)                                                                             \
   {                                                                                                                      \
     const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                                  \
     const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                                 \
     if (X2V_A9_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                                 \
-    bf16x8_t fr[DEPTH];                                                                                                  \
-    _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                        \
+    if (!(PRE_)) {                                                                                                       \
+      _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                      \
+    }                                                                                                                    \
     _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                              \
       const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                                       \
       if (n < 16) {                                                                                                      \
@@ -504,6 +521,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
     }                                                                                                                    \
     if (X2V_A9_PRIO == 0) __builtin_amdgcn_s_setprio(0);                                                                 \
   }
+#define A9_MATRIX(N0_, N1_, VB_, KB_) A9_MATRIX_(N0_, N1_, VB_, KB_, false)
+#define A9_MATRIX_PRE(N0_, N1_, VB_, KB_) A9_MATRIX_(N0_, N1_, VB_, KB_, X2V_A9_LATE_PREFETCH != 0)
+#define A9_PREFETCH_LATE(N0_, VB_, KB_) if (X2V_A9_LATE_PREFETCH) A9_PREFETCH(N0_, VB_, KB_)
   // vector half-step: softmax of the tile in sc -> packed bf16 P in pw.  Register r of sc[kt][g] is key 32 (kt >> 1) + 8 qd + 4 (kt & 1) + r.
 #define A9_SOFTMAX(LAST_)                                                                                                \
   {                                                                                                                      \
@@ -574,10 +594,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
     A9_NEXT_V()                                       \
   }                                                   \
   A9_SB();
-#define A9_BAR_EVEN() __syncthreads();
+  // Barriers are the bare instruction (an asm statement with a memory clobber: nothing moves across it in the compiler either), NOT __syncthreads():
+  // its workgroup-scope release fence makes hipcc wait for every outstanding VMEM operation of the wave — LDS-DMA pieces included — in front of the
+  // barrier, so the late waves' pieces of an even half-step had to LAND within that half-step (s_waitcnt vmcnt(0) in front of the even barrier, found in
+  // the ISA in round 5) instead of flying through the odd one as the protocol above intends; gfx950 barriers do not drain VMEM by themselves
+  // (MI355X_MICROARCH.md "Two waves per SIMD" item 7).  LDS needs no fence inside a CU: a piece is visible once its issuing wave's vmcnt says it
+  // landed, and the odd barrier publishes that to the other waves.  X2V_A9_FENCED_BARRIERS=1 (A/B builds) restores the old form.
+#ifndef X2V_A9_FENCED_BARRIERS
+#define X2V_A9_FENCED_BARRIERS 0
+#endif
+#if X2V_A9_FENCED_BARRIERS
+#define A9_BARRIER() __syncthreads();
+#else
+#define A9_BARRIER() asm volatile("s_barrier" ::: "memory");
+#endif
+#define A9_BAR_EVEN() A9_BARRIER()
 #define A9_BAR_ODD()                                   \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
-  __syncthreads();
+  A9_BARRIER()
   if (wid < NW / 2) {
     A9_MATRIX(0, 16, 0, 0)
     A9_BAR_EVEN()
@@ -606,14 +640,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
     while (t < nt - 1) {
       A9_ISSUE(t + 1)
       A9_SOFTMAX(false)
+      A9_PREFETCH_LATE(0, 0, 1)
       A9_BAR_EVEN()
-      A9_MATRIX(0, 32, 0, 1)
+      A9_MATRIX_PRE(0, 32, 0, 1)
       A9_BAR_ODD()
       if (++t >= nt - 1) break;
       A9_ISSUE(t + 1)
       A9_SOFTMAX(false)
+      A9_PREFETCH_LATE(0, 1, 0)
       A9_BAR_EVEN()
-      A9_MATRIX(0, 32, 1, 0)
+      A9_MATRIX_PRE(0, 32, 1, 0)
       A9_BAR_ODD()
       ++t;
     }
@@ -628,9 +664,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #undef A9_KOFF
 #undef A9_VOFF
 #undef A9_BAR_EVEN
+#undef A9_BARRIER
 #undef A9_BAR_ODD
 #undef A9_SOFTMAX
 #undef A9_MATRIX
+#undef A9_MATRIX_
+#undef A9_MATRIX_PRE
+#undef A9_PREFETCH
+#undef A9_PREFETCH_LATE
 #undef A9_FRAG
 #undef A9_SB
 #undef A9_DMA_K
