@@ -373,7 +373,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #endif
 #ifndef X2V_A9_PRIO
 #define X2V_A9_PRIO 0  // A/B builds: 0 = s_setprio 1 around every matrix half-step (what ships), 1 = no priority changes, 2 = static priority 1 for
-                       // the second-dispatched half of the waves (MI355X_MICROARCH.md "Two waves per SIMD" item 4), 3 = static for the first half
+                       // the second-dispatched half of the waves (MI355X_MICROARCH.md "Two waves per SIMD" item 4), 3 = static for the first half.
+                       // Measured in round 5 (profiles/r05_call2_*, 40 heads x 75 600, two rounds on one box): 0: 1372.1 / 1372.1 TFLOP/s, 1: 1371.6 /
+                       // 1371.5, 2: 1352.7 / 1347.6, 3: 1361.2 / 1358.8; fragment depth 6 instead of 4: 1374.5 / 1369.3 — priority is not a lever here
 #endif
   constexpr int DEPTH = X2V_A9_DEPTH;
   const int tid = threadIdx.x;
@@ -476,13 +478,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + (((N_) & 3) >> 1) * 8192 + ((N_) & 1) * 1024 + kbase[(N_) >> 2]) \
              : *reinterpret_cast<const bf16x8_t*>(vb + (((N_) - 16) & 7) * 2048 + vbase[((N_) - 16) >> 3]))
 #ifndef X2V_A9_LATE_PREFETCH
-#define X2V_A9_LATE_PREFETCH 1  // the late waves read their first DEPTH fragments BEFORE the barrier in front of their matrix half-step (0: A/B builds)
+#define X2V_A9_LATE_PREFETCH 0  // A/B builds: 1 = the late waves read their first DEPTH fragments BEFORE the barrier in front of their matrix half-step
 #endif
   // The first DEPTH fragment reads of a matrix half-step.  A half-step's operands are proven landed by the barrier behind the odd half-step
   // (the issuing waves' vmcnt(0)): for the EARLY waves that is the barrier right in front of their matrix half-step — their first MFMA waits a
-  // full LDS latency behind it — but the LATE waves' matrix half-step starts one barrier later, so they issue these reads at the end of their
-  // vector half-step (A9_PREFETCH, in front of the even barrier; the buffers they read are not written during that half-step) and enter
-  // the matrix half-step with the fragments in registers.
+  // full LDS latency behind it — but the LATE waves' matrix half-step starts one barrier later, so they COULD issue these reads at the end of
+  // their vector half-step (A9_PREFETCH, in front of the even barrier; the buffers they read are not written during that half-step) and enter
+  // the matrix half-step with the fragments in registers.  Measured in round 5 (profiles/r05_call3_*, A-B-A-B on one box, 40 heads x 75 600):
+  // with bare barriers +-0.3 % (1416-1420 vs 1423-1425 TFLOP/s standalone, 162.4 vs 162.9 ms in-step), with __syncthreads() -3 % — an exposed LDS
+  // latency per half-step is not what this kernel waits for: at the board's power limit the cycles it saves come back as a lower clock.  Off.
   bf16x8_t fr[DEPTH];
 #define A9_PREFETCH(N0_, VB_, KB_)                                                                                       \
   {                                                                                                                      \
@@ -594,14 +598,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
     A9_NEXT_V()                                       \
   }                                                   \
   A9_SB();
-  // Barriers are the bare instruction (an asm statement with a memory clobber: nothing moves across it in the compiler either), NOT __syncthreads():
-  // its workgroup-scope release fence makes hipcc wait for every outstanding VMEM operation of the wave — LDS-DMA pieces included — in front of the
-  // barrier, so the late waves' pieces of an even half-step had to LAND within that half-step (s_waitcnt vmcnt(0) in front of the even barrier, found in
-  // the ISA in round 5) instead of flying through the odd one as the protocol above intends; gfx950 barriers do not drain VMEM by themselves
-  // (MI355X_MICROARCH.md "Two waves per SIMD" item 7).  LDS needs no fence inside a CU: a piece is visible once its issuing wave's vmcnt says it
-  // landed, and the odd barrier publishes that to the other waves.  X2V_A9_FENCED_BARRIERS=1 (A/B builds) restores the old form.
+  // What the barriers really wait for (found in the ISA in round 5): __syncthreads() carries a workgroup-scope release fence, and for it hipcc drains
+  // every outstanding VMEM operation of the wave — LDS-DMA pieces included — in front of the barrier.  So the late waves' pieces of an even half-step
+  // LAND within that half-step (compiler-placed s_waitcnt vmcnt(0) in front of the even barrier) and the explicit wait behind the odd half-step is
+  // a no-op; the "two half-steps of flight" of the protocol above is one.  With the bare instruction instead (X2V_A9_FENCED_BARRIERS=0: an asm
+  // s_barrier with a memory clobber; gfx950 barriers do not drain VMEM by themselves, MI355X_MICROARCH.md "Two waves per SIMD" item 7) the pieces do
+  // fly through the odd half-step — parity tests green, and the launch time does not move (profiles/r05_call3_*: standalone 82.2-82.3 ms fenced vs
+  // 82.4-82.7 ms bare; in-step 162.8-163.0 vs 162.3-162.5 ms per paired launch): the kernel is not waiting for its operands.  The fenced form
+  // stays: same speed, and the compiler — not a clobber list — owns the LDS ordering.
 #ifndef X2V_A9_FENCED_BARRIERS
-#define X2V_A9_FENCED_BARRIERS 0
+#define X2V_A9_FENCED_BARRIERS 1
 #endif
 #if X2V_A9_FENCED_BARRIERS
 #define A9_BARRIER() __syncthreads();

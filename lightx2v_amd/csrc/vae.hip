@@ -659,6 +659,14 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 //     issues the next step's weights, then the next slab's halo (11 pieces per loader wave, padded rows masked) and waits vmcnt(11):
 //     the weights have landed, the halo flies on; later taps issue weights only and wait vmcnt(0) (the halo has had more than a whole
 //     step by then).
+#ifndef X2V_VH_FENCED_BARRIERS
+#define X2V_VH_FENCED_BARRIERS 0  // A/B builds: 1 = __syncthreads() as before round 5
+#endif
+#if X2V_VH_FENCED_BARRIERS
+#define VH_BARRIER() __syncthreads()
+#else
+#define VH_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
 constexpr int VH_TH = 8, VH_TW = 32, VH_HW = VH_TW + 2, VH_ROWS = 352, VH_A_BYTES = VH_ROWS * 128, VH_A_PIECES = VH_ROWS / 8 / 4;
 
 template <int NF>
@@ -771,7 +779,9 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         if (halo) stage_a((slab + 1) & 1, slab + 1);
         if (halo) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VH_A_PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's VMEM queue (s_waitcnt vmcnt(0), found in the
+        // ISA in round 5) in front of EVERY barrier, i.e. the halo that the counted wait above lets fly had to land within its first step after all
+        VH_BARRIER();
         bbuf ^= 1;
       }
     }
@@ -808,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef VH_LOAD
-      __syncthreads();
+      VH_BARRIER();
       bbuf ^= 1;
     }
   }
