@@ -655,10 +655,13 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 //   * LDS: halo image [352 rows][128 B] x 2 (row r = hy*34 + hx, chunk ^= (r >> 1) & 7 applied on the DMA source as everywhere),
 //     weight slab [32 NF][128 B] x 2.  Fragment row of lane fl for tap (dh, dw), image row 2 wid + mi: r = (2 wid + mi + dh)*34 + dw + fl;
 //     the swizzle depends on r, so the 8 fragment addresses are recomputed per tap (a few VALU against 8 NF MFMAs).
-//   * schedule: step = (slab, tap), one barrier per step, 4 compute waves + 4 loader waves (one of each per SIMD).  A loader's tap 0
-//     issues the next step's weights, then the next slab's halo (11 pieces per loader wave, padded rows masked) and waits vmcnt(11):
-//     the weights have landed, the halo flies on; later taps issue weights only and wait vmcnt(0) (the halo has had more than a whole
-//     step by then).
+//   * schedule: step = (slab, tap), one barrier per step, 4 compute waves + 4 loader waves (one of each per SIMD).  The weight slabs
+//     travel through a RING of VH_NB = 4 LDS slots: at step s a loader issues the weights of step s + 3 (and, on a slab's first tap, the
+//     next slab's halo: 11 pieces per loader wave, padded rows masked) and waits only until the weights of step s + 1 have landed — a
+//     counted vmcnt that leaves the two younger weight slabs (and, for its first three steps, the halo) in flight.  Round 5: with a
+//     two-slot ring every step waited for weights issued ONE step earlier, i.e. a step lasted an L2 round trip (~2200 cycles against the
+//     step's 1024 MFMA cycles: the 45 % matrix-pipe busy of the round-1 profile), and __syncthreads() in front of the barrier drained
+//     the halo as well (hipcc's VMEM drain for the release fence) — both found in the ISA.
 #ifndef X2V_VH_FENCED_BARRIERS
 #define X2V_VH_FENCED_BARRIERS 0  // A/B builds: 1 = __syncthreads() as before round 5
 #endif
@@ -667,6 +670,11 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #else
 #define VH_BARRIER() asm volatile("s_barrier" ::: "memory")
 #endif
+#ifndef X2V_VH_RING
+#define X2V_VH_RING 4  // weight-slab ring slots (A/B builds: 2 = the one-step-ahead form of rounds 1-4)
+#endif
+constexpr int VH_NB = X2V_VH_RING;
+static_assert(VH_NB == 2 || VH_NB == 4, "ring of 2 (one step ahead) or 4 (three steps ahead)");
 constexpr int VH_TH = 8, VH_TW = 32, VH_HW = VH_TW + 2, VH_ROWS = 352, VH_A_BYTES = VH_ROWS * 128, VH_A_PIECES = VH_ROWS / 8 / 4;
 
 template <int NF>
@@ -757,42 +765,61 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  const int nsteps = nslabs * 9;
+  constexpr int AHEAD = VH_NB - 1;  // weights of step s + AHEAD are issued at step s
+  auto stage_b_step = [&](int st) {
+    const int sl = st / 9;
+    stage_b(st & (VH_NB - 1), sl, st - sl * 9);
+  };
   if (loader) {
-    stage_b(0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) stage_b_step(j);  // nsteps >= 9 > AHEAD
     stage_a(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  int bbuf = 0;
   if (loader) {
-    // same step structure as the compute waves (one barrier per step): issue the next step's weights (and, on a slab's first tap, the
-    // next slab's halo), wait for the weights (the halo may fly for another step), meet the compute waves at the barrier
+    // same step structure as the compute waves (one barrier per step).  Step s: issue the weights of step s + AHEAD into their ring slot (its last
+    // reader was step s - 1, behind the previous barrier) and, on a slab's first tap, the next slab's halo; then wait until the weights of step
+    // s + 1 have landed.  LDS-DMA pieces retire in issue order, so that is "all but the pieces issued after them": AHEAD - 1 weight slabs (fewer at
+    // the tile's end) and, on taps 0..2, the halo issued on tap 0 (behind that step's weights) — on tap 3 the count drops and the halo is drained.
+    auto wait_for_next = [&](int young_w, bool young_halo) {
+      if (young_halo) {
+        if (young_w >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_INSTR + VH_A_PIECES) : "memory");
+        else if (young_w == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_INSTR + VH_A_PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VH_A_PIECES) : "memory");
+      } else {
+        if (young_w >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_INSTR) : "memory");
+        else if (young_w == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_INSTR) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    int st = 0;
     for (int slab = 0; slab < nslabs; ++slab) {
 #pragma unroll 1
-      for (int tap9 = 0; tap9 < 9; ++tap9) {
-        const bool last_step = slab + 1 == nslabs && tap9 == 8;
-        if (!last_step) {
-          if (tap9 == 8) stage_b(bbuf ^ 1, slab + 1, 0);
-          else stage_b(bbuf ^ 1, slab, tap9 + 1);
-        }
-        const bool halo = tap9 == 0 && slab + 1 < nslabs;
-        if (halo) stage_a((slab + 1) & 1, slab + 1);
-        if (halo) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VH_A_PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's VMEM queue (s_waitcnt vmcnt(0), found in the
-        // ISA in round 5) in front of EVERY barrier, i.e. the halo that the counted wait above lets fly had to land within its first step after all
+      for (int tap9 = 0; tap9 < 9; ++tap9, ++st) {
+        const bool issue = st + AHEAD < nsteps;
+        if (issue) stage_b_step(st + AHEAD);
+        const bool more_slabs = slab + 1 < nslabs;
+        if (tap9 == 0 && more_slabs) stage_a((slab + 1) & 1, slab + 1);
+        // weight slabs younger than step s + 1's: those of steps s + 2 .. s + AHEAD that exist
+        int young_w = 0;
+#pragma unroll
+        for (int j = 2; j <= AHEAD; ++j) young_w += (st + j < nsteps) ? 1 : 0;
+        wait_for_next(young_w, more_slabs && tap9 < AHEAD);
+        // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier
         VH_BARRIER();
-        bbuf ^= 1;
       }
     }
     continue;
   }
+  int st = 0;
   for (int slab = 0; slab < nslabs; ++slab) {
     const char* ab = smem + (slab & 1) * VH_A_BYTES;
 #pragma unroll 1
     for (int tap9 = 0; tap9 < 9; ++tap9) {
       const int dh = tap9 / 3, dw = tap9 - dh * 3;
-      const char* bb = smem + B_OFF + bbuf * B_BYTES;
+      const char* bb = smem + B_OFF + (st & (VH_NB - 1)) * B_BYTES;
       int ra[2], sw[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -819,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
       }
 #undef VH_LOAD
       VH_BARRIER();
-      bbuf ^= 1;
+      ++st;
     }
   }
 
@@ -1050,7 +1077,7 @@ static int launch_vconv16(const void* xp, int64_t fs, int64_t rs, int64_t ps, co
 template <int NF>
 static int launch_vconv16h(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
                            int Ww, int Cin, int Cout, int kt, int flags, hipStream_t st) {
-  constexpr int lds = 2 * VH_A_BYTES + 2 * 32 * NF * 128;
+  constexpr int lds = 2 * VH_A_BYTES + VH_NB * 32 * NF * 128;  // NF = 4, ring of 4: 152 KiB of the CU's 160
   {
     int rc = ensure_dynamic_lds((const void*)vae_conv16h_kernel<NF>, lds, "vae conv16h attr");
     if (rc != X2V_OK) return rc;
@@ -1066,7 +1093,7 @@ static int launch_vconv16h(const void* xp, int64_t fs, int64_t rs, int64_t ps, c
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return check_hip(hipErrorUnknown, "vae conv16h device query");
     n_cu = prop.multiProcessorCount;
   }
-  const unsigned grid = (unsigned)std::min<int64_t>(blocks, n_cu);  // one workgroup per CU (120 KiB of LDS each)
+  const unsigned grid = (unsigned)std::min<int64_t>(blocks, n_cu);  // one workgroup per CU (120-152 KiB of LDS each)
   hipLaunchKernelGGL((vae_conv16h_kernel<NF>), dim3(grid), dim3(512), lds, st, (const _Float16*)xp, fs, rs, ps, (const _Float16*)w, wrs, bias, resid, y, T,
                      Hh, Ww, Cin, Cout, kt, flags, ncol, tiles_x, tiles_y);
   X2V_LAUNCH_CHECK("vae_conv_f16 (halo) launch");
