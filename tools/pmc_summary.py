@@ -13,7 +13,7 @@ for f in files:
             name = row.get("Kernel_Name", "?")
             if "fill" in name or "memset" in name.lower():
                 continue
-            short = name.split("(")[0][-48:]
+            short = name.replace("(anonymous namespace)::", "").split("(")[0][-56:]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern, ctrs in acc.items():
     print(f"== {kern}")
