@@ -673,8 +673,16 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #ifndef X2V_VH_RING
 #define X2V_VH_RING 4  // weight-slab ring slots (A/B builds: 2 = the one-step-ahead form of rounds 1-4)
 #endif
+#ifndef X2V_VH_PREFETCH
+#define X2V_VH_PREFETCH (X2V_VH_RING >= 4)  // the compute waves read step s + 1's first fragments in front of step s's barrier (A/B builds: 0)
+#endif
+#ifndef X2V_VH_INTERLEAVE
+#define X2V_VH_INTERLEAVE 0  // A/B builds: 1 = one fragment read behind every MFMA instead of read blocks between MFMA blocks
+#endif
 constexpr int VH_NB = X2V_VH_RING;
+constexpr int VH_NEED = X2V_VH_PREFETCH ? 2 : 1;  // at step s the loaders wait for the weights of step s + VH_NEED
 static_assert(VH_NB == 2 || VH_NB == 4, "ring of 2 (one step ahead) or 4 (three steps ahead)");
+static_assert(VH_NEED <= VH_NB - 1, "the cross-step fragment prefetch needs the 4-slot ring");
 constexpr int VH_TH = 8, VH_TW = 32, VH_HW = VH_TW + 2, VH_ROWS = 352, VH_A_BYTES = VH_ROWS * 128, VH_A_PIECES = VH_ROWS / 8 / 4;
 
 template <int NF>
@@ -781,8 +789,10 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
   if (loader) {
     // same step structure as the compute waves (one barrier per step).  Step s: issue the weights of step s + AHEAD into their ring slot (its last
     // reader was step s - 1, behind the previous barrier) and, on a slab's first tap, the next slab's halo; then wait until the weights of step
-    // s + 1 have landed.  LDS-DMA pieces retire in issue order, so that is "all but the pieces issued after them": AHEAD - 1 weight slabs (fewer at
-    // the tile's end) and, on taps 0..2, the halo issued on tap 0 (behind that step's weights) — on tap 3 the count drops and the halo is drained.
+    // s + VH_NEED have landed (VH_NEED = 2: the compute waves read step s + 1's first fragments in front of THIS step's barrier, so those weights were
+    // published one barrier earlier).  LDS-DMA pieces retire in issue order, so that is "all but the pieces issued after them": AHEAD - VH_NEED weight
+    // slabs (fewer at the tile's end) and, on the first taps, the halo issued on tap 0 (behind that step's weights) — then the count drops and the halo
+    // is drained, long before the next slab's first fragments are read.
     auto wait_for_next = [&](int young_w, bool young_halo) {
       if (young_halo) {
         if (young_w >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_INSTR + VH_A_PIECES) : "memory");
@@ -802,53 +812,106 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         if (issue) stage_b_step(st + AHEAD);
         const bool more_slabs = slab + 1 < nslabs;
         if (tap9 == 0 && more_slabs) stage_a((slab + 1) & 1, slab + 1);
-        // weight slabs younger than step s + 1's: those of steps s + 2 .. s + AHEAD that exist
+        // weight slabs younger than step s + VH_NEED's: those of steps s + VH_NEED + 1 .. s + AHEAD that exist; the halo (issued on tap 0, behind
+        // that step's weights) is younger than them while tap9 <= AHEAD - VH_NEED
         int young_w = 0;
 #pragma unroll
-        for (int j = 2; j <= AHEAD; ++j) young_w += (st + j < nsteps) ? 1 : 0;
-        wait_for_next(young_w, more_slabs && tap9 < AHEAD);
+        for (int j = VH_NEED + 1; j <= AHEAD; ++j) young_w += (st + j < nsteps) ? 1 : 0;
+        wait_for_next(young_w, more_slabs && tap9 <= AHEAD - VH_NEED);
         // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier
         VH_BARRIER();
       }
     }
     continue;
   }
-  int st = 0;
-  for (int slab = 0; slab < nslabs; ++slab) {
-    const char* ab = smem + (slab & 1) * VH_A_BYTES;
-#pragma unroll 1
-    for (int tap9 = 0; tap9 < 9; ++tap9) {
-      const int dh = tap9 / 3, dw = tap9 - dh * 3;
-      const char* bb = smem + B_OFF + (st & (VH_NB - 1)) * B_BYTES;
-      int ra[2], sw[2];
+  // Compute waves.  Fragments of k-step ks + 1 are read before the MFMAs of k-step ks are issued (pinned: left to itself hipcc reads a k-step's
+  // fragments right in front of its MFMAs and the LDS latency is paid four times per step) — and, with VH_NEED = 2, the first fragments of step
+  // s + 1 before the MFMAs of step s's last k-step, i.e. in front of the barrier: the pipeline of fragment reads runs through the whole tile and no
+  // step starts by waiting an LDS round trip (round 5; PMC before: matrix pipe 50.5 % busy, ~1500 cycles per 768-cycle step).
+  struct Step {
+    const char *ab, *bb;
+    int ra[2], sw[2];
+  };
+  auto step_addr = [&](int sl, int tp, int stn) {
+    Step a;
+    const int dh = tp / 3, dw = tp - dh * 3;
+    a.ab = smem + (sl & 1) * VH_A_BYTES;
+    a.bb = smem + B_OFF + (stn & (VH_NB - 1)) * B_BYTES;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = (2 * wid + i + dh) * VH_HW + dw + fl;
-        ra[i] = r * ROWB;
-        sw[i] = (r >> 1) & (CPR - 1);
-      }
-      // fragments of k-step ks+1 are read before the MFMAs of k-step ks are issued (pinned: left to itself hipcc reads a k-step's
-      // fragments right in front of its MFMAs and the LDS latency is paid four times per step — 45 % matrix-pipe busy)
-      vc_half8_t xa[2][2], wb[2][NF];
-#define VH_LOAD(P_, KS_)                                                                                                           \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) xa[P_][i] = *reinterpret_cast<const vc_half8_t*>(ab + ra[i] + (((((KS_) << 1) | fh) ^ sw[i]) << 4)); \
-  _Pragma("unroll") for (int n = 0; n < NF; ++n) wb[P_][n] = *reinterpret_cast<const vc_half8_t*>(bb + n * 32 * ROWB + rd_b[KS_]);
-      VH_LOAD(0, 0)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) { VH_LOAD((ks + 1) & 1, ks + 1) }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#undef VH_LOAD
-      VH_BARRIER();
-      ++st;
+    for (int i = 0; i < 2; ++i) {
+      const int r = (2 * wid + i + dh) * VH_HW + dw + fl;
+      a.ra[i] = r * ROWB;
+      a.sw[i] = (r >> 1) & (CPR - 1);
     }
+    return a;
+  };
+  vc_half8_t xa[2][2], wb[2][NF];
+#define VH_LOAD(P_, KS_, A_)                                                                                                                \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) xa[P_][i] = *reinterpret_cast<const vc_half8_t*>((A_).ab + (A_).ra[i] + (((((KS_) << 1) | fh) ^ (A_).sw[i]) << 4)); \
+  _Pragma("unroll") for (int n = 0; n < NF; ++n) wb[P_][n] = *reinterpret_cast<const vc_half8_t*>((A_).bb + n * 32 * ROWB + rd_b[KS_]);
+  Step cur = step_addr(0, 0, 0);
+  if (X2V_VH_PREFETCH) { VH_LOAD(0, 0, cur) }
+  int slab = 0, tap9 = 0;
+#pragma unroll 1
+  for (int st = 0; st < nsteps; ++st) {
+    int nslab = slab, ntap = tap9 + 1;
+    if (ntap == 9) {
+      ntap = 0;
+      ++nslab;
+    }
+    const Step nxt = step_addr(nslab, ntap, st + 1);
+    if (!X2V_VH_PREFETCH) { VH_LOAD(0, 0, cur) }
+    if constexpr (X2V_VH_INTERLEAVE != 0 && NF < 4) {  // (NF = 4: 128 accumulators + two fragment sets leave no room for it: 12 spilled VGPRs)
+    // slot form: MFMA m of k-step ks is followed by fragment read m of the NEXT k-step (2 + NF reads for 2 NF MFMAs; the next step's first k-step behind
+    // this step's last one), pinned with sched_barrier — in block form (all reads, then all MFMAs) the 12 address / read instructions between two MFMA
+    // blocks drain the matrix pipe four times per step
+    // (behind the tile's last step the "next step" addresses still lie inside the LDS images: those reads are harmless and unused — no branch)
+    constexpr bool more = X2V_VH_PREFETCH != 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int m = 0; m < 2 * NF; ++m) {
+        const int i = m / NF, n = m - i * NF;
+        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
+        // read r of the next k-step: 0 = xa[0], 1 .. NF = wb[0 .. NF-1], NF + 1 = xa[1]; slot m carries read m (the last slot every read that is left: NF = 1)
+#pragma unroll
+        for (int r = m; r < (m == 2 * NF - 1 ? 2 + NF : m + 1); ++r) {
+          if (r < 2 + NF && (ks < 3 || more)) {
+            const int P = (ks + 1) & 1, KS = (ks + 1) & 3;
+            const Step& A = ks < 3 ? cur : nxt;
+            if (r == 0 || r == NF + 1) {
+              const int ii = r == 0 ? 0 : 1;
+              xa[P][ii] = *reinterpret_cast<const vc_half8_t*>(A.ab + A.ra[ii] + ((((KS << 1) | fh) ^ A.sw[ii]) << 4));
+            } else {
+              wb[P][r - 1] = *reinterpret_cast<const vc_half8_t*>(A.bb + (r - 1) * 32 * ROWB + rd_b[KS]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    } else {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+        VH_LOAD((ks + 1) & 1, ks + 1, cur)
+      } else if (X2V_VH_PREFETCH) {  // behind the tile's last step these addresses still lie inside the LDS images: harmless, unused
+        VH_LOAD(0, 0, nxt)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    }
+    VH_BARRIER();
+    cur = nxt;
+    slab = nslab;
+    tap9 = ntap;
   }
+#undef VH_LOAD
 
   // epilogue.  acc[i][n][r]: pixel (y0 + 2 wid + i, x0 + fl), cout co0 + n*32 + (r&3) + 8*(r>>2) + 4*fh
   const bool vec_ok = (Cout & 3) == 0;
