@@ -859,7 +859,8 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
       ntap = 0;
       ++nslab;
     }
-    const Step nxt = step_addr(nslab, ntap, st + 1);
+    Step nxt;
+    if constexpr (!(X2V_VH_INTERLEAVE != 0 && NF < 4)) nxt = step_addr(nslab, ntap, st + 1);
     if (!X2V_VH_PREFETCH) { VH_LOAD(0, 0, cur) }
     if constexpr (X2V_VH_INTERLEAVE != 0 && NF < 4) {  // (NF = 4: 128 accumulators + two fragment sets leave no room for it: 12 spilled VGPRs)
     // slot form: MFMA m of k-step ks is followed by fragment read m of the NEXT k-step (2 + NF reads for 2 NF MFMAs; the next step's first k-step behind
@@ -873,6 +874,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
       for (int m = 0; m < 2 * NF; ++m) {
         const int i = m / NF, n = m - i * NF;
         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
+        if (ks == 1 && m == 2 * NF - 1) nxt = step_addr(nslab, ntap, st + 1);  // the next step's addresses: ~25 VALU / SALU, under k-step 1's last MFMA
         // read r of the next k-step: 0 = xa[0], 1 .. NF = wb[0 .. NF-1], NF + 1 = xa[1]; slot m carries read m (the last slot every read that is left: NF = 1)
 #pragma unroll
         for (int r = m; r < (m == 2 * NF - 1 ? 2 + NF : m + 1); ++r) {
