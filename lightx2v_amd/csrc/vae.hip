@@ -676,6 +676,9 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #ifndef X2V_VH_PREFETCH
 #define X2V_VH_PREFETCH (X2V_VH_RING >= 4)  // the compute waves read step s + 1's first fragments in front of step s's barrier (A/B builds: 0)
 #endif
+#ifndef X2V_VH_PROBE
+#define X2V_VH_PROBE 0  // TIMING PROBES (results invalid): 1 = no halo after a tile's first, 2 = no weight slabs after the prologue, 4 = no MFMAs, 8 = no per-step barriers
+#endif
 #ifndef X2V_VH_INTERLEAVE
 #define X2V_VH_INTERLEAVE 0  // A/B builds: 1 = one fragment read behind every MFMA instead of read blocks between MFMA blocks
 #endif
@@ -809,17 +812,18 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
 #pragma unroll 1
       for (int tap9 = 0; tap9 < 9; ++tap9, ++st) {
         const bool issue = st + AHEAD < nsteps;
-        if (issue) stage_b_step(st + AHEAD);
-        const bool more_slabs = slab + 1 < nslabs;
+        if (issue && !(X2V_VH_PROBE & 2)) stage_b_step(st + AHEAD);
+        const bool more_slabs = slab + 1 < nslabs && !(X2V_VH_PROBE & 1);
         if (tap9 == 0 && more_slabs) stage_a((slab + 1) & 1, slab + 1);
         // weight slabs younger than step s + VH_NEED's: those of steps s + VH_NEED + 1 .. s + AHEAD that exist; the halo (issued on tap 0, behind
         // that step's weights) is younger than them while tap9 <= AHEAD - VH_NEED
         int young_w = 0;
 #pragma unroll
         for (int j = VH_NEED + 1; j <= AHEAD; ++j) young_w += (st + j < nsteps) ? 1 : 0;
+        if (X2V_VH_PROBE & 2) young_w = 0;
         wait_for_next(young_w, more_slabs && tap9 <= AHEAD - VH_NEED);
         // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier
-        VH_BARRIER();
+        if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
       }
     }
     continue;
@@ -873,7 +877,8 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
 #pragma unroll
       for (int m = 0; m < 2 * NF; ++m) {
         const int i = m / NF, n = m - i * NF;
-        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
+        if (!(X2V_VH_PROBE & 4)) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
+        else asm volatile("" ::"v"(wb[ks & 1][n]), "v"(xa[ks & 1][i]));
         if (ks == 1 && m == 2 * NF - 1) nxt = step_addr(nslab, ntap, st + 1);  // the next step's addresses: ~25 VALU / SALU, under k-step 1's last MFMA
         // read r of the next k-step: 0 = xa[0], 1 .. NF = wb[0 .. NF-1], NF + 1 = xa[1]; slot m carries read m (the last slot every read that is left: NF = 1)
 #pragma unroll
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-    VH_BARRIER();
+    if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
     cur = nxt;
     slab = nslab;
     tap9 = ntap;
