@@ -680,7 +680,13 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #define X2V_VH_PROBE 0  // TIMING PROBES (results invalid): 1 = no halo after a tile's first, 2 = no weight slabs after the prologue, 4 = no MFMAs, 8 = no per-step barriers
 #endif
 #ifndef X2V_VH_INTERLEAVE
-#define X2V_VH_INTERLEAVE 0  // A/B builds: 1 = one fragment read behind every MFMA instead of read blocks between MFMA blocks
+#define X2V_VH_INTERLEAVE 1  // one fragment read behind every MFMA (slot form; A/B builds: 0 = read blocks between MFMA blocks)
+#endif
+#ifndef X2V_VH_HALO_SPREAD
+#define X2V_VH_HALO_SPREAD 1  // a slab's halo pieces spread over taps 0..5 (A/B builds: 0 = all on tap 0)
+#endif
+#ifndef X2V_VH_DIST
+#define X2V_VH_DIST 2  // slot form: k-steps of fragment read-ahead (A/B builds: 1)
 #endif
 constexpr int VH_NB = X2V_VH_RING;
 constexpr int VH_NEED = X2V_VH_PREFETCH ? 2 : 1;  // at step s the loaders wait for the weights of step s + VH_NEED
@@ -748,12 +754,13 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
   }
   const int kchunks = Cin / 64;
   const int nslabs = kt * kchunks;  // (dt, kc)
-  auto stage_a = [&](int buf, int slab) {
+  auto stage_a = [&](int buf, int slab, int p0 = 0, int p1 = VH_A_PIECES) {  // this loader wave's halo pieces [p0, p1) of a slab
     const int dt = slab / kchunks, kc = slab - dt * kchunks;
     const unsigned xso = (unsigned)(((int64_t)dt * x_frame_stride + (int64_t)kc * 64) * 2);
     char* as = smem + buf * VH_A_BYTES + wid * (VH_A_PIECES * 1024);
 #pragma unroll
-    for (int i = 0; i < VH_A_PIECES; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (v_lds_ptr_t)(as + i * 1024), 16, a_voff[i], xso, 0, 0);
+    for (int i = 0; i < VH_A_PIECES; ++i)
+      if (i >= p0 && i < p1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (v_lds_ptr_t)(as + i * 1024), 16, a_voff[i], xso, 0, 0);
   };
   auto stage_b = [&](int buf, int slab, int tap9) {
     const int dt = slab / kchunks, kc = slab - dt * kchunks;
@@ -796,32 +803,48 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
     // published one barrier earlier).  LDS-DMA pieces retire in issue order, so that is "all but the pieces issued after them": AHEAD - VH_NEED weight
     // slabs (fewer at the tile's end) and, on the first taps, the halo issued on tap 0 (behind that step's weights) — then the count drops and the halo
     // is drained, long before the next slab's first fragments are read.
-    auto wait_for_next = [&](int young_w, bool young_halo) {
-      if (young_halo) {
-        if (young_w >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_INSTR + VH_A_PIECES) : "memory");
-        else if (young_w == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_INSTR + VH_A_PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VH_A_PIECES) : "memory");
-      } else {
-        if (young_w >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_INSTR) : "memory");
-        else if (young_w == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_INSTR) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Halo pieces per tap (X2V_VH_HALO_SPREAD, round 5): two per tap on taps 0..4 and one on tap 5 instead of all eleven on tap 0 — a piece costs the
+    // issuing wave 60-185 cycles (MI355X_MICROARCH.md), so the burst made every ninth step ~1000 cycles longer than the 768 its MFMAs need
+    // (knock-out probe, profiles/r05_call9_*: the decode without the halo traffic is 10 % shorter).
+    auto halo_pieces = [&](int j) -> int {  // pieces this wave issues in step j (behind that step's weights)
+      if (j < 0) return 0;
+      const int sl = j / 9, tp = j - sl * 9;
+      if (sl + 1 >= nslabs || (X2V_VH_PROBE & 1)) return 0;
+      if (!X2V_VH_HALO_SPREAD) return tp == 0 ? VH_A_PIECES : 0;
+      return tp < 5 ? 2 : tp == 5 ? VH_A_PIECES - 10 : 0;
+    };
+    auto weight_pieces = [&](int j) -> int { return (j + AHEAD < nsteps && !(X2V_VH_PROBE & 2)) ? B_INSTR : 0; };
+    auto vmcnt_wait = [&](int n) {
+      switch (n) {
+#define VH_WAITCASE(N_) case N_: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); break;
+        VH_WAITCASE(1) VH_WAITCASE(2) VH_WAITCASE(3) VH_WAITCASE(4) VH_WAITCASE(5) VH_WAITCASE(6) VH_WAITCASE(7) VH_WAITCASE(8) VH_WAITCASE(9) VH_WAITCASE(10)
+        VH_WAITCASE(11) VH_WAITCASE(12) VH_WAITCASE(13) VH_WAITCASE(14) VH_WAITCASE(15) VH_WAITCASE(16) VH_WAITCASE(17) VH_WAITCASE(18) VH_WAITCASE(19)
+#undef VH_WAITCASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       }
     };
     int st = 0;
     for (int slab = 0; slab < nslabs; ++slab) {
 #pragma unroll 1
       for (int tap9 = 0; tap9 < 9; ++tap9, ++st) {
-        const bool issue = st + AHEAD < nsteps;
-        if (issue && !(X2V_VH_PROBE & 2)) stage_b_step(st + AHEAD);
-        const bool more_slabs = slab + 1 < nslabs && !(X2V_VH_PROBE & 1);
-        if (tap9 == 0 && more_slabs) stage_a((slab + 1) & 1, slab + 1);
-        // weight slabs younger than step s + VH_NEED's: those of steps s + VH_NEED + 1 .. s + AHEAD that exist; the halo (issued on tap 0, behind
-        // that step's weights) is younger than them while tap9 <= AHEAD - VH_NEED
-        int young_w = 0;
+        if (weight_pieces(st)) stage_b_step(st + AHEAD);
+        const int hp = halo_pieces(st);
+        if (hp) {
+          const int p0 = X2V_VH_HALO_SPREAD ? 2 * tap9 : 0;
+          stage_a((slab + 1) & 1, slab + 1, p0, p0 + hp);
+        }
+        // what must have landed: the weights of step st + VH_NEED, issued first thing in step j0 = st + VH_NEED - AHEAD.  Pieces retire in issue order,
+        // so everything issued behind them may stay in flight: step j0's halo pieces, then weights + halo pieces of steps j0 + 1 .. st.  (At the tile's
+        // end, where no such weights exist, everything is drained; a slab's last halo pieces are behind a later step's weights within two steps,
+        // long before the next slab's first fragments are read.)
+        int allowed = 0;
+        if (st + VH_NEED < nsteps) {
+          const int j0 = st + VH_NEED - AHEAD;
+          allowed = halo_pieces(j0);
 #pragma unroll
-        for (int j = VH_NEED + 1; j <= AHEAD; ++j) young_w += (st + j < nsteps) ? 1 : 0;
-        if (X2V_VH_PROBE & 2) young_w = 0;
-        wait_for_next(young_w, more_slabs && tap9 <= AHEAD - VH_NEED);
+          for (int j = 1; j <= AHEAD - VH_NEED; ++j) allowed += weight_pieces(j0 + j) + halo_pieces(j0 + j);
+        }
+        vmcnt_wait(allowed);
         // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier
         if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
       }
@@ -849,76 +872,87 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
     }
     return a;
   };
-  vc_half8_t xa[2][2], wb[2][NF];
-#define VH_LOAD(P_, KS_, A_)                                                                                                                \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) xa[P_][i] = *reinterpret_cast<const vc_half8_t*>((A_).ab + (A_).ra[i] + (((((KS_) << 1) | fh) ^ (A_).sw[i]) << 4)); \
-  _Pragma("unroll") for (int n = 0; n < NF; ++n) wb[P_][n] = *reinterpret_cast<const vc_half8_t*>((A_).bb + n * 32 * ROWB + rd_b[KS_]);
+  // SLOT form (NF < 4): MFMA m of a k-step is followed by fragment read m of the k-step DIST ahead (2 + NF reads for 2 NF MFMAs), pinned with
+  // sched_barrier; the reads run DIST = 2 k-steps ahead through three fragment sets — across the step boundary, i.e. in front of the barrier (VH_NEED = 2:
+  // the next step's weights were published one barrier earlier).  Round 5, by knock-out probes (profiles/r05_call9_*): the kernel's time without its MFMAs
+  // was two thirds of its time with them — one k-step of read-ahead (128-160 cycles of cover) did not hide an LDS round trip under load, so the
+  // read pipeline, not the matrix pipe, set the step; and in BLOCK form (all reads of a k-step, then all its MFMAs; NF = 4, where 128 accumulators leave no
+  // room for a third fragment set) the read / address instructions between two MFMA blocks drain the matrix pipe four times per step.
+  constexpr bool SLOT = X2V_VH_INTERLEAVE != 0 && NF < 4;
+  constexpr bool PF = X2V_VH_PREFETCH != 0 && NF < 4;  // reads run on across the step boundary (NF = 4: no registers for it — every step starts with its own first reads)
+  constexpr int DIST = SLOT && PF ? X2V_VH_DIST : 1;  // k-steps of read-ahead
+  constexpr int NSET = DIST + 1;                                   // fragment sets
+  constexpr int UNR = NSET == 3 ? 3 : 1;                           // a step has 4 k-steps: the set phase advances by 4 mod NSET per step
+  static_assert(DIST == 1 || DIST == 2, "one or two k-steps of fragment read-ahead");
+  vc_half8_t xa[NSET][2], wb[NSET][NF];
+  // read r of k-step KS of the step addressed by A into fragment set S: r = 0: xa[0], 1 .. NF: wb[0 .. NF-1], NF + 1: xa[1]
+  auto frag_read = [&](int S, int KS, const Step& A, int r) {
+    if (r == 0 || r == NF + 1) {
+      const int ii = r == 0 ? 0 : 1;
+      xa[S][ii] = *reinterpret_cast<const vc_half8_t*>(A.ab + A.ra[ii] + ((((KS << 1) | fh) ^ A.sw[ii]) << 4));
+    } else {
+      wb[S][r - 1] = *reinterpret_cast<const vc_half8_t*>(A.bb + (r - 1) * 32 * ROWB + rd_b[KS]);
+    }
+  };
   Step cur = step_addr(0, 0, 0);
-  if (X2V_VH_PREFETCH) { VH_LOAD(0, 0, cur) }
+  if (PF) {  // the pipeline's head: the first DIST k-steps of the tile
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+#pragma unroll
+      for (int r = 0; r < 2 + NF; ++r) frag_read(d, d, cur, r);
+  }
   int slab = 0, tap9 = 0;
 #pragma unroll 1
-  for (int st = 0; st < nsteps; ++st) {
-    int nslab = slab, ntap = tap9 + 1;
-    if (ntap == 9) {
-      ntap = 0;
-      ++nslab;
-    }
-    Step nxt;
-    if constexpr (!(X2V_VH_INTERLEAVE != 0 && NF < 4)) nxt = step_addr(nslab, ntap, st + 1);
-    if (!X2V_VH_PREFETCH) { VH_LOAD(0, 0, cur) }
-    if constexpr (X2V_VH_INTERLEAVE != 0 && NF < 4) {  // (NF = 4: 128 accumulators + two fragment sets leave no room for it: 12 spilled VGPRs)
-    // slot form: MFMA m of k-step ks is followed by fragment read m of the NEXT k-step (2 + NF reads for 2 NF MFMAs; the next step's first k-step behind
-    // this step's last one), pinned with sched_barrier — in block form (all reads, then all MFMAs) the 12 address / read instructions between two MFMA
-    // blocks drain the matrix pipe four times per step
-    // (behind the tile's last step the "next step" addresses still lie inside the LDS images: those reads are harmless and unused — no branch)
-    constexpr bool more = X2V_VH_PREFETCH != 0;
+  for (int st = 0; st < nsteps; st += UNR) {  // nsteps is a multiple of 9
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int p = 0; p < UNR; ++p) {
+      int nslab = slab, ntap = tap9 + 1;
+      if (ntap == 9) {
+        ntap = 0;
+        ++nslab;
+      }
+      // (behind the tile's last step the "next step" addresses still lie inside the LDS images: those reads are harmless and unused — no branch)
+      const Step nxt = step_addr(nslab, ntap, st + p + 1);
+      if (!PF) {
 #pragma unroll
-      for (int m = 0; m < 2 * NF; ++m) {
-        const int i = m / NF, n = m - i * NF;
-        if (!(X2V_VH_PROBE & 4)) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
-        else asm volatile("" ::"v"(wb[ks & 1][n]), "v"(xa[ks & 1][i]));
-        if (ks == 1 && m == 2 * NF - 1) nxt = step_addr(nslab, ntap, st + 1);  // the next step's addresses: ~25 VALU / SALU, under k-step 1's last MFMA
-        // read r of the next k-step: 0 = xa[0], 1 .. NF = wb[0 .. NF-1], NF + 1 = xa[1]; slot m carries read m (the last slot every read that is left: NF = 1)
+        for (int r = 0; r < 2 + NF; ++r) frag_read(0, 0, cur, r);
+      }
 #pragma unroll
-        for (int r = m; r < (m == 2 * NF - 1 ? 2 + NF : m + 1); ++r) {
-          if (r < 2 + NF && (ks < 3 || more)) {
-            const int P = (ks + 1) & 1, KS = (ks + 1) & 3;
-            const Step& A = ks < 3 ? cur : nxt;
-            if (r == 0 || r == NF + 1) {
-              const int ii = r == 0 ? 0 : 1;
-              xa[P][ii] = *reinterpret_cast<const vc_half8_t*>(A.ab + A.ra[ii] + ((((KS << 1) | fh) ^ A.sw[ii]) << 4));
-            } else {
-              wb[P][r - 1] = *reinterpret_cast<const vc_half8_t*>(A.bb + (r - 1) * 32 * ROWB + rd_b[KS]);
-            }
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cs = (4 * p + ks) % NSET, ns = (4 * p + ks + DIST) % NSET;  // sets consumed / filled by this k-step
+        const int kn = ks + DIST;                                           // the k-step read now: of this step, or of the next one
+        const bool rd = kn < 4 || PF;
+        if constexpr (SLOT) {
+#pragma unroll
+          for (int m = 0; m < 2 * NF; ++m) {
+            const int i = m / NF, n = m - i * NF;
+            if (!(X2V_VH_PROBE & 4)) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cs][n], xa[cs][i], acc[i][n], 0, 0, 0);
+            else asm volatile("" ::"v"(wb[cs][n]), "v"(xa[cs][i]));
+            // slot m carries read m (the last slot every read that is left: NF = 1 has 3 reads for 2 MFMAs)
+#pragma unroll
+            for (int r = m; r < (m == 2 * NF - 1 ? 2 + NF : m + 1); ++r)
+              if (r < 2 + NF && rd) frag_read(ns, kn & 3, kn < 4 ? cur : nxt, r);
+            __builtin_amdgcn_sched_barrier(0);
           }
+        } else {
+          if (rd) {
+#pragma unroll
+            for (int r = 0; r < 2 + NF; ++r) frag_read(ns, kn & 3, kn < 4 ? cur : nxt, r);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cs][n], xa[cs][i], acc[i][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
+      cur = nxt;
+      slab = nslab;
+      tap9 = ntap;
     }
-    } else {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) {
-        VH_LOAD((ks + 1) & 1, ks + 1, cur)
-      } else if (X2V_VH_PREFETCH) {  // behind the tile's last step these addresses still lie inside the LDS images: harmless, unused
-        VH_LOAD(0, 0, nxt)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][n], xa[ks & 1][i], acc[i][n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    }
-    if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
-    cur = nxt;
-    slab = nslab;
-    tap9 = ntap;
   }
-#undef VH_LOAD
 
   // epilogue.  acc[i][n][r]: pixel (y0 + 2 wid + i, x0 + fl), cout co0 + n*32 + (r&3) + 8*(r>>2) + 4*fh
   const bool vec_ok = (Cout & 3) == 0;
