@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #define X2V_VH_HALO_SPREAD 1  // a slab's halo pieces spread over taps 0..5 (A/B builds: 0 = all on tap 0)
 #endif
 #ifndef X2V_VH_DIST
-#define X2V_VH_DIST 2  // slot form: k-steps of fragment read-ahead (A/B builds: 1)
+#define X2V_VH_DIST 1  // slot form: k-steps of fragment read-ahead.  2 (three fragment sets, step loop unrolled by 3, 239 VGPRs) was measured in round 5
+                       // and is SLOWER: 2.62 vs 2.38 s per 720p x 81f decode on one box (profiles/r05_call10_*) — the read pipeline's depth is not the limiter either
 #endif
 constexpr int VH_NB = X2V_VH_RING;
 constexpr int VH_NEED = X2V_VH_PREFETCH ? 2 : 1;  // at step s the loaders wait for the weights of step s + VH_NEED
