@@ -683,7 +683,8 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #define X2V_VH_INTERLEAVE 1  // one fragment read behind every MFMA (slot form; A/B builds: 0 = read blocks between MFMA blocks)
 #endif
 #ifndef X2V_VH_HALO_SPREAD
-#define X2V_VH_HALO_SPREAD 1  // a slab's halo pieces spread over taps 0..5 (A/B builds: 0 = all on tap 0)
+#define X2V_VH_HALO_SPREAD 0  // A/B builds: 1 = a slab's halo pieces spread over taps 0..5 instead of all on tap 0.  Measured in round 5 and SLOWER: 2.545 / 2.565 s vs
+                              // 2.408 / 2.410 s per 720p x 81f decode on one box (profiles/r05_call11_*), although the decode without any halo traffic is 10 % shorter
 #endif
 #ifndef X2V_VH_DIST
 #define X2V_VH_DIST 1  // slot form: k-steps of fragment read-ahead.  2 (three fragment sets, step loop unrolled by 3, 239 VGPRs) was measured in round 5
@@ -804,9 +805,9 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
     // published one barrier earlier).  LDS-DMA pieces retire in issue order, so that is "all but the pieces issued after them": AHEAD - VH_NEED weight
     // slabs (fewer at the tile's end) and, on the first taps, the halo issued on tap 0 (behind that step's weights) — then the count drops and the halo
     // is drained, long before the next slab's first fragments are read.
-    // Halo pieces per tap (X2V_VH_HALO_SPREAD, round 5): two per tap on taps 0..4 and one on tap 5 instead of all eleven on tap 0 — a piece costs the
-    // issuing wave 60-185 cycles (MI355X_MICROARCH.md), so the burst made every ninth step ~1000 cycles longer than the 768 its MFMAs need
-    // (knock-out probe, profiles/r05_call9_*: the decode without the halo traffic is 10 % shorter).
+    // Halo pieces per tap: all eleven on tap 0 (what ships), or — X2V_VH_HALO_SPREAD, an experiment of round 5 — two per tap on taps 0..4 and one on tap 5.
+    // A piece costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md) and the knock-out probe says the decode without the halo traffic is 10 %
+    // shorter (profiles/r05_call9_*), but spreading the burst made the decode 5.7 % SLOWER (profiles/r05_call11_*).
     auto halo_pieces = [&](int j) -> int {  // pieces this wave issues in step j (behind that step's weights)
       if (j < 0) return 0;
       const int sl = j / 9, tp = j - sl * 9;
