@@ -676,9 +676,6 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #ifndef X2V_VH_PREFETCH
 #define X2V_VH_PREFETCH (X2V_VH_RING >= 4)  // the compute waves read step s + 1's first fragments in front of step s's barrier (A/B builds: 0)
 #endif
-#ifndef X2V_VH_PROBE
-#define X2V_VH_PROBE 0  // TIMING PROBES (results invalid): 1 = no halo after a tile's first, 2 = no weight slabs after the prologue, 4 = no MFMAs, 8 = no per-step barriers
-#endif
 #ifndef X2V_VH_INTERLEAVE
 #define X2V_VH_INTERLEAVE 1  // one fragment read behind every MFMA (slot form; A/B builds: 0 = read blocks between MFMA blocks)
 #endif
@@ -811,11 +808,11 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
     auto halo_pieces = [&](int j) -> int {  // pieces this wave issues in step j (behind that step's weights)
       if (j < 0) return 0;
       const int sl = j / 9, tp = j - sl * 9;
-      if (sl + 1 >= nslabs || (X2V_VH_PROBE & 1)) return 0;
+      if (sl + 1 >= nslabs) return 0;
       if (!X2V_VH_HALO_SPREAD) return tp == 0 ? VH_A_PIECES : 0;
       return tp < 5 ? 2 : tp == 5 ? VH_A_PIECES - 10 : 0;
     };
-    auto weight_pieces = [&](int j) -> int { return (j + AHEAD < nsteps && !(X2V_VH_PROBE & 2)) ? B_INSTR : 0; };
+    auto weight_pieces = [&](int j) -> int { return j + AHEAD < nsteps ? B_INSTR : 0; };
     auto vmcnt_wait = [&](int n) {
       switch (n) {
 #define VH_WAITCASE(N_) case N_: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); break;
@@ -848,7 +845,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         }
         vmcnt_wait(allowed);
         // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier
-        if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
+        VH_BARRIER();
       }
     }
     continue;
@@ -875,11 +872,12 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
     return a;
   };
   // SLOT form (NF < 4): MFMA m of a k-step is followed by fragment read m of the k-step DIST ahead (2 + NF reads for 2 NF MFMAs), pinned with
-  // sched_barrier; the reads run DIST = 2 k-steps ahead through three fragment sets — across the step boundary, i.e. in front of the barrier (VH_NEED = 2:
-  // the next step's weights were published one barrier earlier).  Round 5, by knock-out probes (profiles/r05_call9_*): the kernel's time without its MFMAs
-  // was two thirds of its time with them — one k-step of read-ahead (128-160 cycles of cover) did not hide an LDS round trip under load, so the
-  // read pipeline, not the matrix pipe, set the step; and in BLOCK form (all reads of a k-step, then all its MFMAs; NF = 4, where 128 accumulators leave no
-  // room for a third fragment set) the read / address instructions between two MFMA blocks drain the matrix pipe four times per step.
+  // sched_barrier; the reads run DIST k-steps ahead through DIST + 1 fragment sets — across the step boundary, i.e. in front of the barrier (VH_NEED = 2:
+  // the next step's weights were published one barrier earlier).  Round 5 (profiles/r05_call8_* .. r05_call11_*): against the BLOCK form (all reads of a
+  // k-step, then all its MFMAs — the read / address instructions between two MFMA blocks drain the matrix pipe four times per step; still what NF = 4 runs,
+  // where 128 accumulators leave no room for more) the slot form is worth +3.5 % of the 720p decode; DIST = 2 (three sets, step loop unrolled by 3, 239 VGPRs)
+  // is 9 % SLOWER than DIST = 1.  Knock-out probes of that round (a build without MFMAs / without DMA / without barriers, results invalid by construction,
+  // git history: commit "VAE timing probes") put the decode at 75 % / 85 % / 97 % of its time: no single resource is the limit, the step is too small.
   constexpr bool SLOT = X2V_VH_INTERLEAVE != 0 && NF < 4;
   constexpr bool PF = X2V_VH_PREFETCH != 0 && NF < 4;  // reads run on across the step boundary (NF = 4: no registers for it — every step starts with its own first reads)
   constexpr int DIST = SLOT && PF ? X2V_VH_DIST : 1;  // k-steps of read-ahead
@@ -928,8 +926,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
 #pragma unroll
           for (int m = 0; m < 2 * NF; ++m) {
             const int i = m / NF, n = m - i * NF;
-            if (!(X2V_VH_PROBE & 4)) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cs][n], xa[cs][i], acc[i][n], 0, 0, 0);
-            else asm volatile("" ::"v"(wb[cs][n]), "v"(xa[cs][i]));
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cs][n], xa[cs][i], acc[i][n], 0, 0, 0);
             // slot m carries read m (the last slot every read that is left: NF = 1 has 3 reads for 2 MFMAs)
 #pragma unroll
             for (int r = m; r < (m == 2 * NF - 1 ? 2 + NF : m + 1); ++r)
@@ -949,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (!(X2V_VH_PROBE & 8)) VH_BARRIER();
+      VH_BARRIER();
       cur = nxt;
       slab = nslab;
       tap9 = ntap;
