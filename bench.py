@@ -528,7 +528,11 @@ def main():
                               "the compute stream had nothing to run but the wait); max over ranks; what replaced the reference's two torch.cuda.synchronize() per attention (ulysses/attn.py:48,85)"}
     if calib is not None:
         calib["mfma_probe_tflops_after"] = lib.mfma_probe(args.probe_ms)
-        calib["mfma_probe_tflops"] = 0.5 * (calib["mfma_probe_tflops_before"] + calib["mfma_probe_tflops_after"])
+        # the reference value for `frac_of_probe`: the probe taken right behind the timed steps, i.e. on the board in the state the steps ran in.  With
+        # warm-up steps the first probe now sits in front of them and reads a cooler board (2065 vs 2024 TFLOP/s in a 25-step run) — it is
+        # reported, not averaged in; without warm-up steps both probes bracket the timed region as in round 4 and the mean is used
+        calib["mfma_probe_tflops"] = calib["mfma_probe_tflops_after"] if args.warmup > 0 else 0.5 * (calib["mfma_probe_tflops_before"] + calib["mfma_probe_tflops_after"])
+        calib["mfma_probe_definition"] = "after the timed steps" if args.warmup > 0 else "mean of before / after the timed steps"
         calib["mfma_probe_frac_of_nominal_peak"] = calib["mfma_probe_tflops"] / BF16_MFMA_PEAK_TFLOPS
         if world == 1:
             calib["smi_during_timed_region"] = sampler.summary()

@@ -443,6 +443,7 @@ class UlyssesHunyuanAttention:
         self.comm_stream = None
         self._buffers = {}
         self.copies = 0  # image-row layout copies made by the row-major entry (the blocked entry makes none): asserted by the tests
+        self.comm_timer = None  # tools/hunyuan_bench.py at N > 1: a CommTimer while the timed region runs (None: no events are recorded)
         self.split_head2seq = True
 
     # ---- the fused driver's path: exchange buffers are kernel operands ---------------------------------------------------
@@ -475,9 +476,16 @@ class UlyssesHunyuanAttention:
             self.comm_stream = torch.cuda.Stream()
         cur, cs = torch.cuda.current_stream(), self.comm_stream
         cs.wait_stream(cur)
+        t = self.comm_timer if (self.comm_timer is not None and self.comm_timer.enabled) else None  # CommTimer accounting as in UlyssesAttention
         with torch.cuda.stream(cs):
+            done = t.bracket("comm", cs) if t is not None else None
             out = fn()
+            if done is not None:
+                done()
+        done = t.bracket("exposed", cur) if t is not None else None
         cur.wait_stream(cs)
+        if done is not None:
+            done()
         src.record_stream(cs)
         out.record_stream(cur)
         return out
@@ -505,13 +513,24 @@ class UlyssesHunyuanAttention:
                 self.comm_stream = torch.cuda.Stream()
             cur, cs = torch.cuda.current_stream(), self.comm_stream
 
+        tm = self.comm_timer if (use_streams and self.comm_timer is not None and self.comm_timer.enabled) else None
+
         def on_comm(fn):
             if use_streams:
                 cs.wait_stream(cur)
                 with torch.cuda.stream(cs):
+                    done = tm.bracket("comm", cs) if tm is not None else None
                     fn()
+                    if done is not None:
+                        done()
             else:
                 fn()
+
+        def join():  # the compute stream waits for everything enqueued on the communication stream so far
+            done = tm.bracket("exposed", cur) if tm is not None else None
+            cur.wait_stream(cs)
+            if done is not None:
+                done()
 
         def seq2head():
             for i in range(3):
@@ -521,7 +540,7 @@ class UlyssesHunyuanAttention:
         for i in range(3):  # this rank's heads of the text tokens (n_txt x hd/N: a few hundred rows), beside the exchange
             joint[i][tot:].copy_(txt_qkv[i][:, r * hdn : (r + 1) * hdn])
         if use_streams:
-            cur.wait_stream(cs)
+            join()
         jq, jk, jv = joint[0], joint[1], joint[2]
         nq = tot + n_valid
         fast = self.attn_fn is None and (variant & 0xFF) == lib.ATTN_FAST
@@ -554,7 +573,7 @@ class UlyssesHunyuanAttention:
         # text rows: every rank holds all text tokens for its heads -> gather the head blocks (block j = rank j's heads)
         on_comm(lambda: dist.all_gather_into_tensor(a_txt[:n].view(n * n_txt, hdn), o[tot:], group=self.group))
         if use_streams:
-            cur.wait_stream(cs)
+            join()
         return a_img, a_txt
 
     # ---- row-major entry (the reference's functional form) -----------------------------------------------------------------

@@ -77,6 +77,13 @@ def main():
     for i in range(a.warmup):
         one(i)
     fence()
+    comm_timer = None
+    if world > 1:  # HIP-event accounting of the exchanges, as bench.py does for Wan (ulysses.CommTimer)
+        from lightx2v_amd import ulysses
+
+        pa = getattr(model.transformer_infer, "parallel_attention", None)
+        if pa is not None and hasattr(pa, "comm_timer"):
+            comm_timer = pa.comm_timer = ulysses.CommTimer()
     t0 = time.perf_counter()
     for i in range(a.steps):
         one(a.warmup + i)
@@ -87,6 +94,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     assert torch.isfinite(sch.latents).all()
+    comm = None
+    if comm_timer is not None:
+        comm_timer.enabled = False
+        c_ms, e_ms, n_coll = comm_timer.totals_ms()
+        mine = torch.tensor([c_ms / a.steps, e_ms / a.steps, n_coll / a.steps], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        comm = {"comm_ms_per_step": mine[0].item(), "exposed_comm_ms_per_step": mine[1].item(), "exchanges_per_step": mine[2].item()}
     _, _, t, h, w = wl["target_shape"]
     n_img = t * (h // 2) * (w // 2)
     fl = step_flops(dims, n_img, dims["text_len"])
@@ -94,7 +108,7 @@ def main():
         print(json.dumps({"workload": a.workload, "n_gpus": world, "parallelism": f"ulysses-sp{world}" if world > 1 else "single", "tokens": n_img + dims["text_len"],
                           "ms_per_step": dt * 1e3, "step_tflop": fl / 1e12, "tflops_per_s": fl / dt / 1e12, "tflops_per_s_per_gpu": fl / dt / 1e12 / world,
                           "frac_of_bf16_peak": fl / dt / 1e12 / world / 2500.0, "frames_per_s_50_steps": wl["frames"] / (50 * dt),
-                          "hbm_gb": torch.cuda.max_memory_allocated() / 1e9}))
+                          "hbm_gb": torch.cuda.max_memory_allocated() / 1e9, "comm": comm}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
