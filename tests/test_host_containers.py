@@ -177,3 +177,25 @@ def test_patch_embedding_state_dict_returns_the_checkpoint_tensor():
         assert op.weight.shape[1] % 64 == 0
         sd = op.state_dict()
         assert sd["patch_embedding.weight"].shape == w.shape and torch.equal(sd["patch_embedding.weight"], w) and torch.equal(sd["patch_embedding.bias"], b)
+
+
+def test_i2v_benchmark_workloads_are_the_reference_bench_config():
+    """synth.WORKLOADS' i2v entries restate configs/bench/lightx2v_2.json (I2V-14B, 81 frames, 40 steps, CFG scale 5, shift 5) at the two resolutions the
+    reference publishes numbers for (docs/EN/source/getting_started/benchmark_source.md:29-57); `workload_setup` hands bench.py / tools/e2e.py the i2v checkpoint's
+    tensor set (36-channel patch embedding, img_emb MLP, k_img / v_img / norm_k_img per block), the config overrides and the seeded CLIP / VAE-encode stand-ins."""
+    import torch
+
+    from lightx2v_amd import synth
+
+    for name, hw in (("wan14b_i2v_720px81f", (90, 160)), ("wan14b_i2v_480px81f", (60, 104))):
+        wl = synth.WORKLOADS[name]
+        assert wl["frames"] == 81 and wl["infer_steps"] == 40 and wl["sample_guide_scale"] == 5.0 and wl["sample_shift"] == 5.0
+        assert wl["target_shape"] == (16, 21, *hw) and synth.WAN_DIMS[wl["model"]]["task"] == "i2v"
+    dims, overrides, wd, lat, inputs = synth.workload_setup("wan-tiny-i2v", device="cpu")
+    assert overrides["task"] == "i2v" and overrides["in_dim"] == 36 and overrides["cross_attn_2_type"] == "hip_flash"
+    assert wd["patch_embedding.weight"].shape[1] == 36 and "img_emb.proj.1.weight" in wd and "blocks.0.cross_attn.k_img.weight" in wd
+    img = inputs["image_encoder_output"]
+    assert img["clip_encoder_out"].shape == (synth.I2V_CLIP_TOKENS, dims["clip_dim"]) and img["vae_encode_out"].shape == (20, 3, 8, 8)
+    assert lat.shape == (16, 3, 8, 8) and lat.dtype == torch.float32
+    d2, o2, _, _, in2 = synth.workload_setup("wan-tiny", device="cpu")
+    assert "task" not in o2 and "image_encoder_output" not in in2
