@@ -342,8 +342,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   static_assert(NW == 8, "DMA piece assignment below is written for 4 issuing waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Work mapping.  The launch grid is (query blocks, heads, sequences) and the dispatcher hands workgroup number L = x + gx (y + gy z) to XCD
-  // L % 8 (observed placement; a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch").  Taken as it comes, the 64 workgroups
-  // resident on an XCD (32 CUs x 2) belong to ~2 heads whose K / V^T streams all eight 4 MiB L2s pull through together.  XCD-aware form
+  // L % 8 (observed placement; a speed assumption only, MI355X_MICROARCH.md "Workgroup dispatch").  Taken as it comes, the 32 workgroups
+  // resident on an XCD (one per CU: 224 VGPRs = two waves per SIMD = the workgroup's eight waves) belong to ~1-2 heads whose K / V^T streams all eight 4 MiB L2s pull through together.  XCD-aware form
   // (bit 0 of bs.xcd_remap): XCD c owns the contiguous range c of the (sequence, head, query block) list (bijective for any count), so
   // its resident workgroups are consecutive query blocks of ONE head walking the same K / V^T tiles at about the same time.  Measured
   // (profiles/r03_attn_*): L2 hit rate 73-79 % -> 96 %, L2<->fabric traffic 99-123 GB -> 16 GB per Wan-14B 720p launch — and the launch is
