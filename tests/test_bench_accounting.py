@@ -112,3 +112,37 @@ def test_reference_cpu_baseline_script_reproduces_the_golden_latents():
     assert rec["kind"] == "reference" and rec["threads"] in (1, 2) and len(rec["ms_per_step"]) == 4
     gold = load_file(os.path.join(ROOT, "tests", "golden", "wan-tiny_model.safetensors"))["latents_after_step3"]
     assert rec["latents_abs_sum"] == float(gold.double().abs().sum())
+
+
+def test_kernel_gaps_accounting_on_a_synthetic_trace(tmp_path):
+    """tools/kernel_gaps.py (the config-#2 accounting of profiles/r05_call2_*): on a synthetic rocprofv3 kernel trace with known durations and gaps it must
+    report the union-of-intervals busy time, the idle share, and classify the GEMM launches by epilogue and duration (ffn2's F -> D residual launches run
+    F / D times longer than the D -> D ones)."""
+    import csv
+    import json
+    import subprocess
+
+    rows, t = [], 1000
+    names = {"q": "void x2v::gemm256c_kernel<0>(char const*)", "o": "void x2v::gemm256c_kernel<2>(char const*)", "f0": "void x2v::gemm256c_kernel<1>(char const*)",
+             "f2": "void x2v::gemm256c_kernel<2>(char const*)", "attn": "void x2v::attn_fwd_v9_kernel<8, 8, true, false>(x)", "ln": "void x2v::layernorm_stream_kernel<1, false, true>(x)"}
+    dur = {"q": 80_000, "o": 90_000, "f0": 480_000, "f2": 400_000, "attn": 2_000_000, "ln": 30_000}
+    for layer in range(20):
+        for k in ("ln", "q", "attn", "o", "ln", "f0", "f2"):
+            rows.append((t, t + dur[k], names[k]))
+            t += dur[k] + 10_000  # 10 us between kernels
+    p = tmp_path / "kernel_trace.csv"
+    with open(p, "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Kind", "Start_Timestamp", "End_Timestamp", "Kernel_Name"])
+        for s, e, n in rows:
+            w.writerow(["KERNEL_DISPATCH", s, e, n])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_gaps.py"), str(p), "20280", "1536", "8960", "12", "0.0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1000:]
+    d = json.loads(out.stdout)
+    busy = sum(dur[k] for k in ("ln", "q", "attn", "o", "ln", "f0", "f2")) * 20
+    assert abs(d["busy_ms"] - busy / 1e6) < 1e-6 and abs(d["idle_share"] - (139 * 10_000) / (busy + 139 * 10_000)) < 1e-6 and abs(d["median_gap_us"] - 10.0) < 1e-9
+    g = d["gemm_by_shape"]
+    assert g["D->D plain / V^T"]["calls"] == 20 and g["D->D +residual"]["calls"] == 20 and g["F->D +residual"]["calls"] == 20 and g["D->F +GELU"]["calls"] == 20
+    assert abs(g["F->D +residual"]["tflops"] - 2.0 * 20280 * 8960 * 1536 / 400e-6 / 1e12) < 1e-6
+    attn = next(k for k in d["kernels"] if k["kernel"].startswith("attn_fwd_v9_kernel<8, 8, true"))
+    assert abs(attn["tflops"] - 4.0 * 20280 * 20280 * 12 * 128 / 2e-3 / 1e12) < 1e-6
