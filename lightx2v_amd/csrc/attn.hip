@@ -328,10 +328,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const unsigne
 //     hash, would collide two-fold.  The DMA pieces of a wave are chosen so that h is the same for all of them (one voffset register).
 //   * a query's 64 scores of a tile sit in 4 lanes (the 4 qd of its column): row maxima of both groups cross lanes with 3 swaps
 //     (permlane16_swap, permlane32_swap, permlane16_swap) and 2 max.
-struct AttnBatch {
-  int64_t q, k, vt, o;  // elements from one sequence of the batch to the next (0: single sequence)
-  int xcd_remap;        // bit 0: XCD-aware head-major work mapping (see the kernel), bit 8: staggered key walk; 0: the grid as dispatched, walk from tile 0
-};
 template <int NW, int RESCALE_THR, bool PRESCALED, bool ROT>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned short* __restrict__ Q, int64_t ldq,
                                                                    const unsigned short* __restrict__ Kp, int64_t ldk,
@@ -368,26 +364,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   VTp += (int64_t)seq * bs.vt;
   O += (int64_t)seq * bs.o;
   constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES;
-#ifndef X2V_A9_DEPTH
-#define X2V_A9_DEPTH 4  // fragment reads in flight ahead of their MFMAs (A/B builds)
-#endif
-#ifndef X2V_A9_PRIO
-#define X2V_A9_PRIO 0  // A/B builds: 0 = s_setprio 1 around every matrix half-step (what ships), 1 = no priority changes, 2 = static priority 1 for
-                       // the second-dispatched half of the waves (MI355X_MICROARCH.md "Two waves per SIMD" item 4), 3 = static for the first half.
-                       // Measured in round 5 (profiles/r05_call2_*, 40 heads x 75 600, two rounds on one box): 0: 1372.1 / 1372.1 TFLOP/s, 1: 1371.6 /
-                       // 1371.5, 2: 1352.7 / 1347.6, 3: 1361.2 / 1358.8; fragment depth 6 instead of 4: 1374.5 / 1369.3 — priority is not a lever here
-#endif
-  constexpr int DEPTH = X2V_A9_DEPTH;
+  // (static wave priorities, a deeper fragment queue, the late waves' first fragments read in front of their barrier, and bare s_barrier instead of
+  //  __syncthreads() were all measured in round 5 and move nothing: HISTORY.md §R5.)
+  constexpr int DEPTH = 4;  // fragment reads in flight ahead of their MFMAs
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, qd = lane >> 4;
   const int64_t q0 = (int64_t)qblk * (NW * 32) + wid * 32;
-#if X2V_A9_PRIO == 2
-  if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#elif X2V_A9_PRIO == 3
-  if (wid < NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   const unsigned short* Kh = Kp + (int64_t)head * AT_D;
   const unsigned short* Vh = VTp + (int64_t)head * AT_D * ldvt;
 
@@ -477,32 +461,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #define A9_FRAG(N_)                                                                                                      \
   ((N_) < 16 ? *reinterpret_cast<const bf16x8_t*>(kb_ + (((N_) & 3) >> 1) * 8192 + ((N_) & 1) * 1024 + kbase[(N_) >> 2]) \
              : *reinterpret_cast<const bf16x8_t*>(vb + (((N_) - 16) & 7) * 2048 + vbase[((N_) - 16) >> 3]))
-#ifndef X2V_A9_LATE_PREFETCH
-#define X2V_A9_LATE_PREFETCH 0  // A/B builds: 1 = the late waves read their first DEPTH fragments BEFORE the barrier in front of their matrix half-step
-#endif
-  // The first DEPTH fragment reads of a matrix half-step.  A half-step's operands are proven landed by the barrier behind the odd half-step
-  // (the issuing waves' vmcnt(0)): for the EARLY waves that is the barrier right in front of their matrix half-step — their first MFMA waits a
-  // full LDS latency behind it — but the LATE waves' matrix half-step starts one barrier later, so they COULD issue these reads at the end of
-  // their vector half-step (A9_PREFETCH, in front of the even barrier; the buffers they read are not written during that half-step) and enter
-  // the matrix half-step with the fragments in registers.  Measured in round 5 (profiles/r05_call3_*, A-B-A-B on one box, 40 heads x 75 600):
-  // with bare barriers +-0.3 % (1416-1420 vs 1423-1425 TFLOP/s standalone, 162.4 vs 162.9 ms in-step), with __syncthreads() -3 % — an exposed LDS
-  // latency per half-step is not what this kernel waits for: at the board's power limit the cycles it saves come back as a lower clock.  Off.
   bf16x8_t fr[DEPTH];
-#define A9_PREFETCH(N0_, VB_, KB_)                                                                                       \
+#define A9_MATRIX(N0_, N1_, VB_, KB_)                                                                                   \
   {                                                                                                                      \
     const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                                  \
     const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
     _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                        \
-    A9_SB();                                                                                                             \
-  }
-#define A9_MATRIX_(N0_, N1_, VB_, KB_, PRE_)                                                                             \
-  {                                                                                                                      \
-    const char* vb = smem + V_OFF + (VB_) * AT_K_BYTES;                                                                  \
-    const char* kb_ = smem + K_OFF + (KB_) * AT_K_BYTES;                                                                 \
-    if (X2V_A9_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                                 \
-    if (!(PRE_)) {                                                                                                       \
-      _Pragma("unroll") for (int d = 0; d < DEPTH; ++d) fr[d] = A9_FRAG((N0_) + d);                                      \
-    }                                                                                                                    \
     _Pragma("unroll") for (int n = (N0_); n < (N1_); ++n) {                                                              \
       const bf16x8_t f_ = fr[(n - (N0_)) % DEPTH];                                                                       \
       if (n < 16) {                                                                                                      \
@@ -523,11 +488,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
       if (n + DEPTH < (N1_)) fr[(n - (N0_)) % DEPTH] = A9_FRAG(n + DEPTH);                                               \
       A9_SB();                                                                                                           \
     }                                                                                                                    \
-    if (X2V_A9_PRIO == 0) __builtin_amdgcn_s_setprio(0);                                                                 \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
   }
-#define A9_MATRIX(N0_, N1_, VB_, KB_) A9_MATRIX_(N0_, N1_, VB_, KB_, false)
-#define A9_MATRIX_PRE(N0_, N1_, VB_, KB_) A9_MATRIX_(N0_, N1_, VB_, KB_, X2V_A9_LATE_PREFETCH != 0)
-#define A9_PREFETCH_LATE(N0_, VB_, KB_) if (X2V_A9_LATE_PREFETCH) A9_PREFETCH(N0_, VB_, KB_)
   // vector half-step: softmax of the tile in sc -> packed bf16 P in pw.  Register r of sc[kt][g] is key 32 (kt >> 1) + 8 qd + 4 (kt & 1) + r.
 #define A9_SOFTMAX(LAST_)                                                                                                \
   {                                                                                                                      \
@@ -598,22 +560,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
     A9_NEXT_V()                                       \
   }                                                   \
   A9_SB();
-  // What the barriers really wait for (found in the ISA in round 5): __syncthreads() carries a workgroup-scope release fence, and for it hipcc drains
-  // every outstanding VMEM operation of the wave — LDS-DMA pieces included — in front of the barrier.  So the late waves' pieces of an even half-step
-  // LAND within that half-step (compiler-placed s_waitcnt vmcnt(0) in front of the even barrier) and the explicit wait behind the odd half-step is
-  // a no-op; the "two half-steps of flight" of the protocol above is one.  With the bare instruction instead (X2V_A9_FENCED_BARRIERS=0: an asm
-  // s_barrier with a memory clobber; gfx950 barriers do not drain VMEM by themselves, MI355X_MICROARCH.md "Two waves per SIMD" item 7) the pieces do
-  // fly through the odd half-step — parity tests green, and the launch time does not move (profiles/r05_call3_*: standalone 82.2-82.3 ms fenced vs
-  // 82.4-82.7 ms bare; in-step 162.8-163.0 vs 162.3-162.5 ms per paired launch): the kernel is not waiting for its operands.  The fenced form
-  // stays: same speed, and the compiler — not a clobber list — owns the LDS ordering.
-#ifndef X2V_A9_FENCED_BARRIERS
-#define X2V_A9_FENCED_BARRIERS 1
-#endif
-#if X2V_A9_FENCED_BARRIERS
+  // __syncthreads() carries a workgroup-scope release fence, for which hipcc drains every outstanding VMEM operation of the wave — LDS-DMA pieces
+  // included — in front of the barrier: the late waves' pieces of an even half-step land within that half-step and the explicit wait behind the odd
+  // half-step is a no-op.  The bare instruction (pieces in flight through the odd half-step) runs at the same speed (HISTORY.md §R5), so the fenced form
+  // stays: the compiler — not a clobber list — owns the LDS ordering.
 #define A9_BARRIER() __syncthreads();
-#else
-#define A9_BARRIER() asm volatile("s_barrier" ::: "memory");
-#endif
 #define A9_BAR_EVEN() A9_BARRIER()
 #define A9_BAR_ODD()                                   \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
@@ -646,16 +597,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
     while (t < nt - 1) {
       A9_ISSUE(t + 1)
       A9_SOFTMAX(false)
-      A9_PREFETCH_LATE(0, 0, 1)
       A9_BAR_EVEN()
-      A9_MATRIX_PRE(0, 32, 0, 1)
+      A9_MATRIX(0, 32, 0, 1)
       A9_BAR_ODD()
       if (++t >= nt - 1) break;
       A9_ISSUE(t + 1)
       A9_SOFTMAX(false)
-      A9_PREFETCH_LATE(0, 1, 0)
       A9_BAR_EVEN()
-      A9_MATRIX_PRE(0, 32, 1, 0)
+      A9_MATRIX(0, 32, 1, 0)
       A9_BAR_ODD()
       ++t;
     }
@@ -674,10 +623,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #undef A9_BAR_ODD
 #undef A9_SOFTMAX
 #undef A9_MATRIX
-#undef A9_MATRIX_
-#undef A9_MATRIX_PRE
-#undef A9_PREFETCH
-#undef A9_PREFETCH_LATE
 #undef A9_FRAG
 #undef A9_SB
 #undef A9_DMA_K

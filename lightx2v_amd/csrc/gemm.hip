@@ -295,7 +295,7 @@ static int launch_gemm(const void* x, int64_t ldx_bytes, const void* w, int64_t 
 #endif
 // The 256x256 kernels address an operand tile through a 32-bit buffer descriptor from the tile's first row: 255 rows + the K span of one row
 // (K-blocked x: (K blocks - 1) block strides + one block) must stay below 4 GiB, else the range check would wrap and valid elements read as
-// zero (ADVICE r2).  Such shapes take the 128x128 kernel (64-bit addressing).
+// zero.  Such shapes take the 128x128 kernel (64-bit addressing).
 static bool spans_fit_256(int nk, int64_t ldxb, int64_t ldwb, const GemmBlocking& gb) {
   const int64_t a_kpb = gb.a_kpb > 0 && gb.a_kpb < nk ? gb.a_kpb : nk;
   const int64_t a_span = a_kpb < nk ? ((nk - 1) / a_kpb) * (int64_t)gb.a_cbs + a_kpb * 128 : (int64_t)nk * 128;
@@ -515,7 +515,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_gemm_kernel_choice(int
   const int nk = fp8 ? K / 128 : K / GB_K;
   const int tile = fp8 ? choose_kernel(M, N, nk, ldx, ldw, true) : choose_kernel(M, N, nk, ldx * 2, ldw * 2, false);
   // bit 8: variant 0 runs the CONTINUOUS-pipeline form of that tile family (gemm256c.hip / gemm256c8.hip) for a row-major y (ldy == N) and a
-  // residual of y's stride — what the parity tests and the bench line record (the two forms used to be indistinguishable here)
+  // residual of y's stride — what the parity tests and the bench line record
   const bool cont = (tile == 3 && !fp8 && gemm_continuous_switch() != 0) || (tile == 2 && fp8 && gemm_fp8_continuous_switch() >= 1);
   const bool can_c = gemm256c_ok(nk, GemmBlocking()) && N % 256 == 0 && (255 * (int64_t)N + N) * 2 < 0x80000000ll;
   return tile | ((cont && can_c) ? 0x100 : 0);

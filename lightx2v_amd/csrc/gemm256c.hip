@@ -5,7 +5,7 @@
 // Bound: MFMA (bf16 dense peak ~2.5 PFLOP/s; at this board's 1400 W limit a bare 16x16x32 MFMA loop with GEMM-like LDS traffic sustains
 // ~1.8 PFLOP/s, tools/probes/mfma_power_probe.hip).  Algorithmic work 2*M*N*K FLOP per launch.
 //
-// What this file changes (DESIGN.md §4.2; VERDICT r3 #2).  A one-workgroup-per-CU kernel has nothing on its matrix pipe during its own prologue
+// What this file changes (DESIGN.md §4.2).  A one-workgroup-per-CU kernel has nothing on its matrix pipe during its own prologue
 // (first operand tiles in flight: a full memory latency) and epilogue (accumulators -> LDS -> barrier -> 16-byte stores): ~5 us of a 117 us
 // output tile at K = 5120, ~20 % of a tile at K = 1536.  Here
 //   * a workgroup is PERSISTENT: it walks the output tiles of its XCD's chunk of the grouped tile order (the same assignment an in-order
@@ -358,9 +358,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int e = 0; e < 8; ++e) ov[e] = xv[e] + rbf(yv[e] * gv[e]);
       yv4 = __builtin_bit_cast(c_u32x4_t, pack8(ov));
     }
-#ifdef X2V_C_PROBE_NOSTORE  // timing probe (results invalid): what the epilogue's stores cost
-    if (yv4.x == 0x12345678u && yv4.y == 0x9abcdef0u)
-#endif
     __builtin_amdgcn_raw_buffer_store_b128(yv4, r_y, row_voff(16 * xb + 4 * i), s_col + (unsigned)(16 * xb + 4 * i) * y_row, C_STORE_AUX);
   };
   auto epilogue = [&]() {

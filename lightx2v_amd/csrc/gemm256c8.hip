@@ -7,7 +7,7 @@
 // Bound: MFMA (fp8 dense peak ~5 PFLOP/s; at the board's 1400 W limit a bare 32x32x64 loop with this LDS fragment traffic sustains ~3.9 PFLOP/s,
 // profiles/r02_mfma_power_probe.log PROBE_SET=2).  Algorithmic work 2*M*N*K FLOP per launch.
 //
-// Why (VERDICT r3 #9 / task 8): gemm256.hip's two-groups-of-four-waves ping-pong reaches 2.6-2.85 PFLOP/s in the w8a8 step, 68-73 % of what the
+// Why: gemm256.hip's two-groups-of-four-waves ping-pong reaches 2.6-2.85 PFLOP/s in the w8a8 step, 68-73 % of what the
 // chip sustains for this instruction mix; its prologue and epilogue (dequantise -> LDS -> barrier -> stores) are un-overlapped and weigh twice what
 // they weigh in bf16 because an fp8 K tile (128 k) takes the time of a bf16 one (64 k).  The bf16 answer (gemm256s -> gemm256c) carries over because
 // the BYTES are the same: a K tile is one 128-byte line per operand row either way, so the LDS images, the LDS-DMA pieces, the cursors that run on into

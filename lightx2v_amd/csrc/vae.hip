@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
         for (int e = 0; e < 4; ++e) o[e] = o[e] / (1.f + __expf(-o[e]));
       }
       if constexpr (sizeof(OT) == 2) {
-        if (split) {  // hi = fp16(x) must stay finite: beyond the fp16 range hi saturates at 65504 and lo carries the remainder at fp16 precision (2^-12 relative instead of inf; ADVICE r2)
+        if (split) {  // hi = fp16(x) must stay finite: beyond the fp16 range hi saturates at 65504 and lo carries the remainder at fp16 precision (2^-12 relative instead of inf)
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], -131008.f), 131008.f);
         }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void vae_prep_kernel(const float* __restrict__
           // [hi | lo * 2^12 | hi] — the 16-bit convolution then accumulates xh.wh + xh.wl + xl.wh in fp32 (the xl.wl term is below fp32
           // resolution).  The power-of-two pair on the middle plane keeps the weights' lo halves NORMAL fp16 numbers (|w_lo| <= 2^-12 |w|
           // would be subnormal for every |w| < 1/4, i.e. nearly all of a conv kernel: ~17 instead of 22 bits, and dependent on the matrix
-          // unit not flushing subnormals — ADVICE r2); x_hi * 2^-12 only has to carry the 11 bits a 2^-11-sized correction term needs.
+          // unit not flushing subnormals); x_hi * 2^-12 only has to carry the 11 bits a 2^-11-sized correction term needs.
           const Out4 lv = {{(OT)(o[0] - (float)ov.e[0]), (OT)(o[1] - (float)ov.e[1]), (OT)(o[2] - (float)ov.e[2]), (OT)(o[3] - (float)ov.e[3])}};
           const Out4 mv = {{(OT)((float)ov.e[0] * 0.000244140625f), (OT)((float)ov.e[1] * 0.000244140625f), (OT)((float)ov.e[2] * 0.000244140625f),
                             (OT)((float)ov.e[3] * 0.000244140625f)}};
@@ -662,14 +662,8 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 //     two-slot ring every step waited for weights issued ONE step earlier, i.e. a step lasted an L2 round trip (~2200 cycles against the
 //     step's 1024 MFMA cycles: the 45 % matrix-pipe busy of the round-1 profile), and __syncthreads() in front of the barrier drained
 //     the halo as well (hipcc's VMEM drain for the release fence) — both found in the ISA.
-#ifndef X2V_VH_FENCED_BARRIERS
-#define X2V_VH_FENCED_BARRIERS 0  // A/B builds: 1 = __syncthreads() as before round 5
-#endif
-#if X2V_VH_FENCED_BARRIERS
-#define VH_BARRIER() __syncthreads()
-#else
+// the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier (+2.8 % on the decode)
 #define VH_BARRIER() asm volatile("s_barrier" ::: "memory")
-#endif
 #ifndef X2V_VH_RING
 #define X2V_VH_RING 4  // weight-slab ring slots (A/B builds: 2 = the one-step-ahead form of rounds 1-4)
 #endif
@@ -678,10 +672,6 @@ __global__ __launch_bounds__(256) void blend_axis_kernel(const float* __restrict
 #endif
 #ifndef X2V_VH_INTERLEAVE
 #define X2V_VH_INTERLEAVE 1  // one fragment read behind every MFMA (slot form; A/B builds: 0 = read blocks between MFMA blocks)
-#endif
-#ifndef X2V_VH_HALO_SPREAD
-#define X2V_VH_HALO_SPREAD 0  // A/B builds: 1 = a slab's halo pieces spread over taps 0..5 instead of all on tap 0.  Measured in round 5 and SLOWER: 2.545 / 2.565 s vs
-                              // 2.408 / 2.410 s per 720p x 81f decode on one box (profiles/r05_call11_*), although the decode without any halo traffic is 10 % shorter
 #endif
 #ifndef X2V_VH_DIST
 #define X2V_VH_DIST 1  // slot form: k-steps of fragment read-ahead.  2 (three fragment sets, step loop unrolled by 3, 239 VGPRs) was measured in round 5
@@ -802,15 +792,14 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
     // published one barrier earlier).  LDS-DMA pieces retire in issue order, so that is "all but the pieces issued after them": AHEAD - VH_NEED weight
     // slabs (fewer at the tile's end) and, on the first taps, the halo issued on tap 0 (behind that step's weights) — then the count drops and the halo
     // is drained, long before the next slab's first fragments are read.
-    // Halo pieces per tap: all eleven on tap 0 (what ships), or — X2V_VH_HALO_SPREAD, an experiment of round 5 — two per tap on taps 0..4 and one on tap 5.
-    // A piece costs the issuing wave 60-185 cycles (MI355X_MICROARCH.md) and the knock-out probe says the decode without the halo traffic is 10 %
-    // shorter (profiles/r05_call9_*), but spreading the burst made the decode 5.7 % SLOWER (profiles/r05_call11_*).
+    // Halo pieces per tap: all eleven on tap 0 (spreading the burst over six taps made the decode 5.7 % slower, profiles/r05_call11_*).
+    // These two functions are what the counted waits below are computed from: they must mirror the issue statements of the tap loop exactly
+    // (stage_b_step issues B_INSTR pieces, stage_a issues the halo's VH_A_PIECES on a slab's first tap).
     auto halo_pieces = [&](int j) -> int {  // pieces this wave issues in step j (behind that step's weights)
       if (j < 0) return 0;
       const int sl = j / 9, tp = j - sl * 9;
       if (sl + 1 >= nslabs) return 0;
-      if (!X2V_VH_HALO_SPREAD) return tp == 0 ? VH_A_PIECES : 0;
-      return tp < 5 ? 2 : tp == 5 ? VH_A_PIECES - 10 : 0;
+      return tp == 0 ? VH_A_PIECES : 0;
     };
     auto weight_pieces = [&](int j) -> int { return j + AHEAD < nsteps ? B_INSTR : 0; };
     auto vmcnt_wait = [&](int n) {
@@ -829,8 +818,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
         if (weight_pieces(st)) stage_b_step(st + AHEAD);
         const int hp = halo_pieces(st);
         if (hp) {
-          const int p0 = X2V_VH_HALO_SPREAD ? 2 * tap9 : 0;
-          stage_a((slab + 1) & 1, slab + 1, p0, p0 + hp);
+          stage_a((slab + 1) & 1, slab + 1, 0, hp);
         }
         // what must have landed: the weights of step st + VH_NEED, issued first thing in step j0 = st + VH_NEED - AHEAD.  Pieces retire in issue order,
         // so everything issued behind them may stay in flight: step j0's halo pieces, then weights + halo pieces of steps j0 + 1 .. st.  (At the tile's
@@ -844,7 +832,6 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
           for (int j = 1; j <= AHEAD - VH_NEED; ++j) allowed += weight_pieces(j0 + j) + halo_pieces(j0 + j);
         }
         vmcnt_wait(allowed);
-        // the bare instruction, not __syncthreads(): its release fence makes hipcc drain the wave's whole VMEM queue in front of the barrier
         VH_BARRIER();
       }
     }

@@ -404,7 +404,7 @@ class PatchEmbedConv3dHip(MMWeightHip):
             self.weight = torch.nn.functional.pad(self.weight, (0, 64 - self._k % 64)).contiguous()
 
     def state_dict(self, destination=None):
-        """The checkpoint's tensor back (ADVICE r4): the K padding of `load` is an operand detail of the GEMM, not part of the parameter — without this
+        """The checkpoint's tensor back: the K padding of `load` is an operand detail of the GEMM, not part of the parameter — without this
         an i2v round trip exported [D, 192] under patch_embedding.weight instead of [D, 36, 1, 2, 2]."""
         destination = super().state_dict(destination)
         destination[self.weight_name] = destination[self.weight_name][:, : self._k].reshape(self._ckpt_shape).contiguous()

@@ -80,7 +80,7 @@ def split_form_ok(group, device):
     """Does this PyTorch / RCCL build take the split-size `all_to_all_single` with a zero-row receive view (the two-piece head->seq
     exchange)?  Probed ONCE per (group, device) on a few rows, every rank running the same calls; a rank-local failure (argument checks
     raise before anything is sent) is agreed on with a MIN all-reduce so that all ranks take the same path afterwards.  X2V_ULYSSES_SPLIT=0/1
-    skips the probe.  ADVICE r2: the fallback lives here, next to the collective, not only in bench.py."""
+    skips the probe.  The fallback lives here, next to the collective, not only in bench.py."""
     import os
 
     env = os.environ.get("X2V_ULYSSES_SPLIT")
@@ -189,7 +189,7 @@ class UlyssesAttention:
     def on_comm(self, fn, src):
         """Run the collective `fn()` (which reads `src` and returns a fresh tensor) on the communication stream, ordered behind what the current
         stream has enqueued, and join the current stream behind it.  EVERY collective of this driver goes through the one communication stream
-        (ADVICE r3): with synchronous collectives running on the calling stream, a gather issued from a compute stream would put kernels of the
+        With synchronous collectives running on the calling stream, a gather issued from a compute stream would put kernels of the
         same RCCL communicator on several streams at once and leave their order to RCCL's internals."""
         if not (self.overlap and src.is_cuda):
             return fn()
@@ -476,7 +476,7 @@ class UlyssesHunyuanAttention:
             self.comm_stream = torch.cuda.Stream()
         cur, cs = torch.cuda.current_stream(), self.comm_stream
         cs.wait_stream(cur)
-        t = self.comm_timer if (self.comm_timer is not None and self.comm_timer.enabled) else None  # CommTimer accounting as in UlyssesAttention (ADVICE r4)
+        t = self.comm_timer if (self.comm_timer is not None and self.comm_timer.enabled) else None  # CommTimer accounting as in UlyssesAttention
         with torch.cuda.stream(cs):
             done = t.bracket("comm", cs) if t is not None else None
             out = fn()

@@ -791,7 +791,7 @@ class WanModel:
             want = _cfg(self.config, "cfg_branch_streams", "auto")
             if want == "auto":
                 # under Ulysses (il installed by parallelize_wan): OFF until a multi-GPU run has shown the two-stream form safe and faster there
-                # (ADVICE r3; bench.py at N > 1 times both forms and sets the key explicitly); on one GPU: by size
+                # (bench.py at N > 1 times both forms and sets the key explicitly); on one GPU: by size
                 want = il is None and cfg_form_by_size(self.scheduler.seq_len, self.transformer_infer.num_heads) == "streams"
             want = bool(want) and self.scheduler.latents.is_cuda
             if want and il is None:

@@ -7,6 +7,7 @@
 //
 // CPU references here are plain fp32/fp64 loops over the same bf16 inputs (the torch oracle lives in
 // oracle/ and is exercised by tests/).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -643,8 +644,20 @@ struct AttnVt {
     X2V_OKAY(x2v_transpose_heads_bf16(v, ldv, vt->p, ldvt, Sk, H, nullptr));
   }
 };
+// variant 13: the producer / consumer probe (tools/probes/attn_pc.hip) where the loaded library carries it (tools/probes/build_attn_pc.sh)
+typedef int (*probe_attn_fn)(const void*, int64_t, const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, int, int, float, int, void*);
+static probe_attn_fn probe_attn_pc() {
+  static probe_attn_fn fn = (probe_attn_fn)dlsym(RTLD_DEFAULT, "x2v_probe_attn_pc");
+  return fn;
+}
 static void attn_any(int variant, AttnVt& t, const void* q, const void* k, const void* v, void* o, int64_t Sq, int64_t Sk, int H) {
-  if (variant == 12)  // the ping-pong kernel on a pre-transposed V
+  if (variant == 13) {
+    if (!probe_attn_pc()) {
+      fprintf(stderr, "variant 13 needs a library built by tools/probes/build_attn_pc.sh (x2v_probe_attn_pc not found)\n");
+      exit(2);
+    }
+    X2V_OKAY(probe_attn_pc()(q, H * 128, k, H * 128, t.vt->p, t.ldvt, o, H * 128, Sq, Sk, H, 128, 0.f, 0, nullptr));
+  } else if (variant == 12)  // the ping-pong kernel on a pre-transposed V
     X2V_OKAY(x2v_attn_fwd_bf16_vt(q, H * 128, k, H * 128, t.vt->p, t.ldvt, o, H * 128, Sq, Sk, H, 128, 0.f, 0, nullptr));
   else
     X2V_OKAY(x2v_attn_fwd_bf16_variant(q, H * 128, k, H * 128, v, H * 128, o, H * 128, Sq, Sk, H, 128, 0.f, variant, nullptr));
@@ -666,7 +679,8 @@ static void run_attn() {
     ref_attn(q, k, v, sh.Sq, sh.Sk, sh.H, ref);
     AttnVt vt;
     vt.prepare(dv.p, sh.H * 128, sh.Sk, sh.H);
-    for (int variant : {0, 4, 5, 6, 12}) {
+    for (int variant : {0, 4, 5, 6, 12, 13}) {
+      if (variant == 13 && !probe_attn_pc()) continue;
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, sh.Sq, sh.Sk, sh.H);
       HIP_OK(hipDeviceSynchronize());
@@ -693,7 +707,8 @@ static void run_attn() {
     ref_attn(q, k, v, S, S, H, ref);
     AttnVt vt;
     vt.prepare(dv.p, H * 128, S, H);
-    for (int variant : {4, 6, 12}) {
+    for (int variant : {4, 6, 12, 13}) {
+      if (variant == 13 && !probe_attn_pc()) continue;
       HIP_OK(hipMemset(dout.p, 0xff, dout.n * 2));
       attn_any(variant, vt, dq.p, dk.p, dv.p, dout.p, S, S, H);
       HIP_OK(hipDeviceSynchronize());
@@ -1135,6 +1150,13 @@ static void run_single(int argc, char** argv) {
     vt.prepare(v.p, H * 128, S, H);
     double ms = time_ms(iters, [&] { attn_any(variant, vt, q.p, k.p, v.p, o.p, S, S, H); });
     printf("pattn variant=%d S=%lld H=%d: %.3f ms %.1f TFLOP/s\n", variant, (long long)S, H, ms, 4.0 * S * S * H * 128 / ms / 1e9);
+    if (getenv("X2V_DUMP_TRACE")) {  // probe builds of attn_pc.hip (-DX2V_PC_TRACE) leave per-wave cycle sums in the first bytes of o
+      std::vector<float> t(32);
+      HIP_OK(hipMemcpy(t.data(), o.p, 32 * sizeof(float), hipMemcpyDeviceToHost));
+      for (int w = 0; w < 8; ++w)
+        printf("  wave %d: stream %.0f wait %.0f cycles over %.0f barriers (per interval: %.0f + %.0f), tail %.0f\n", w, t[w * 4], t[w * 4 + 1], t[w * 4 + 2], t[w * 4] / t[w * 4 + 2],
+               t[w * 4 + 1] / t[w * 4 + 2], t[w * 4 + 3]);
+    }
   } else {
     const int64_t M = atoll(argv[2]);
     const int N = atoi(argv[3]), K = atoi(argv[4]);
