@@ -362,7 +362,10 @@ int x2v_vae_prep_ex_f32(const float* x, float* y, int T, int Hh, int Ww, int C, 
 
 /* 16-bit-operand form of x2v_vae_conv_f32 for the HunyuanVideo VAE, which the reference runs in fp16 (hunyuan_runner.py:40): xp and w
  * are fp16 (strides in halves, Cin % 64 == 0), accumulation fp32 on v_mfma_f32_32x32x16_f16, bias / residual / output fp32 — the residual
- * stream and the normalisation statistics keep fp32, only the convolution operands are rounded.  Same flags and layouts as the fp32 entry. */
+ * stream and the normalisation statistics keep fp32, only the convolution operands are rounded.  Same flags and layouts as the fp32 entry, plus
+ * 4 = the per-tap kernel and 8 = the 64-pixel halo kernel (kernel choice for A/B runs and tests: by default 3x3 kernels with Cout % 96 == 0 take the
+ * 128-pixel x 96-cout kernel on v_mfma_f32_16x16x32_f16, whose reduction order differs in rounding) and 16 = the last 32 channels of Cin are zero
+ * padding in both operands (skipped where the kernel steps in 32 channels; a no-op for the results). */
 int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w, int64_t w_row_stride, const float* bias,
                      const float* resid, float* y, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream);
 

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.path.join(HERE, "libx2v_hip.so")
-SOURCES = ["x2v_api.hip", "norm.hip", "gemm.hip", "gemm256.hip", "gemm256s.hip", "gemm256c.hip", "gemm256c8.hip", "attn.hip", "quant_fp8.hip", "conv3d.hip", "vae.hip", "mx.hip", "sched.hip", "probe.hip"]
+SOURCES = ["x2v_api.hip", "norm.hip", "gemm.hip", "gemm256.hip", "gemm256s.hip", "gemm256c.hip", "gemm256c8.hip", "attn.hip", "quant_fp8.hip", "conv3d.hip", "vae.hip", "vae16g.hip", "mx.hip", "sched.hip", "probe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE, "-I", CSRC]
 

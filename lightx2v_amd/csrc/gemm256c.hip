@@ -40,9 +40,6 @@ namespace x2v {
 #ifndef C_DMA_AUX_A
 #define C_DMA_AUX_A 0  // cache policy of the x-operand LDS-DMA (A/B builds)
 #endif
-#ifndef C_SRC0_OUTER
-#define C_SRC0_OUTER 0  // A/B builds: 1 = a k-step walks W blocks in the outer loop (8 consecutive MFMAs share src0, the W fragment) instead of x blocks
-#endif
 constexpr int C_M = 256, C_N = 256;
 constexpr int C_OP_BYTES = 256 * 128;          // one operand tile of one stage
 constexpr int C_STAGE_BYTES = 2 * C_OP_BYTES;  // W tile | x tile
@@ -55,6 +52,8 @@ constexpr int C_LDS_TOTAL = C_LDS_BYTES + 4 * C_STRIP_BYTES;
 //   C_FREE + 1 + C_STEP i the first C_EARLY pieces of tile t+2
 //   C_READY               vmcnt + barrier "tile t+1 has landed"                      C_READY + 2, + 4, ..   fragment reads of k-step 0 of t+1
 //   (LAST K tile of an output tile only) one epilogue-operand buffer load in each slot of [C_X0, C_READY) that holds no LDS-DMA piece
+// (Round 6, profiles/r06_gemm_vs_hipblaslt_pmc_and_knockouts.txt: pieces every 5 / 6 slots, READY at 106 with a read per slot, k-step-1 reads a slot apart, FREE at 44 and a
+//  W-major k-step order are all nil or slower at the step's shapes; builds without the vmcnt / lgkmcnt waits below — invalid results — gain 0.1-0.6 %: the plan is at its optimum.)
 constexpr int C_STEP = 7, C_FREE = 36, C_READY = 94, C_LATE0 = 3;
 constexpr int C_EARLY = (127 - C_FREE - 1) / C_STEP + 1 < 16 ? (127 - C_FREE - 1) / C_STEP + 1 : 16;  // pieces of tile t+2 that fit behind C_FREE
 constexpr int C_NEWER = (C_READY - C_FREE - 1) / C_STEP + 1 < C_EARLY ? (C_READY - C_FREE - 1) / C_STEP + 1 : C_EARLY;  // of them issued before C_READY
@@ -225,21 +224,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   bf16x8_t fx[2][8], fw[2][8];
   // fragment R_ in 0..15 of k-step KS_ of the tile in stage STAGE_; order x0, W0..W7, x1..x7 (the first MFMA of a k-step needs x0 and W0)
-#if C_SRC0_OUTER
-#define C_READ(R_, STAGE_, KS_)                                                                                                                 \
-  {                                                                                                                                            \
-    if constexpr ((R_) == 0) fw[KS_][0] = *reinterpret_cast<const bf16x8_t*>(smem + (STAGE_) * C_STAGE_BYTES + rd_w[KS_]);                      \
-    else if constexpr ((R_) <= 8) fx[KS_][(R_) - 1] = *reinterpret_cast<const bf16x8_t*>(smem + (STAGE_) * C_STAGE_BYTES + ((R_) - 1) * 2048 + rd_x[KS_]); \
-    else fw[KS_][(R_) - 8] = *reinterpret_cast<const bf16x8_t*>(smem + (STAGE_) * C_STAGE_BYTES + ((R_) - 8) * 2048 + rd_w[KS_]);               \
-  }
-#else
 #define C_READ(R_, STAGE_, KS_)                                                                                                                 \
   {                                                                                                                                            \
     if constexpr ((R_) == 0) fx[KS_][0] = *reinterpret_cast<const bf16x8_t*>(smem + (STAGE_) * C_STAGE_BYTES + rd_x[KS_]);                      \
     else if constexpr ((R_) <= 8) fw[KS_][(R_) - 1] = *reinterpret_cast<const bf16x8_t*>(smem + (STAGE_) * C_STAGE_BYTES + ((R_) - 1) * 2048 + rd_w[KS_]); \
     else fx[KS_][(R_) - 8] = *reinterpret_cast<const bf16x8_t*>(smem + (STAGE_) * C_STAGE_BYTES + ((R_) - 8) * 2048 + rd_x[KS_]);               \
   }
-#endif
 #define C_SB() __builtin_amdgcn_sched_barrier(0)
 
   // ---- epilogue of the CURRENT output tile.  LDS holds the next output tile's operands, so the accumulators cannot be staged tile-wide as in
@@ -313,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int ST = decltype(stc)::value;
     constexpr bool FIRST = decltype(firstc)::value != 0, LAST = decltype(lastc)::value != 0;
     c_for<0, 128>([&](auto nc) {
-      constexpr int n = decltype(nc)::value, ks = n >> 6, xb = C_SRC0_OUTER ? n & 7 : (n >> 3) & 7, wb = C_SRC0_OUTER ? (n >> 3) & 7 : n & 7;
+      constexpr int n = decltype(nc)::value, ks = n >> 6, xb = (n >> 3) & 7, wb = n & 7;
       if constexpr (FIRST && ks == 0) c_mfma_first<xb * 8 + wb>(fw[ks][wb], fx[ks][xb]);
       else c_mfma<xb * 8 + wb>(fw[ks][wb], fx[ks][xb]);
       if constexpr (n < 32 && (n & 1) == 0) C_READ(n >> 1, ST, 1)  // k-step 1 of this tile

@@ -986,6 +986,10 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
 #endif
 }
 
+bool vae_conv16g_ok(int Ww, int Cin, int Cout);
+int vae_conv16g_dispatch(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
+                         int Ww, int Cin, int Cout, int kt, int flags, int cin_zero_tail, hipStream_t st);
+
 }  // namespace x2v
 
 using namespace x2v;
@@ -1205,8 +1209,14 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16(const voi
               "vae_conv_f16: a kt-frame input window / 128 weight rows must stay below 2 GiB (32-bit buffer offsets)");
   X2V_REQUIRE(!(flags & VCF_TSPLIT) || (Cout % 8 == 0 && resid == nullptr), X2V_E_ARG, "vae_conv_f16: time-split output needs Cout %% 8 == 0 and no residual");
   hipStream_t st = (hipStream_t)stream;
-  // 3x3 spatial kernels take the halo-tiled kernel (2.3x fewer L2 bytes per FLOP) unless the image is narrower than half a tile or the
-  // caller asks for the per-tap kernel (flag 4: A/B measurements and tests)
+  X2V_REQUIRE((flags & ~31) == 0 && (!(flags & 16) || Cin >= 64), X2V_E_ARG, "vae_conv_f16: flags = 1 clamp | 2 time-split | 4 per-tap kernel | 8 64-pixel halo kernel | 16 zero tail");
+  // 3x3 spatial kernels take a halo-tiled kernel (2.3x fewer L2 bytes per FLOP than a fresh pixel block per tap) unless the image is narrower than half a tile
+  // or the caller asks for the per-tap kernel (flag 4: A/B measurements and tests): the 128-pixel x 96-cout kernel of vae16g.hip where Cout is a multiple of 96
+  // (every 3x3 convolution of the Wan decoder but its 3-channel head), else — or with flag 8 — the 64-pixel kernel below.
+  // Flag 16: the last 32 channels of Cin are zero padding in both operands (the split mode's 3 x 96 = 288 channels in a 320-channel buffer); the 32-channel-slab
+  // kernel skips them, the others multiply the zeros.
+  if (kh == 3 && kw == 3 && !(flags & (VCF_TSPLIT | 4 | 8)) && vae_conv16g_ok(Ww, Cin, Cout))
+    return vae_conv16g_dispatch(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, (flags & 16) ? 32 : 0, st);
   if (kh == 3 && kw == 3 && !(flags & (VCF_TSPLIT | 4)) && Ww >= 16) {
 #define X2V_VC16H(NF_) return launch_vconv16h<NF_>(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, st)
     if (Cout <= 32) X2V_VC16H(1);

@@ -1,0 +1,316 @@
+// 3x3(x kt) convolution on fp16 operands, fp32 accumulate — the GEMM-shaped form of the Wan VAE decoder's halo convolution (vae.hip's vae_conv16h_kernel is the
+// round 1-5 form and still serves Cout that is not a multiple of 96, narrow images and the A/B flag).
+// reference: models/video_encoders/hf/wan/vae.py — CausalConv3d :19-44 as used by ResidualBlock :185-223, Resample :70-159 and the decoder head :436-489.
+//
+// Bound: MFMA (16-bit dense peak ~2.5 PFLOP/s).  Algorithmic work 2 * T*H*W * Cout * Cin * 9 kt FLOP per launch (Cin = the operand buffer's channels: three
+// fp16 planes per fp32 channel in the decoder's hi/lo split mode, see x2v_vae_prep_split_f16).
+//
+// Why a second kernel.  vae_conv16h gives a wave 64 pixels x 96 couts: 6 MFMAs against 5 fragment reads per k-step, one barrier per 24 MFMAs, and a loader wave
+// per SIMD that caps the compute wave at 256 registers; round 5 took it apart (profiles/r05_call4..11) and found no single limiter — the step is too small for its
+// fixed costs.  Here a workgroup is four waves, one per SIMD, with the whole register file each:
+//   * wave = 128 pixels (4 image rows x 32) x 96 couts = 8 x 6 accumulator tiles of v_mfma_f32_16x16x32_f16 (192 registers); D = W . X, so a lane ends up with 4
+//     consecutive couts of one pixel (16-byte channels-last stores);
+//   * workgroup tile = 16 rows x 32 pixels of one output frame; per input frame tap dt and 32-CHANNEL slab the 18 x 34 halo is staged once ([612 rows][64 B],
+//     double buffered, 40 KiB each) and serves nine spatial taps; 32-channel slabs instead of 64 keep two halos + a weight ring inside 160 KiB and make the split
+//     mode's 3 x 96 = 288 channels nine slabs with no padding (the 64-channel form multiplied a zero tenth at the 96-channel stages);
+//   * a STEP = one tap row (dh; dw = 0, 1, 2) of a slab: 3 taps x 48 MFMAs = 144 MFMAs (2304 matrix cycles) per wave behind ONE barrier, 42 fragment reads
+//     (0.29 per MFMA: the GEMMs' ratio), its 18 KiB of weights ([3 taps][96 couts][64 B]) from a ring of three slots filled two steps ahead;
+//   * no loader waves: every wave issues its share of the LDS-DMA (5 weight pieces per step, 10 halo pieces per slab in its first two steps) in fixed MFMA slots,
+//     as gemm256c.hip does; counted vmcnt waits (pieces retire in issue order): what a step's barrier publishes is the NEXT step's weights (and, on a slab's last
+//     step, the next slab's halo), so the fragment reads of step s + 1's first tap run under the MFMAs of step s's last tap — no step starts with an LDS round trip;
+//   * LDS rows are 64 B = 4 chunks of 16 B, chunk index XOR (row >> 2) & 3: any 16 consecutive rows x one chunk column cover the 64 banks once (conflict-free
+//     ds_read_b128 for every tap shift); the swizzle is applied on the DMA source side as everywhere;
+//   * persistent grid (one workgroup per CU), XCD-aware tile order; the next tile's first halo and weights are requested before the epilogue's stores.
+// Reduction order of an output value: (dt, slab, dh, dw, channel) — independent of the launch's frame count and of the tile position, so frame batching and the
+// halo-split parallel decode stay bit-identical to one-frame / one-rank decoding (tests/test_gpu_vae.py).
+#include <algorithm>
+#include <type_traits>
+
+#include "x2v_common.h"
+
+namespace x2v {
+
+typedef __attribute__((address_space(3))) void* g_lds_ptr_t;
+typedef _Float16 g_half8_t __attribute__((ext_vector_type(8)));
+
+constexpr int G_TH = 16, G_TW = 32, G_HW = G_TW + 2, G_HROWS = (G_TH + 2) * G_HW;  // 612 halo rows of 64 B
+constexpr int G_HP = 10;                                                           // halo pieces (16 rows) per wave: 40 pieces = 640 rows >= 612
+constexpr int G_H_BYTES = 4 * G_HP * 1024;                                         // 40960
+constexpr int G_WP = 5;                                                            // weight pieces (one tap x 16 couts) per wave and step: 20 >= 18
+constexpr int G_W_BYTES = 4 * G_WP * 1024;                                         // 20480
+constexpr int G_W_OFF = 2 * G_H_BYTES;
+constexpr int G_LDS = G_W_OFF + 3 * G_W_BYTES;  // 143360
+constexpr unsigned G_OOB = 0x80000000u;
+static_assert(4 * G_HP * 16 >= G_HROWS && 4 * G_WP >= 18, "piece counts");
+
+constexpr int GF_CLAMP = 1;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void g_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    g_for<B + 1, E>(f);
+  }
+}
+
+// The 192 accumulator registers are AGPRs addressed literally by the asm statements below (left to the register allocator the accumulators bounce between the
+// two halves of the file: 337 spills).  Every such statement names all of them as clobbered (gemm256s.hip: the round-3 incident).
+#define G_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
+template <int I>
+__device__ __forceinline__ void g_mfma(const g_half8_t& wf, const g_half8_t& xf) {  // accumulator tile I = cb * 8 + pb is a[4 I : 4 I + 3]
+  asm volatile("v_mfma_f32_16x16x32_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(4 * I), "i"(4 * I + 3) : G_AGPRS);
+}
+template <int R>
+__device__ __forceinline__ float g_acc_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R) : G_AGPRS);
+  return x;
+}
+template <int R>
+__device__ __forceinline__ void g_acc_zero() {
+  asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(R) : G_AGPRS);
+}
+
+#ifndef X2V_G_BAR_SLOT
+#define X2V_G_BAR_SLOT 40  // MFMA slot of a step's middle tap behind which the step's barrier sits
+#endif
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void vae_conv16g_kernel(
+    const _Float16* __restrict__ xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const _Float16* __restrict__ w, int64_t w_row_stride,
+    const float* __restrict__ bias, const float* __restrict__ resid, float* __restrict__ y, int T, int Hh, int Ww, int Hp, int Cin, int Cout, int kt, int flags,
+    int ncol, int tiles_x, int tiles_y, int kchunks) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  asm volatile("" ::: G_AGPRS);  // the accumulator half belongs to the asm statements of this kernel
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int nslabs = kt * kchunks;
+  const unsigned ntiles = (unsigned)T * (unsigned)tiles_y * (unsigned)tiles_x * (unsigned)ncol;
+
+  // ---- tile-invariant per-lane parts
+  // halo piece i of this wave: LDS rows (wid*G_HP + i)*16 + (lane >> 2), 16-byte slot lane & 3 <- source chunk (lane & 3) ^ ((row >> 2) & 3)
+  unsigned h_lane[G_HP];
+  int h_hy[G_HP];
+#pragma unroll
+  for (int i = 0; i < G_HP; ++i) {
+    const int r = (wid * G_HP + i) * 16 + (lane >> 2);
+    const int hy = r / G_HW, hx = r - hy * G_HW;
+    h_hy[i] = r < G_HROWS ? hy : (1 << 20);
+    h_lane[i] = (unsigned)(((int64_t)hy * x_row_stride + (int64_t)hx * x_px_stride) * 2) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+  }
+  // weight piece p = wid*G_WP + i = tap j (0..2) x cout block cb (0..5); row (lane >> 2) of the block, its swizzle (row >> 2) & 3 = (lane >> 4) & 3
+  unsigned w_vo[G_WP], w_so[G_WP];
+#pragma unroll
+  for (int i = 0; i < G_WP; ++i) {
+    const int p = wid * G_WP + i;
+    const int j = p / 6, cb = p - j * 6;
+    w_vo[i] = p < 18 ? (unsigned)((int64_t)(lane >> 2) * w_row_stride * 2) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3))) << 4) : G_OOB;
+    w_so[i] = p < 18 ? (unsigned)(((int64_t)j * Cin + (int64_t)cb * 16 * w_row_stride) * 2) : 0u;
+    w_so[i] = __builtin_amdgcn_readfirstlane(w_so[i]);
+  }
+  // fragment addresses.  x: halo row t = (4 wid + rr) * 34 + dw + c16 (rr = image row of the wave + dh: 0..5), chunk g4 ^ ((t >> 2) & 3); + 1024 for the right
+  // half of the 32 pixels, + G_H_BYTES for the odd halo buffer (immediates).  W: row c16 of a cout block, chunk g4 ^ ((c16 >> 2) & 3); tap / block / slot immediates.
+  int xaddr[6][3];
+#pragma unroll
+  for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int t = (4 * wid + rr) * G_HW + dw + c16;
+      xaddr[rr][dw] = t * 64 + (((g4 ^ (t >> 2)) & 3) << 4);
+    }
+  const int waddr = G_W_OFF + c16 * 64 + (((g4 ^ (c16 >> 2)) & 3) << 4);
+
+  g_half8_t fx[2][8], fw[2][6];
+
+  // ---- tile state
+  struct TileAt {
+    int frame, y0, x0, co0;
+  };
+  auto tile_at = [&](unsigned tile) {
+    const unsigned v = xcd_remap(tile, ntiles);
+    TileAt t;
+    t.co0 = (int)(v % (unsigned)ncol) * 96;
+    unsigned pt = v / (unsigned)ncol;
+    t.x0 = (int)(pt % (unsigned)tiles_x) * G_TW;
+    pt /= (unsigned)tiles_x;
+    t.y0 = (int)(pt % (unsigned)tiles_y) * G_TH;
+    t.frame = (int)(pt / (unsigned)tiles_y);
+    return t;
+  };
+  __amdgpu_buffer_rsrc_t rx, rwt;
+  unsigned h_vo[G_HP];
+  auto tile_operands = [&](const TileAt& t) {
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xp + (int64_t)t.frame * x_frame_stride), 0, (unsigned)(x_frame_stride * 2 * kt), 0x00020000);
+    rwt = __builtin_amdgcn_make_buffer_rsrc((void*)(w + (int64_t)t.co0 * w_row_stride), 0, (unsigned)((95 * w_row_stride + (int64_t)kt * 9 * Cin) * 2), 0x00020000);
+    const unsigned base = (unsigned)(((int64_t)t.y0 * x_row_stride + (int64_t)t.x0 * x_px_stride) * 2);
+#pragma unroll
+    for (int i = 0; i < G_HP; ++i) h_vo[i] = (t.y0 + h_hy[i] < Hp) ? base + h_lane[i] : G_OOB;  // rows below the padded image (ragged last tile row) read as zero
+  };
+  // LDS-DMA issue.  halo piece i of the slab at scalar offset xso into halo buffer HB; weight piece i of the step at scalar offset wso into ring slot SLOT
+#define G_DMA_H(I_, HB_, XSO_, LIVE_) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (g_lds_ptr_t)(smem + (HB_) * G_H_BYTES + (wid * G_HP + (I_)) * 1024), 16, (LIVE_) ? h_vo[I_] : G_OOB, (XSO_), 0, 0)
+#define G_DMA_W(I_, SLOT_, WSO_, LIVE_) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (g_lds_ptr_t)(smem + G_W_OFF + (SLOT_) * G_W_BYTES + (wid * G_WP + (I_)) * 1024), 16, (LIVE_) ? w_vo[I_] : G_OOB, \
+                                           (WSO_) + w_so[I_], 0, 0)
+  auto xso_of = [&](int dt, int kc) { return (unsigned)(((int64_t)dt * x_frame_stride + (int64_t)kc * 32) * 2); };
+  auto wso_of = [&](int dt, int kc, int dh) { return (unsigned)((((int64_t)(dt * 9 + dh * 3)) * Cin + (int64_t)kc * 32) * 2); };
+  auto prologue_dma = [&]() {  // weights of steps 0 and 1, halo of slab 0 (nslabs >= 1: a slab has three steps)
+    g_for<0, G_WP>([&](auto ic) { G_DMA_W(decltype(ic)::value, 0, wso_of(0, 0, 0), true); });
+    g_for<0, G_WP>([&](auto ic) { G_DMA_W(decltype(ic)::value, 1, wso_of(0, 0, 1), true); });
+    g_for<0, G_HP>([&](auto ic) { G_DMA_H(decltype(ic)::value, 0, xso_of(0, 0), true); });
+  };
+
+  // fragment read q (0..13) of tap (DH, J) into set S: q = 0: W block 0, 1..8: pixel blocks 0..7, 9..13: W blocks 1..5 (a tap walks W blocks in its outer loop)
+#define G_READ(S_, Q_, P_, DH_, J_)                                                                                                                          \
+  {                                                                                                                                                          \
+    if constexpr ((Q_) == 0) fw[S_][0] = *reinterpret_cast<const g_half8_t*>(smem + waddr + (DH_) * G_W_BYTES + ((J_) * 6) * 1024);                           \
+    else if constexpr ((Q_) <= 8)                                                                                                                            \
+      fx[S_][(Q_) - 1] = *reinterpret_cast<const g_half8_t*>(smem + xaddr[(((Q_) - 1) >> 1) + (DH_)][J_] + (P_) * G_H_BYTES + (((Q_) - 1) & 1) * 1024);       \
+    else fw[S_][(Q_) - 8] = *reinterpret_cast<const g_half8_t*>(smem + waddr + (DH_) * G_W_BYTES + ((J_) * 6 + (Q_) - 8) * 1024);                             \
+  }
+#define G_SB() __builtin_amdgcn_sched_barrier(0)
+
+  unsigned tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  TileAt cur = tile_at(tile);
+  tile_operands(cur);
+  prologue_dma();
+
+  for (;;) {
+    g_for<0, 192>([&](auto rc) { g_acc_zero<decltype(rc)::value>(); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    g_for<0, 14>([&](auto qc) { G_READ(0, decltype(qc)::value, 0, 0, 0) });
+    G_SB();
+
+    int dt_c = 0, kc_c = 0;  // (dt, kc) of the current slab
+    // One slab = three steps (dh) of three taps (dw).  P = parity of the slab within the tile (halo buffer, and the phase of the two fragment sets).
+    auto slab = [&](auto pc, int h) {
+      constexpr int P = decltype(pc)::value;
+      int dt_n = dt_c, kc_n = kc_c + 1;
+      if (kc_n == kchunks) {
+        kc_n = 0;
+        ++dt_n;
+      }
+      const bool has_next = h + 1 < nslabs;
+      const unsigned xso_n = xso_of(dt_n, kc_n);
+      g_for<0, 3>([&](auto dhc) {
+        constexpr int DH = decltype(dhc)::value;
+        // weights of step s + 2 = (this slab, dh 2) for DH = 0, (next slab, dh DH - 1) otherwise, into ring slot (DH + 2) % 3
+        const bool w_issue = DH == 0 || has_next;
+        const unsigned wso = DH == 0 ? wso_of(dt_c, kc_c, 2) : wso_of(dt_n, kc_n, DH - 1);
+        g_for<0, 3>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          constexpr int SET = (P + DH + J) & 1;
+          // the tap behind this one: same step, or tap 0 of the next step (next slab's halo buffer behind DH = 2)
+          constexpr int NJ = J == 2 ? 0 : J + 1, NDH = J == 2 ? (DH + 1) % 3 : DH, NP = (J == 2 && DH == 2) ? (P ^ 1) : P;
+          g_for<0, 48>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, cb = m >> 3, pb = m & 7;
+            g_mfma<cb * 8 + pb>(fw[SET][cb], fx[SET][pb]);
+            // (reads, weight and halo pieces are issued unconditionally: behind the tile's last step they fetch nothing — masked pieces, stale fragments —
+            //  which keeps the stream free of branches and the counted waits below the same constants for every step)
+            if constexpr ((m & 1) == 0 && (m >> 1) < 14) G_READ(SET ^ 1, m >> 1, NP, NDH, NJ)
+            if constexpr (J == 0 && (m - 5) % 8 == 0 && (m - 5) / 8 >= 0 && (m - 5) / 8 < G_WP) G_DMA_W((m - 5) / 8, (DH + 2) % 3, wso, w_issue);
+            if constexpr (J == 1 && DH < 2 && (m - 3) % 8 == 0 && (m - 3) / 8 >= 0 && (m - 3) / 8 < 5) G_DMA_H(DH * 5 + (m - 3) / 8, P ^ 1, xso_n, has_next);
+            if constexpr (J == 1 && m == X2V_G_BAR_SLOT) {
+              // every fragment read of this step has returned (its last one was issued ~14 slots ago); what must have landed: the next step's weights and, on
+              // the slab's last step, the next slab's halo — everything but the pieces issued behind them (see the header)
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DH == 0 ? 2 * G_WP : DH == 1 ? 3 * G_WP : G_WP) : "memory");
+              __builtin_amdgcn_s_barrier();
+            }
+            G_SB();
+          });
+        });
+      });
+      dt_c = dt_n;
+      kc_c = kc_n;
+    };
+    for (int h = 0; h < nslabs; h += 2) {
+      slab(std::integral_constant<int, 0>{}, h);
+      if (h + 1 < nslabs) slab(std::integral_constant<int, 1>{}, h + 1);
+    }
+
+    // ---- the next tile's first operands fly under this tile's epilogue (behind the last barrier nothing reads LDS any more)
+    const TileAt done = cur;
+    const unsigned next = tile + gridDim.x;
+    const bool more = next < ntiles;
+    if (more) {
+      cur = tile_at(next);
+      tile_operands(cur);
+      prologue_dma();
+    }
+    // ---- epilogue: acc[cb][pb][e] = pixel (y0 + 4 wid + (pb >> 1), x0 + 16 (pb & 1) + c16), cout co0 + 16 cb + 4 g4 + e
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs' results before the accumulator reads below
+    float4 bv[6];
+#pragma unroll
+    for (int cb = 0; cb < 6; ++cb) bv[cb] = bias != nullptr ? *reinterpret_cast<const float4*>(bias + done.co0 + cb * 16 + 4 * g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    g_for<0, 8>([&](auto pbc) {
+      constexpr int pb = decltype(pbc)::value;
+      const int py = done.y0 + 4 * wid + (pb >> 1), px = done.x0 + 16 * (pb & 1) + c16;
+      if (py < Hh && px < Ww) {
+        const int64_t obase = (((int64_t)done.frame * Hh + py) * Ww + px) * Cout + done.co0 + 4 * g4;
+        float4 rv[6];
+        if (resid != nullptr) {
+#pragma unroll
+          for (int cb = 0; cb < 6; ++cb) rv[cb] = *reinterpret_cast<const float4*>(resid + obase + cb * 16);
+        }
+        g_for<0, 6>([&](auto cbc) {
+          constexpr int cb = decltype(cbc)::value, I = cb * 8 + pb;
+          float4 o = make_float4(g_acc_read<4 * I + 0>() + bv[cb].x, g_acc_read<4 * I + 1>() + bv[cb].y, g_acc_read<4 * I + 2>() + bv[cb].z, g_acc_read<4 * I + 3>() + bv[cb].w);
+          if (resid != nullptr) {
+            o.x += rv[cb].x;
+            o.y += rv[cb].y;
+            o.z += rv[cb].z;
+            o.w += rv[cb].w;
+          }
+          if (flags & GF_CLAMP) {
+            o.x = fminf(fmaxf(o.x, -1.f), 1.f);
+            o.y = fminf(fmaxf(o.y, -1.f), 1.f);
+            o.z = fminf(fmaxf(o.z, -1.f), 1.f);
+            o.w = fminf(fmaxf(o.w, -1.f), 1.f);
+          }
+          *reinterpret_cast<float4*>(y + obase + cb * 16) = o;
+        });
+      }
+    });
+    if (!more) break;
+    tile = next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef G_DMA_H
+#undef G_DMA_W
+#undef G_READ
+#undef G_SB
+#endif
+}
+
+// Shapes this kernel takes (the rest stays on vae_conv16h): Cout a multiple of 96, Cin a multiple of 32, at least half a tile wide.
+bool vae_conv16g_ok(int Ww, int Cin, int Cout) { return Cout % 96 == 0 && Cin % 32 == 0 && Ww >= 16; }
+
+// Called by x2v_vae_conv_f16 (arguments validated there).  cin_zero_tail: trailing channels of Cin that are zero padding in BOTH operands (skipped in whole slabs).
+int vae_conv16g_dispatch(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
+                         int Ww, int Cin, int Cout, int kt, int flags, int cin_zero_tail, hipStream_t st) {
+  int rc = ensure_dynamic_lds((const void*)vae_conv16g_kernel, G_LDS, "vae conv16g attr");
+  if (rc != X2V_OK) return rc;
+  const int tiles_x = (Ww + G_TW - 1) / G_TW, tiles_y = (Hh + G_TH - 1) / G_TH;
+  const int ncol = Cout / 96;
+  const int64_t blocks = (int64_t)T * tiles_x * tiles_y * ncol;
+  X2V_REQUIRE(blocks < (1ll << 31), X2V_E_SHAPE, "vae_conv_f16: too many tiles");
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    return n;
+  }();
+  const int kchunks = (Cin - cin_zero_tail) / 32;
+  X2V_REQUIRE(kchunks >= 1, X2V_E_SHAPE, "vae_conv_f16: no channels left");
+  const int Hp = (int)(fs / rs);  // rows of a padded frame
+  const unsigned grid = (unsigned)std::min<int64_t>(blocks, n_cu);
+  hipLaunchKernelGGL(vae_conv16g_kernel, dim3(grid), dim3(256), G_LDS, st, (const _Float16*)xp, fs, rs, ps, (const _Float16*)w, wrs, bias, resid, y, T, Hh, Ww, Hp, Cin,
+                     Cout, kt, flags & GF_CLAMP, ncol, tiles_x, tiles_y, kchunks);
+  X2V_LAUNCH_CHECK("vae_conv_f16 (128 x 96) launch");
+  return X2V_OK;
+}
+
+}  // namespace x2v

@@ -693,6 +693,7 @@ def causal_conv3d(x, weight, bias=None, cache=None):
 
 
 VCONV_CLAMP, VCONV_TSPLIT = 1, 2
+VCONV_PER_TAP, VCONV_HALO64, VCONV_ZERO_TAIL32 = 4, 8, 16  # x2v_vae_conv_f16 only: kernel choice for A/B runs; the last 32 channels of Cin are zero padding
 
 
 def _f32c(t, name):
@@ -737,6 +738,9 @@ def vae_conv(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0, 
     return out
 
 
+_VCONV16_FORCE = {"": 0, "halo64": VCONV_HALO64, "pertap": VCONV_PER_TAP}[os.environ.get("X2V_VAE_CONV16", "")]  # A/B runs: force one of the older 3x3 kernels
+
+
 def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0):
     """x2v_vae_conv_f16: fp16 operand buffer `xp` (strides in halves) and fp16 weight [Cout,kt,kh,kw,Cin], fp32 bias / resid / out."""
     if xp.dtype != torch.float16 or weight.dtype != torch.float16 or not xp.is_cuda or not weight.is_contiguous():
@@ -745,6 +749,7 @@ def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0
     Cout, kt, kh, kw, Cin = weight.shape
     fs, rs, ps = strides
     init()
+    flags |= _VCONV16_FORCE
     _check(_lib.x2v_vae_conv_f16(_p(xp), fs, rs, ps, _p(weight), weight.stride(0), _p(bias), _p(resid), _p(out), T, H, W, Cin, Cout, kt, kh, kw, flags, _stream()), "vae_conv16")
     return out
 

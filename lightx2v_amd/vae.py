@@ -95,6 +95,7 @@ class Decoder3d:
             v = v.to(device=device, dtype=torch.float32)
             self.w[k] = _cl(v) if (k.endswith(".weight") and v.dim() >= 4) else v.reshape(-1).contiguous()
         self.w16 = {}
+        self.w16_tail = {}
         if conv16:
             for k, v in self.w.items():
                 if k.endswith(".weight") and v.dim() == 5 and v.shape[1] * v.shape[2] * v.shape[3] > 1 and v.shape[4] >= 32:
@@ -107,6 +108,7 @@ class Decoder3d:
                         w16[..., cin : 2 * cin] = ((v - hi.float()) * 4096.0).to(torch.float16)
                         w16[..., 2 * cin : 3 * cin] = hi
                     self.w16[k] = w16
+                    self.w16_tail[k] = cp - (3 * cin if self.split else cin)  # zero channels behind the planes (weights and activations alike)
         self.h0, self.w0 = latent_hw
         self._bufs = {}
         self._pool = {}  # shared frame buffers by geometry (see _ConvInput)
@@ -143,6 +145,8 @@ class Decoder3d:
         else:
             out = torch.empty((t, ho, wo, cout), dtype=torch.float32, device=x.device)
         if w16 is not None:
+            if self.w16_tail[name + ".weight"] == 32:  # e.g. 3 x 96 = 288 planes in a 320-channel buffer: the 32-channel-slab kernel skips the zero slab
+                flags |= lib.VCONV_ZERO_TAIL32
             lib.vae_conv16(b.buf, b.strides, w16, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
         else:
             lib.vae_conv(b.buf, b.strides, wt, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)

@@ -301,3 +301,50 @@ def test_vae_decode_real_widths_vs_oracle():
     out = vae.WanVAE(sd, dim=96, conv16=False).decode(z.cuda())
     assert out.shape == (1, 3, 5, 32, 64)
     _check(out[0], ref, "WanVAE.decode (dim 96) vs oracle")
+
+
+def test_vae_conv16_128x96_kernel_against_conv3d_and_the_other_kernels():
+    """The 128-pixel x 96-cout convolution kernel (csrc/vae16g.hip: what x2v_vae_conv_f16 runs for 3x3 kernels with Cout % 96 == 0, i.e. every 3x3(x3)
+    convolution of the Wan decoder but its head) against F.conv3d on the same fp16-rounded operands (fp32 accumulate; tolerance as the other 16-bit
+    kernels' test: |d| <= 3e-4, relative L2 <= 1e-5) and against the 64-pixel halo kernel (flag 8) and the per-tap kernel (flag 4), which reduce in another
+    order.  Shapes: ragged tiles in H and W (tile = 16 x 32 pixels), one to four cout tiles, kt 1 and 3 with a non-zero 2-frame cache, 2..12 32-channel
+    slabs (odd and even counts: both halo buffers end a tile), residual, clamp, the zero-tail flag (288 channels in a 320-channel buffer: bit-identical
+    with and without the flag), several tiles per workgroup (more tiles than CUs)."""
+    from lightx2v_amd import lib
+
+    g = torch.Generator().manual_seed(11)
+    for (T, H, W, Cin, Cout, kt, tail) in [(2, 8, 32, 128, 96, 1, 0), (2, 9, 11, 64, 192, 3, 0), (1, 17, 40, 288, 96, 3, 32), (3, 33, 70, 96, 384, 3, 32), (2, 16, 64, 192, 288, 1, 0),
+                                           (9, 90, 160, 64, 96, 3, 0)]:
+        cp = (Cin + 63) // 64 * 64
+        assert cp - Cin == tail
+        x = torch.randn(kt - 1 + T, H, W, Cin, generator=g).half()  # the leading kt - 1 frames are the cache
+        w = (torch.randn(Cout, Cin, kt, 3, 3, generator=g) / (kt * 9 * Cin) ** 0.5).half()
+        b = torch.randn(Cout, generator=g)
+        res = torch.randn(T, H, W, Cout, generator=g)
+        xin = F.pad(x.float().permute(3, 0, 1, 2), (1, 1, 1, 1, 0, 0))
+        ref = (F.conv3d(xin.unsqueeze(0).cuda(), w.float().cuda(), b.cuda())[0].permute(1, 2, 3, 0) + res.cuda()).clamp(-1, 1)
+        buf = torch.zeros(kt - 1 + T, H + 2, W + 2, cp, dtype=torch.float16, device="cuda")
+        buf[:, 1 : 1 + H, 1 : 1 + W, :Cin] = x.cuda()
+        w16 = torch.zeros(Cout, kt, 3, 3, cp, dtype=torch.float16, device="cuda")
+        w16[..., :Cin] = w.permute(0, 2, 3, 4, 1).cuda()
+        strides = ((H + 2) * (W + 2) * cp, (W + 2) * cp, cp)
+        outs = {}
+        for flags in (0, lib.VCONV_HALO64, lib.VCONV_PER_TAP) + ((lib.VCONV_ZERO_TAIL32,) if tail else ()):
+            out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
+            lib.vae_conv16(buf, strides, w16, out, T, H, W, bias=b.cuda(), resid=res.cuda(), flags=flags | lib.VCONV_CLAMP)
+            _check(out, ref, f"16-bit conv kt={kt} {T}x{H}x{W} Cin={Cin} Cout={Cout} flags={flags}", atol=3e-4, rel=1e-5)
+            outs[flags] = out
+        _check(outs[0], outs[lib.VCONV_HALO64], "128 x 96 kernel vs 64-pixel halo kernel", atol=1e-5, rel=1e-6)
+        if tail:
+            assert torch.equal(outs[0], outs[lib.VCONV_ZERO_TAIL32]), "skipping the zero slab must not change a bit"
+    # frame batching: a launch over T frames = T one-frame launches, bit for bit
+    T, H, W, Cin, Cout, kt = 4, 20, 48, 128, 96, 3
+    x = torch.randn(kt - 1 + T, H + 2, W + 2, Cin, generator=g).half().cuda()
+    w16 = (torch.randn(Cout, kt, 3, 3, Cin, generator=g) / (kt * 9 * Cin) ** 0.5).half().cuda()
+    strides = ((H + 2) * (W + 2) * Cin, (W + 2) * Cin, Cin)
+    whole = torch.empty(T, H, W, Cout, device="cuda")
+    lib.vae_conv16(x, strides, w16, whole, T, H, W)
+    for t in range(T):
+        one = torch.empty(1, H, W, Cout, device="cuda")
+        lib.vae_conv16(x[t:], strides, w16, one, 1, H, W)
+        assert torch.equal(one[0], whole[t]), t

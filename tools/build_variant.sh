@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 out=tools/probes/ab/$tag
 mkdir -p $out/obj
-ALL="x2v_api norm gemm gemm256 gemm256s gemm256c gemm256c8 attn quant_fp8 conv3d vae mx sched probe"
+ALL="x2v_api norm gemm gemm256 gemm256s gemm256c gemm256c8 attn quant_fp8 conv3d vae vae16g mx sched probe"
 SRC=${ONLY:-$ALL}
 for s in $SRC; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I include -I lightx2v_amd/csrc "$@" -c lightx2v_amd/csrc/$s.hip -o $out/obj/$s.o &
