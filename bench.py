@@ -432,7 +432,8 @@ def run_wan_vae_decode(latent_shape=(16, 21, 90, 160)):
     orig16 = lib.vae_conv16
 
     def counted16(xp, strides, weight, out, T, H, W, **kw):
-        flops[0] += 2.0 * T * H * W * weight.shape[0] * weight.shape[4] * weight.shape[1] * weight.shape[2] * weight.shape[3]
+        cin = weight.shape[4] - (32 if kw.get("flags", 0) & lib.VCONV_ZERO_TAIL32 else 0)  # channels multiplied: the 32-channel-slab kernel skips a zero tail
+        flops[0] += 2.0 * T * H * W * weight.shape[0] * cin * weight.shape[1] * weight.shape[2] * weight.shape[3]
         return orig16(xp, strides, weight, out, T, H, W, **kw)
 
     lib.vae_conv16 = counted16
@@ -448,7 +449,7 @@ def run_wan_vae_decode(latent_shape=(16, 21, 90, 160)):
         lib.vae_conv16 = orig16
     assert torch.isfinite(out).all(), "non-finite VAE output"
     rec = {"workload": f"wan_vae_decode z{list(latent_shape)} -> {list(out.shape)}", "conv_operands": "fp16 hi/lo split (fp32-grade)", "decode_s": dt,
-           "conv16_tflop": flops[0] / 1e12, "roofline": {"kernel": "x2v::vae_conv16h_kernel (the 16-bit halo-tiled 3x3x3 convolutions, three MFMA products per fp32-grade product)",
+           "conv16_tflop": flops[0] / 1e12, "roofline": {"kernel": "x2v::vae_conv16g_kernel<6> (the 16-bit halo-tiled 3x3x3 convolutions, 128 pixels x 96 couts per wave; three MFMA products per fp32-grade product)",
                                                          "bound": "mfma", "achieved": flops[0] / dt / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                          "frac": flops[0] / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, "note": "whole-decode average: numerator = the 16-bit convolution launches' FLOPs only"}}
     del m, out, z

@@ -987,8 +987,8 @@ __global__ __launch_bounds__(512, 2) void vae_conv16h_kernel(const _Float16* __r
 }
 
 bool vae_conv16g_ok(int Ww, int Cin, int Cout);
-int vae_conv16g_dispatch(const void* xp, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
-                         int Ww, int Cin, int Cout, int kt, int flags, int cin_zero_tail, hipStream_t st);
+int vae_conv16g_dispatch(const void* xp, const void* cache, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y,
+                         int T, int Hh, int Ww, int Cin, int Cout, int kt, int flags, int cin_zero_tail, hipStream_t st);
 
 }  // namespace x2v
 
@@ -1194,9 +1194,31 @@ static int launch_vconv16h(const void* xp, int64_t fs, int64_t rs, int64_t ps, c
   return X2V_OK;
 }
 
+static int vae_conv_f16_impl(const void* xp, const void* cache, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w, int64_t w_row_stride,
+                             const float* bias, const float* resid, float* y, int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream);
+
 extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w,
                                                                        int64_t w_row_stride, const float* bias, const float* resid, float* y, int T, int Hh, int Ww,
                                                                        int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream) {
+  return vae_conv_f16_impl(xp, nullptr, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, kh, kw, flags, stream);
+}
+
+// 1 if x2v_vae_conv_f16_cached takes this shape (the 128-pixel kernel of vae16g.hip does), else 0: the caller then puts the cache frames in front of xp itself.
+extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16_cached_ok(int Ww, int Cin, int Cout, int kh, int kw, int flags) {
+  return (kh == 3 && kw == 3 && !(flags & (VCF_TSPLIT | 4 | 8)) && vae_conv16g_ok(Ww, Cin, Cout)) ? 1 : 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16_cached(const void* xp, const void* cache, int64_t x_frame_stride, int64_t x_row_stride,
+                                                                              int64_t x_px_stride, const void* w, int64_t w_row_stride, const float* bias, const float* resid,
+                                                                              float* y, int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream) {
+  X2V_REQUIRE(cache != nullptr && aligned16(cache), X2V_E_ARG, "vae_conv_f16_cached: cache must be a 16-byte aligned pointer");
+  X2V_REQUIRE(x2v_vae_conv_f16_cached_ok(Ww, Cin, Cout, kh, kw, flags) == 1, X2V_E_SHAPE,
+              "vae_conv_f16_cached: 3x3 kernels with Cout %% 96 == 0 or Cout <= 16 only (x2v_vae_conv_f16_cached_ok)");
+  return vae_conv_f16_impl(xp, cache, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, kh, kw, flags, stream);
+}
+
+static int vae_conv_f16_impl(const void* xp, const void* cache, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w, int64_t w_row_stride,
+                             const float* bias, const float* resid, float* y, int T, int Hh, int Ww, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream) {
   X2V_REQUIRE(xp && w && y, X2V_E_ARG, "vae_conv_f16: null pointer");
   X2V_REQUIRE(T > 0 && Hh > 0 && Ww > 0 && Cin > 0 && Cout > 0, X2V_E_SHAPE, "vae_conv_f16: bad shape");
   X2V_REQUIRE(kt >= 1 && kt <= 3 && kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3, X2V_E_SHAPE, "vae_conv_f16: kernel %dx%dx%d unsupported", kt, kh, kw);
@@ -1216,7 +1238,7 @@ extern "C" __attribute__((visibility("default"))) int x2v_vae_conv_f16(const voi
   // Flag 16: the last 32 channels of Cin are zero padding in both operands (the split mode's 3 x 96 = 288 channels in a 320-channel buffer); the 32-channel-slab
   // kernel skips them, the others multiply the zeros.
   if (kh == 3 && kw == 3 && !(flags & (VCF_TSPLIT | 4 | 8)) && vae_conv16g_ok(Ww, Cin, Cout))
-    return vae_conv16g_dispatch(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, (flags & 16) ? 32 : 0, st);
+    return vae_conv16g_dispatch(xp, cache, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, (flags & 16) ? 32 : 0, st);
   if (kh == 3 && kw == 3 && !(flags & (VCF_TSPLIT | 4)) && Ww >= 16) {
 #define X2V_VC16H(NF_) return launch_vconv16h<NF_>(xp, x_frame_stride, x_row_stride, x_px_stride, w, w_row_stride, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, st)
     if (Cout <= 32) X2V_VC16H(1);

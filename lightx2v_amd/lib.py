@@ -72,6 +72,8 @@ PROTOTYPES = {
     "x2v_vae_prep_f32": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _c_void_p],
     "x2v_softmax_rows_f32": [_c_void_p, _i64, _i64, _i32, _f32, _c_void_p],
     "x2v_vae_conv_f16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+    "x2v_vae_conv_f16_cached": [_c_void_p, _c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
+    "x2v_vae_conv_f16_cached_ok": [_i32, _i32, _i32, _i32, _i32, _i32],
     "x2v_vae_prep_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _i64, _c_void_p],
     "x2v_vae_prep_split_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i64, _i64, _i64, _c_void_p],
     "x2v_vae_prep_ex_f16": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i64, _i64, _c_void_p],
@@ -741,8 +743,16 @@ def vae_conv(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0, 
 _VCONV16_FORCE = {"": 0, "halo64": VCONV_HALO64, "pertap": VCONV_PER_TAP}[os.environ.get("X2V_VAE_CONV16", "")]  # A/B runs: force one of the older 3x3 kernels
 
 
-def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0):
-    """x2v_vae_conv_f16: fp16 operand buffer `xp` (strides in halves) and fp16 weight [Cout,kt,kh,kw,Cin], fp32 bias / resid / out."""
+def vae_conv16_cached_ok(W, weight, flags=0):
+    """Whether vae_conv16(..., cache=...) is available for this weight [Cout,kt,kh,kw,Cin] and image width (x2v_vae_conv_f16_cached_ok)."""
+    Cout, kt, kh, kw, Cin = weight.shape
+    init()
+    return kt > 1 and _lib.x2v_vae_conv_f16_cached_ok(W, Cin, Cout, kh, kw, flags | _VCONV16_FORCE) == 1
+
+
+def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0, cache=None):
+    """x2v_vae_conv_f16: fp16 operand buffer `xp` (strides in halves) and fp16 weight [Cout,kt,kh,kw,Cin], fp32 bias / resid / out.
+    cache: the kt - 1 leading input frames in a tensor of their own ([kt-1, H+2, W+2, Cin], xp's layout; x2v_vae_conv_f16_cached) — xp's own leading frames are not read."""
     if xp.dtype != torch.float16 or weight.dtype != torch.float16 or not xp.is_cuda or not weight.is_contiguous():
         raise X2VError("vae_conv16: operand buffer and weight must be CUDA float16 (weight contiguous)")
     _f32c(out, "vae_conv16 out")
@@ -750,6 +760,11 @@ def vae_conv16(xp, strides, weight, out, T, H, W, bias=None, resid=None, flags=0
     fs, rs, ps = strides
     init()
     flags |= _VCONV16_FORCE
+    if cache is not None:
+        if cache.dtype != torch.float16 or not cache.is_cuda or not cache.is_contiguous() or cache.shape[0] != kt - 1 or cache[0].numel() != fs:
+            raise X2VError("vae_conv16: cache must be a contiguous CUDA float16 tensor of kt - 1 frames in xp's layout")
+        _check(_lib.x2v_vae_conv_f16_cached(_p(xp), _p(cache), fs, rs, ps, _p(weight), weight.stride(0), _p(bias), _p(resid), _p(out), T, H, W, Cin, Cout, kt, kh, kw, flags, _stream()), "vae_conv16 (cached)")
+        return out
     _check(_lib.x2v_vae_conv_f16(_p(xp), fs, rs, ps, _p(weight), weight.stride(0), _p(bias), _p(resid), _p(out), T, H, W, Cin, Cout, kt, kh, kw, flags, _stream()), "vae_conv16")
     return out
 

@@ -50,9 +50,11 @@ class _ConvInput:
         self.cache = torch.zeros((self.lead, self.hp, self.wp, self.c), dtype=dtype, device=device) if self.lead else None
         self.strides = (self.hp * self.wp * self.c, self.wp * self.c, self.c)  # frame, row, pixel (elements)
 
-    def acquire(self):
-        """Put this convolution's cache frames in front of the shared frame buffer (call before the producer writes the new frames)."""
-        if self.lead:
+    def acquire(self, copy=True):
+        """Put this convolution's cache frames in front of the shared frame buffer (call before the producer writes the new frames).
+        copy=False: the kernel reads the cache frames from `self.cache` itself (lib.vae_conv16(cache=...)): the buffer's leading frames stay
+        stale and `roll` must be told (head_valid=False)."""
+        if self.lead and copy:
             self.buf[: self.lead].copy_(self.cache)
         return self
 
@@ -60,10 +62,16 @@ class _ConvInput:
         """View whose first element is where pixel (t=0, h=0, w=0) of the new frames goes."""
         return self.buf[self.lead :, self.pad :, self.pad :, :]
 
-    def roll(self, t):
+    def roll(self, t, head_valid=True):
         """Cache update (vae.py:199-214): keep the last `lead` frames of [cache | x]."""
-        if self.lead:
+        if not self.lead:
+            return
+        if head_valid or t >= self.lead:  # t >= lead: the last `lead` frames all lie among the new ones
             self.cache.copy_(self.buf[t : t + self.lead])
+        else:  # fewer new frames than the cache holds and the buffer's head is stale: shift the cache, append the new frames
+            keep = self.cache[t:].clone()
+            self.cache[: self.lead - t].copy_(keep)
+            self.cache[self.lead - t :].copy_(self.buf[self.lead : self.lead + t])
 
     def reset(self):
         if self.lead:
@@ -115,14 +123,14 @@ class Decoder3d:
         self._rep = {}  # upsample3d time-conv state: False until the first chunk has passed (the reference's "Rep", vae.py:113-115)
 
     # ---- buffers ------------------------------------------------------------------------------------------------------
-    def _input(self, key, t, h, w, c, kt, pad, dtype=torch.float32):
+    def _input(self, key, t, h, w, c, kt, pad, dtype=torch.float32, copy_cache=True):
         b = self._bufs.get(key)
         if b is None or b.t_max < t:
             nb = _ConvInput(max(t, 4 if kt == 3 else t), h, w, c, kt, pad, self.device, dtype, split=self.split and dtype == torch.float16, pool=self._pool)
             if b is not None and b.lead:
                 nb.cache.copy_(b.cache)
             self._bufs[key] = b = nb
-        return b.acquire()
+        return b.acquire(copy=copy_cache)
 
     def clear_cache(self):
         """reference: WanVAE_.clear_cache (vae.py:752-760)."""
@@ -138,19 +146,21 @@ class Decoder3d:
         cout, wkt, kh, kw, _ = wt.shape
         ho, wo = (2 * h, 2 * w) if upsample else (h, w)
         w16 = self.w16.get(name + ".weight")
-        b = self._input(key, t, ho, wo, c, wkt, kh // 2, torch.float16 if w16 is not None else torch.float32)
+        if w16 is not None and self.w16_tail[name + ".weight"] == 32:  # e.g. 3 x 96 = 288 planes in a 320-channel buffer: the 32-channel-slab kernel skips the zero slab
+            flags |= lib.VCONV_ZERO_TAIL32
+        # the 128-pixel kernel reads the 2-frame cache from its own tensor: no copy in front of the shared frame buffer
+        sep = w16 is not None and lib.vae_conv16_cached_ok(wo, w16, flags)
+        b = self._input(key, t, ho, wo, c, wkt, kh // 2, torch.float16 if w16 is not None else torch.float32, copy_cache=not sep)
         lib.vae_prep(x, b.interior(), b.strides[:2], gamma=gamma, silu=silu, upsample=upsample, split=self.split and w16 is not None)
         if flags & lib.VCONV_TSPLIT:
             out = torch.empty((2 * t, ho, wo, cout // 2), dtype=torch.float32, device=x.device)
         else:
             out = torch.empty((t, ho, wo, cout), dtype=torch.float32, device=x.device)
         if w16 is not None:
-            if self.w16_tail[name + ".weight"] == 32:  # e.g. 3 x 96 = 288 planes in a 320-channel buffer: the 32-channel-slab kernel skips the zero slab
-                flags |= lib.VCONV_ZERO_TAIL32
-            lib.vae_conv16(b.buf, b.strides, w16, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
+            lib.vae_conv16(b.buf, b.strides, w16, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags, cache=b.cache if sep else None)
         else:
             lib.vae_conv(b.buf, b.strides, wt, out, t, ho, wo, bias=self.w[name + ".bias"], resid=resid, flags=flags)
-        b.roll(t)
+        b.roll(t, head_valid=not sep)
         return out
 
     def _conv1x1(self, name, x, resid=None):
@@ -224,8 +234,9 @@ def chunk_bounds(t, chunk_frames):
 class WanVAE_:
     """reference: vae.py:640-760 (decode side)."""
 
-    def __init__(self, sd, dim=96, z_dim=16, device="cuda", conv16="split", chunk_frames=2):
-        """chunk_frames: latent frames per pass through the decoder after the first one.  The reference pushes ONE latent frame at a time
+    def __init__(self, sd, dim=96, z_dim=16, device="cuda", conv16="split", chunk_frames=4):
+        """chunk_frames: latent frames per pass through the decoder after the first one (default 4: 88 GB of buffers at 720p, 2.8 % faster than 2 at 56 GB —
+        fewer cache moves and tile tails; profiles/r06_call10_*).  The reference pushes ONE latent frame at a time
         through its cache-carrying decoder (vae.py:722-736) to bound memory; every kernel here reduces each output pixel in an order that
         does not depend on how many frames share the launch, and the 2-frame caches are the leading frames of the conv input buffers, so
         any chunking gives bit-identical output — larger chunks only fill the GPU better in the low-resolution stages
@@ -257,7 +268,7 @@ class WanVAE_:
 class WanVAE:
     """reference: vae.py:789-957 (decode side; `use_tiling` is not built)."""
 
-    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False, conv16="split", chunk_frames=2):
+    def __init__(self, sd, z_dim=16, dim=96, device="cuda", parallel=False, conv16="split", chunk_frames=4):
         """conv16 selects how the 3x3(x3) convolutions multiply (accumulation, residual stream, norms and attention are fp32 in every mode):
           "split" (default)  activations and weights as hi + lo fp16 pairs (~22 mantissa bits), three 16-bit products per fp32 product:
                              fp32-grade — it meets the all-fp32 decode's tolerance against the reference's fp32 decode (vae.py:794) — at

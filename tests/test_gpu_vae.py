@@ -309,12 +309,14 @@ def test_vae_conv16_128x96_kernel_against_conv3d_and_the_other_kernels():
     kernels' test: |d| <= 3e-4, relative L2 <= 1e-5) and against the 64-pixel halo kernel (flag 8) and the per-tap kernel (flag 4), which reduce in another
     order.  Shapes: ragged tiles in H and W (tile = 16 x 32 pixels), one to four cout tiles, kt 1 and 3 with a non-zero 2-frame cache, 2..12 32-channel
     slabs (odd and even counts: both halo buffers end a tile), residual, clamp, the zero-tail flag (288 channels in a 320-channel buffer: bit-identical
-    with and without the flag), several tiles per workgroup (more tiles than CUs)."""
+    with and without the flag), several tiles per workgroup (more tiles than CUs), and the one-cout-block form the decoder's 3-channel head takes
+    (Cout 3 and 16: weight rows beyond Cout masked, element-wise stores)."""
     from lightx2v_amd import lib
 
     g = torch.Generator().manual_seed(11)
+    cached_runs = 0
     for (T, H, W, Cin, Cout, kt, tail) in [(2, 8, 32, 128, 96, 1, 0), (2, 9, 11, 64, 192, 3, 0), (1, 17, 40, 288, 96, 3, 32), (3, 33, 70, 96, 384, 3, 32), (2, 16, 64, 192, 288, 1, 0),
-                                           (9, 90, 160, 64, 96, 3, 0)]:
+                                           (9, 90, 160, 64, 96, 3, 0), (1, 17, 33, 64, 3, 3, 0), (2, 36, 70, 288, 3, 3, 32), (2, 9, 40, 128, 16, 1, 0)]:
         cp = (Cin + 63) // 64 * 64
         assert cp - Cin == tail
         x = torch.randn(kt - 1 + T, H, W, Cin, generator=g).half()  # the leading kt - 1 frames are the cache
@@ -335,8 +337,18 @@ def test_vae_conv16_128x96_kernel_against_conv3d_and_the_other_kernels():
             _check(out, ref, f"16-bit conv kt={kt} {T}x{H}x{W} Cin={Cin} Cout={Cout} flags={flags}", atol=3e-4, rel=1e-5)
             outs[flags] = out
         _check(outs[0], outs[lib.VCONV_HALO64], "128 x 96 kernel vs 64-pixel halo kernel", atol=1e-5, rel=1e-6)
+        assert lib.vae_conv16_cached_ok(W, w16) == (kt > 1 and W >= 16)  # W < 16 takes the per-tap kernel, which has no separate-cache form
+        if lib.vae_conv16_cached_ok(W, w16):  # the feature cache in a tensor of its own (x2v_vae_conv_f16_cached), the buffer's leading frames poisoned: bit-identical
+            cached_runs += 1
+            cache = buf[: kt - 1].clone()
+            poisoned = buf.clone()
+            poisoned[: kt - 1] = float("nan")
+            out = torch.full((T, H, W, Cout), float("nan"), device="cuda")
+            lib.vae_conv16(poisoned, strides, w16, out, T, H, W, bias=b.cuda(), resid=res.cuda(), flags=lib.VCONV_CLAMP, cache=cache)
+            assert torch.equal(out, outs[0]), "separate cache tensor"
         if tail:
             assert torch.equal(outs[0], outs[lib.VCONV_ZERO_TAIL32]), "skipping the zero slab must not change a bit"
+    assert cached_runs >= 4
     # frame batching: a launch over T frames = T one-frame launches, bit for bit
     T, H, W, Cin, Cout, kt = 4, 20, 48, 128, 96, 3
     x = torch.randn(kt - 1 + T, H + 2, W + 2, Cin, generator=g).half().cuda()

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--conv16", action="store_true", help="opt-in fp16 convolution operands")
     ap.add_argument("--split", action="store_true", help="hi/lo fp16 split of the convolution operands (fp32-grade; WanVAE's default)")
-    ap.add_argument("--chunk-frames", type=int, default=2, help="latent frames per decoder pass (1 = the reference's chunking)")
+    ap.add_argument("--chunk-frames", type=int, default=4, help="latent frames per decoder pass (1 = the reference's chunking)")
     a = ap.parse_args()
     shape = tuple(int(v) for v in a.latent.split(","))
     lib.init(0)
@@ -39,7 +39,8 @@ def main():
     orig16 = lib.vae_conv16
 
     def counted16(xp, strides, weight, out, T, H, W, **kw):
-        flops[0] += 2.0 * T * H * W * weight.shape[0] * weight.shape[4] * weight.shape[1] * weight.shape[2] * weight.shape[3]  # incl. channel padding
+        cin = weight.shape[4] - (32 if kw.get("flags", 0) & lib.VCONV_ZERO_TAIL32 else 0)  # channels multiplied (the 32-channel-slab kernel skips a zero tail)
+        flops[0] += 2.0 * T * H * W * weight.shape[0] * cin * weight.shape[1] * weight.shape[2] * weight.shape[3]
         return orig16(xp, strides, weight, out, T, H, W, **kw)
 
     lib.vae_conv = counted
