@@ -201,15 +201,21 @@ int x2v_transpose_heads_bf16(const void* v, int64_t ldv, void* vt, int64_t ldvt,
  * key tiles (b mod 8) tiles in (the online softmax does not care where the walk starts; the L2 does: +1.3 % at Wan-14B 720p in 2-step runs, but
  * -0.9 % at sustained load, profiles/r04_call12_*: the fused drivers stopped setting it in round 4).  The result of a
  * query row then depends on which 256-row block of the launch it sits in (another fp32 summation order, same tolerance): callers that compare
- * bits across differently partitioned launches (the Ulysses driver) leave it off. */
+ * bits across differently partitioned launches (the Ulysses driver) leave it off.  X2V_ATTN_VT_ONE_WALK — never the persistent short-walk form
+ * (below): one workgroup per 256-row query block, as for long walks (A/B runs and the bit-equality test of the two forms).
+ * Short walks — cross-attention over the text context, transformer_infer.py:424-455: 4..32 whole 64-key tiles and >= 512 query blocks x heads —
+ * run as a persistent launch: a workgroup walks a contiguous range of the (sequence, head, query block) list as one tile stream, the next
+ * block's q rows prefetched through LDS, the previous block's output stored under the next block's first tile.  Same bits as the one-walk form. */
 #define X2V_ATTN_VT_PRESCALED 1
 #define X2V_ATTN_VT_STAGGER 2
+#define X2V_ATTN_VT_ONE_WALK 4
 int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
                          int H, int head_dim, float scale, int flags, void* stream);
 
 /* Which launch form x2v_attn_fwd_bf16_vt / _batched takes for a shape (host-only, no GPU needed): bit 0 = the XCD-aware head-major work mapping
  * (on while the K / V^T streams of the <= 8 heads in flight fit the Infinity Cache and the launch has >= 512 workgroups — e.g. the Ulysses
- * rank's 5 heads x 75 600 keys; off for 40 heads at 720p), bit 8 = the staggered key walk (X2V_ATTN_VT_STAGGER and Sk >= 16 tiles).  Lets a parity
+ * rank's 5 heads x 75 600 keys; off for 40 heads at 720p), bit 8 = the staggered key walk (X2V_ATTN_VT_STAGGER and Sk >= 16 tiles), bit 9 = the
+ * persistent short-walk form (then bits 0 and 8 are clear).  `flags` as x2v_attn_fwd_bf16_vt's.  Lets a parity
  * test assert that the kernel branch it compared with the oracle is the one a model's shapes take — the launches replace
  * attentions/distributed/ulysses/attn.py:68-80 (per rank) and transformer_infer.py:369-379 (single GPU).  Negative = X2V_E_SHAPE. */
 int x2v_attn_vt_launch_plan(int64_t Sq, int64_t Sk, int H, int B, int flags);

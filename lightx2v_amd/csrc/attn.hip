@@ -621,12 +621,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
 #undef A9_BAR_EVEN
 #undef A9_BARRIER
 #undef A9_BAR_ODD
-#undef A9_SOFTMAX
-#undef A9_MATRIX
-#undef A9_FRAG
-#undef A9_SB
-#undef A9_DMA_K
-#undef A9_DMA_V
+  // (A9_SOFTMAX, A9_MATRIX, A9_FRAG, A9_SB, A9_DMA_K, A9_DMA_V stay defined for the persistent form below)
 
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -648,6 +643,379 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_v9_kernel(const unsigned 
   }
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// Persistent short-walk form of the ping-pong kernel ("p9").  Cross-attention (Wan-14B 720p: 75 600 query rows x 512 text keys x 40 heads) is 11 840
+// walks of 8 key tiles.  As one-walk workgroups (v9 above) every walk exposes its prologue (q rows and K(0) from memory), its tail (PV of the last tile,
+// normalise, store) and the workgroup turnover: 1.02 ms per launch = 0.31 of the bf16 peak against 0.56 on the 1182-tile self-attention walk
+// (profiles/r05_final_rocprof_kernel_stats_wan14b_720p.csv).  Here a workgroup takes every gridDim.x-th item of the (sequence, head, query block)
+// list and runs them as ONE tile stream through the same half-step protocol:
+//   * tile tau of the stream is key tile tau mod nt of block tau / nt; the K / V^T double buffers, the DMA cadence (K(tau + 2) and V^T(tau + 1) issued
+//     by the late waves under softmax(tau)) and the two-role schedule do not notice block boundaries — the first QK^T of block b + 1 shares its matrix
+//     half-step with the last PV of block b;
+//   * the q rows of block b + 1 arrive by LDS-DMA (issued by the EARLY waves in the walk of block b, pieces spread over the vector half-steps of tiles
+//     1 .. nt-3, into a [256 rows][256 B] image whose 16-byte chunk index is XORed with row & 15: conflict-free fragment reads) and are read into the
+//     fragment registers behind softmax(nt - 1) of block b, when the last QK^T of block b has issued;
+//   * block b's output is normalised and stored in front of softmax(0) of block b + 1 — a vector half-step, the other role's waves are in their matrix
+//     half-step — and the accumulators, row sums and running maxima start again from v9's initial state.
+// Every query row sees the arithmetic of v9 in v9's order (same 256-row blocks, same wave -> row mapping, same lazy-rescale decisions): bit-identical
+// output (tests/test_gpu_ops.py::test_attention_persistent_short_walk).  Whole key tiles only (Sk % 64 == 0: no mask), 4 <= nt: the launcher's rule (attn_vt_plan bit 9).
+typedef unsigned int at_u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int at_u32x4_t __attribute__((ext_vector_type(4)));
+struct P9Item {
+  int qblk, head, seq;
+};
+
+template <int RESCALE_THR, bool PRESCALED>
+__global__ __launch_bounds__(512, 2) void attn_fwd_p9_kernel(const unsigned short* __restrict__ Q, int64_t ldq, const unsigned short* __restrict__ Kp, int64_t ldk,
+                                                               const unsigned short* __restrict__ VTp, int64_t ldvt, unsigned short* __restrict__ O, int64_t ldo,
+                                                               int64_t Sq, int nt, float scale_log2e, unsigned k_bytes, unsigned v_bytes, AttnBatch bs, int nqb, int H,
+                                                               unsigned n_items) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K_OFF = 0, V_OFF = 2 * AT_K_BYTES, Q_OFF = 4 * AT_K_BYTES;  // K x 2 | V^T x 2 | the next block's q rows (64 KiB)
+  constexpr int DEPTH = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, qd = lane >> 4;
+  // Work: items blockIdx.x, + gridDim.x, + 2 gridDim.x, .. of the (sequence, head, query block) list — at any time the workgroups of the chip are on
+  // ~gridDim.x consecutive query blocks, i.e. one or two heads, whose K / V^T (256 KB per head at 512 keys) every XCD's L2 then holds, as with v9's
+  // plain grid.  (Contiguous ranges per workgroup put all 40 heads in flight at once: 10 MB of K / V^T through each 4 MB L2 — measured 20-25 % more
+  // time per tile than v9, profiles/r06_call15_*.)
+  if (blockIdx.x >= n_items) return;
+  const int64_t Sk = (int64_t)nt * AT_KV;  // whole tiles: A9_SOFTMAX's key mask (LAST_) is never compiled in
+  const int t = 0;
+  (void)Sk;
+  (void)t;
+  const int dq = (int)(gridDim.x % (unsigned)nqb), dh = (int)(gridDim.x / (unsigned)nqb);
+  auto item_next = [&](P9Item& it) {
+    it.qblk += dq;
+    it.head += dh;
+    if (it.qblk >= nqb) {
+      it.qblk -= nqb;
+      ++it.head;
+    }
+    while (it.head >= H) {
+      it.head -= H;
+      ++it.seq;
+    }
+  };
+  auto item_prev = [&](P9Item& it) {
+    it.qblk -= dq;
+    it.head -= dh;
+    if (it.qblk < 0) {
+      it.qblk += nqb;
+      --it.head;
+    }
+    while (it.head < 0) {
+      it.head += H;
+      --it.seq;
+    }
+  };
+  P9Item cur;
+  {
+    const unsigned hz = blockIdx.x / (unsigned)nqb;
+    cur.qblk = (int)(blockIdx.x - hz * (unsigned)nqb);
+    cur.head = (int)(hz % (unsigned)H);
+    cur.seq = (int)(hz / (unsigned)H);
+  }
+  const unsigned n_mine = (n_items - blockIdx.x + gridDim.x - 1) / gridDim.x;  // >= 1
+
+  // q rows of the FIRST block: memory -> registers (as v9); every later block's come through the LDS image
+  bf16x8_t qf[2][4];
+  {
+    const unsigned short* Qb = Q + (int64_t)cur.seq * bs.q + (int64_t)cur.head * AT_D;
+    const int64_t q0 = (int64_t)cur.qblk * (NW * 32) + wid * 32;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      int64_t qr = q0 + 16 * g + c16;
+      qr = qr < Sq ? qr : Sq - 1;
+      const unsigned short* qp = Qb + qr * ldq + qd * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+        if constexpr (!PRESCALED) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);
+        }
+        qf[g][ks] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[g][ks]));
+
+  // LDS-DMA pieces and fragment offsets: v9's
+  constexpr int NDW = NW / 2;
+  constexpr int NPC = 16 / NDW;
+  const int wl = wid & (NW / 2 - 1);
+  const unsigned k_tile_bytes = (unsigned)(AT_KV * ldk * 2), k_row_bytes = (unsigned)(ldk * 2), v_piece_bytes = (unsigned)(8 * NDW * 128);
+  const int krr = lane >> 4, vrow_w = wl * 8 + (lane >> 3);
+  const unsigned k_voff = (unsigned)((8 * wl + krr) * ldk * 2) + (unsigned)(((lane & 15) ^ (krr | (wl << 2))) << 4);
+  const unsigned v_voff = (unsigned)(vrow_w * 128) + (unsigned)(((lane & 7) ^ ((vrow_w >> 1) & 7)) << 4);
+  // q piece j of late wave wl: rows 16 j + 4 wl + (lane >> 4) of the block (row & 15 = 4 wl + (lane >> 4) for all of them: one per-lane offset)
+  const unsigned q_voff = (unsigned)((4 * wl + krr) * ldq * 2) + (unsigned)(((lane & 15) ^ (4 * wl + krr)) << 4);
+  const unsigned q_row16_bytes = (unsigned)(16 * ldq * 2);
+  int kbase[4], vbase[2];
+  const int krow_rd = 8 * (c16 >> 2) + (c16 & 3);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kbase[ks] = krow_rd * 256 + ((((ks << 2) | qd) ^ c16) << 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) vbase[j] = c16 * 128 + ((((j << 2) | qd) ^ ((c16 >> 1) & 7)) << 4);
+  const unsigned o_row_bytes = (unsigned)(ldo * 2), o_row16_bytes = 16u * o_row_bytes;
+  // per-lane offsets of the block hand-over are recomputed where they are used, from a lane index the compiler cannot see through: hoisted out of the
+  // loop they are eight more live registers, and the loop is at the 256-register limit of two waves per SIMD
+#define P9_LANE()                      \
+  int ln_ = lane;                      \
+  asm volatile("" : "+v"(ln_));        \
+  const int c_ = ln_ & 15, q_ = ln_ >> 4;
+
+  f32x4_t oacc[8][2], sc[4][2], negm[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      negm[g][e] = 0.f;
+#pragma unroll
+      for (int T = 0; T < 8; ++T) oacc[T][g][e] = 0.f;
+    }
+  float m_run[2] = {0.f, 0.f};
+  float lsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  bool force = true;
+  unsigned pw[2][2][4];
+  bf16x8_t fr[DEPTH];
+
+  // ---- the end of the stream: normalise and store the last block's rows from registers (buffer stores: one loop-invariant per-lane offset, rows
+  //      past Sq fall outside the descriptor's range and are dropped)
+#define P9_OUT_DESC()                                                                                                    \
+  P9Item pv = cur;                                                                                                       \
+  item_prev(pv);                                                                                                         \
+  const int64_t r0_ = (int64_t)pv.qblk * (NW * 32);                                                                      \
+  const int64_t rows_ = Sq - r0_ < (int64_t)(NW * 32) ? Sq - r0_ : (int64_t)(NW * 32);                                   \
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(                                                   \
+      (void*)(O + (int64_t)pv.seq * bs.o + (int64_t)pv.head * AT_D + r0_ * ldo), 0, (unsigned)((rows_ - 1) * ldo * 2 + AT_D * 2), 0x00020000);
+#define P9_STORE()                                                                                                       \
+  {                                                                                                                      \
+    P9_OUT_DESC()                                                                                                        \
+    P9_LANE()                                                                                                            \
+    const unsigned o_voff = (unsigned)(wid * 32 + c_) * o_row_bytes + (unsigned)(8 * q_);                                \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                      \
+      float l_run = lsum[g][0] + lsum[g][1];                                                                             \
+      l_run += __shfl_xor(l_run, 16, 64);                                                                                \
+      l_run += __shfl_xor(l_run, 32, 64);                                                                                \
+      const float inv = 1.0f / l_run;                                                                                    \
+      _Pragma("unroll") for (int T = 0; T < 8; ++T) {                                                                    \
+        at_u32x2_t pk;                                                                                                   \
+        pk.x = pack_bf2(oacc[T][g][0] * inv, oacc[T][g][1] * inv);                                                       \
+        pk.y = pack_bf2(oacc[T][g][2] * inv, oacc[T][g][3] * inv);                                                       \
+        __builtin_amdgcn_raw_buffer_store_b64(pk, ro, o_voff, (unsigned)g * o_row16_bytes + 32u * T, 0);                  \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  }
+  // ---- block hand-over inside the stream: every wave normalises and stores its rows from registers in front of softmax(0) of the next block, then
+  //      starts again from v9's initial accumulator state.  (An LDS-staged form — all waves write the block into the q image, the early role
+  //      flushes whole 256-byte rows, the late role's memory counter never sees a store — ran at 0.80 ms against this form's 0.85 on the Wan-14B
+  //      launch but returned wrong rows for the second query group of every wave, with every piece of it correct in isolation; not shipped:
+  //      profiles/r06_cross_attn_persistent_form.txt.)
+#define P9_HANDOVER()                                                                                                    \
+  {                                                                                                                      \
+    P9_STORE()                                                                                                           \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                      \
+      lsum[g][0] = 0.f;                                                                                                  \
+      lsum[g][1] = 0.f;                                                                                                  \
+      _Pragma("unroll") for (int T = 0; T < 8; ++T) _Pragma("unroll") for (int e = 0; e < 4; ++e) oacc[T][g][e] = 0.f;   \
+    }                                                                                                                    \
+    A9_SB();                                                                                                             \
+  }
+  // behind softmax(nt - 1): the next block starts from running maximum 0 (first tile: adopt), its q fragments come out of the LDS image
+#define P9_NEXT_BLOCK()                                                                                                  \
+  {                                                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                      \
+      m_run[g] = 0.f;                                                                                                    \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) negm[g][e] = 0.f;                                                    \
+    }                                                                                                                    \
+    force = true;                                                                                                        \
+    if (left > 1) {                                                                                                      \
+      P9_LANE()                                                                                                          \
+      const char* const qr_ = smem + Q_OFF + (wid * 32 + c_) * 256; /* + 4096 g, chunk (4 ks + qd) ^ c16 */              \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                   \
+        bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(qr_ + g * 4096 + ((((ks << 2) | q_) ^ c_) << 4));                \
+        if constexpr (!PRESCALED) {                                                                                      \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale_log2e);                      \
+        }                                                                                                                \
+        qf[g][ks] = v;                                                                                                   \
+      }                                                                                                                  \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[g][ks])); \
+    }                                                                                                                    \
+    A9_SB();                                                                                                             \
+  }
+  // One form for every tile: behind the stream's last tile the QK^T half multiplies whatever the idle K buffer holds into the dead score registers
+  // (32 MFMAs per workgroup; a second, PV-only form of the half-step in the loop costs 100+ spilled registers).
+#define P9_MATRIX_STEP(P_) A9_MATRIX(0, 32, P_, (P_) ^ 1)
+#define P9_ADVANCE()     \
+  if (++tc == nt) {      \
+    tc = 0;              \
+    have_prev = true;    \
+    item_next(cur);      \
+    --left;              \
+  }
+  // bare barrier: __syncthreads() carries a release fence for which hipcc drains every LDS-DMA piece of the wave (v9's note).  LDS ordering by hand:
+  // fragment reads are consumed by the half-step's MFMAs before the barrier that frees their buffer; DMA pieces are waited for (vmcnt) by the
+  // issuing wave in front of the barrier that publishes them; the q image is read into registers that the next half-step's MFMAs consume.
+#define P9_BAR() asm volatile("s_barrier" ::: "memory");
+
+  unsigned left = n_mine;  // blocks of this workgroup not finished yet (the current one included)
+  int tc = 0;              // key tile of the current block whose softmax comes next
+  bool have_prev = false;
+
+  if (wid < NW / 2) {
+    // ---- early role: matrix half-steps on even global half-steps; all q / o traffic.
+    // q pieces of the next block: wave wl's 16 pieces in the vector half-steps of tiles 1 .. nt - 3 (the late role reads the image for the current
+    // block half a step behind this role's softmax(0)), waited for once, behind softmax(nt - 2): the barrier that follows is in front of both roles'
+    // reads (behind their softmax(nt - 1)).  Issued by THIS role because it never waits on its memory counter inside a walk: in the late role's
+    // queue the pieces (HBM latency) sat in front of K / V^T tiles (L2 latency) that are waited for every step — 0.93 ms per Wan-14B launch; counted
+    // waits that leave them in flight: 0.91; here, with the round-robin item order: 0.85 (v9: 0.93-0.94; profiles/r06_cross_attn_persistent_form.txt).
+    const int qps = (16 + nt - 4) / (nt - 3);
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, 0u, 0x00020000);
+#define P9_ISSUE_Q()                                                                                                                  \
+  if (left > 1 && tc >= 1 && (tc - 1) * qps < 16) {                                                                                   \
+    if (tc == 1) {                                                                                                                    \
+      P9Item nx = cur;                                                                                                                \
+      item_next(nx);                                                                                                                  \
+      const int64_t r0 = (int64_t)nx.qblk * (NW * 32);                                                                                \
+      const int64_t rows = Sq - r0 < (int64_t)(NW * 32) ? Sq - r0 : (int64_t)(NW * 32);                                               \
+      rq = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (int64_t)nx.seq * bs.q + (int64_t)nx.head * AT_D + r0 * ldq), 0,            \
+                                             (unsigned)((rows - 1) * ldq * 2 + AT_D * 2), 0x00020000);                                \
+    }                                                                                                                                 \
+    const int j0 = (tc - 1) * qps, j1 = j0 + qps < 16 ? j0 + qps : 16;                                                                \
+    for (int j = j0; j < j1; ++j)                                                                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (at_lds_ptr_t)(smem + Q_OFF + j * 4096 + wl * 1024), 16, q_voff, (unsigned)j * q_row16_bytes, 0, 0); \
+    A9_SB();                                                                                                                          \
+  }
+#define P9_VECTOR_EARLY()                                             \
+  P9_ISSUE_Q()                                                        \
+  if (tc == 0 && have_prev) {                                         \
+    P9_HANDOVER()                                                     \
+  }                                                                   \
+  A9_SOFTMAX(false)                                                                   \
+  if (tc == nt - 2 && left > 1) {                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  \
+  }                                                                   \
+  if (tc == nt - 1) {                                                 \
+    P9_NEXT_BLOCK()                                                   \
+  }
+    P9_BAR()  // K(0): the late waves' prologue
+    A9_MATRIX(0, 16, 0, 0)
+    P9_BAR()
+    for (;;) {
+      P9_VECTOR_EARLY()
+      P9_BAR()
+      P9_MATRIX_STEP(0)
+      P9_BAR()
+      P9_ADVANCE()
+      if (left == 0) break;
+      P9_VECTOR_EARLY()
+      P9_BAR()
+      P9_MATRIX_STEP(1)
+      P9_BAR()
+      P9_ADVANCE()
+      if (left == 0) break;
+    }
+    P9_BAR()
+#undef P9_ISSUE_Q
+#undef P9_VECTOR_EARLY
+  } else {
+    // ---- late role: vector half-steps and the K / V^T LDS-DMA on even global half-steps.
+    // Cursors: K(tau + 2) / V^T(tau + 1) of the stream, as (descriptor of the block's head, tile within the block, block).
+    P9Item ik = cur;  // V^T runs one tile behind K: when it wraps into a block, K's cursor is already in that block
+    int tk = 0, tv = 0;
+    unsigned k_left = n_mine * (unsigned)nt, v_left = k_left;
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kp + (int64_t)ik.seq * bs.k + (int64_t)ik.head * AT_D), 0, k_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(VTp + (int64_t)ik.seq * bs.vt + (int64_t)ik.head * AT_D * ldvt), 0, v_bytes, 0x00020000);
+#define P9_ISSUE_K(BUF_)                                                                                                              \
+  if (k_left) {                                                                                                                       \
+    A9_DMA_K((unsigned)tk * k_tile_bytes, BUF_)                                                                                       \
+    --k_left;                                                                                                                         \
+    if (++tk == nt) {                                                                                                                 \
+      tk = 0;                                                                                                                         \
+      item_next(ik);                                                                                                                  \
+      rk = __builtin_amdgcn_make_buffer_rsrc((void*)(Kp + (int64_t)ik.seq * bs.k + (int64_t)ik.head * AT_D), 0, k_left ? k_bytes : 0u, 0x00020000); \
+    }                                                                                                                                 \
+  }
+#define P9_ISSUE_V(BUF_)                                                                                                              \
+  if (v_left) {                                                                                                                       \
+    A9_DMA_V((unsigned)tv * (unsigned)AT_K_BYTES, BUF_)                                                                               \
+    --v_left;                                                                                                                         \
+    if (++tv == nt) {                                                                                                                 \
+      tv = 0;                                                                                                                         \
+      rv = __builtin_amdgcn_make_buffer_rsrc((void*)(VTp + (int64_t)ik.seq * bs.vt + (int64_t)ik.head * AT_D * ldvt), 0, v_left ? v_bytes : 0u, 0x00020000); \
+    }                                                                                                                                 \
+  }
+#define P9_VECTOR_LATE()                                              \
+  if (tc == 0 && have_prev) {                                         \
+    P9_HANDOVER()                                                     \
+  }                                                                   \
+  A9_SOFTMAX(false)                                                   \
+  if (tc == nt - 1) {                                                 \
+    P9_NEXT_BLOCK()                                                   \
+  }
+#define P9_BAR_ODD()                                 \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+  P9_BAR()
+    P9_ISSUE_K(0)  // K(0)
+    P9_BAR_ODD()
+    P9_ISSUE_K(1)  // K(1), V^T(0)
+    P9_ISSUE_V(0)
+    A9_SB();
+    P9_BAR()
+    A9_MATRIX(0, 16, 0, 0)
+    P9_BAR_ODD()
+    for (;;) {
+      P9_ISSUE_K(0)  // tau even: K(tau + 2) -> buffer 0, V^T(tau + 1) -> buffer 1
+      P9_ISSUE_V(1)
+      A9_SB();
+      P9_VECTOR_LATE()
+      P9_BAR()
+      P9_MATRIX_STEP(0)
+      P9_BAR_ODD()
+      P9_ADVANCE()
+      if (left == 0) break;
+      P9_ISSUE_K(1)
+      P9_ISSUE_V(0)
+      A9_SB();
+      P9_VECTOR_LATE()
+      P9_BAR()
+      P9_MATRIX_STEP(1)
+      P9_BAR_ODD()
+      P9_ADVANCE()
+      if (left == 0) break;
+    }
+#undef P9_ISSUE_K
+#undef P9_ISSUE_V
+#undef P9_VECTOR_LATE
+#undef P9_BAR_ODD
+  }
+  P9_STORE()
+#undef P9_LANE
+#undef P9_OUT_DESC
+#undef P9_STORE
+#undef P9_HANDOVER
+#undef P9_NEXT_BLOCK
+#undef P9_MATRIX_STEP
+#undef P9_ADVANCE
+#undef P9_BAR
+#endif
+}
+#undef A9_SOFTMAX
+#undef A9_MATRIX
+#undef A9_FRAG
+#undef A9_SB
+#undef A9_DMA_K
+#undef A9_DMA_V
 
 // V [Sk, H*128] (token stride ldv) -> V^T [H][ldvt/64][128][64] bf16 (per head and 64-key tile a contiguous 16 KiB [dv][key] block: one
 // attention tile = one linear stream, like K's) with keys >= Sk zero-filled up to ldvt (a multiple of 64).  One tile per block, through LDS.
@@ -712,20 +1080,36 @@ int attn_rot_switch() {
   static const int v = [] { const char* e = getenv("X2V_ATTN_ROT"); return e ? atoi(e) : -1; }();
   return v;
 }
+int attn_short_switch() {  // X2V_ATTN_SHORT=0: never the persistent short-walk form (A/B runs)
+  static const int v = [] { const char* e = getenv("X2V_ATTN_SHORT"); return e ? atoi(e) : -1; }();
+  return v;
+}
 }  // namespace x2v
-static int attn_vt_plan(int64_t Sq, int64_t Sk, int H, int B, bool stagger, int q_rows_per_wg) {
+static int attn_cu_count() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return n;
+  }();
+  return cus;
+}
+static int attn_vt_plan(int64_t Sq, int64_t Sk, int H, int B, bool stagger, int q_rows_per_wg, bool one_walk = false) {
   const int map_env = attn_map_switch(), rot_env = attn_rot_switch();
   const uint64_t nwg = (uint64_t)((Sq + q_rows_per_wg - 1) / q_rows_per_wg) * (uint64_t)H * (uint64_t)B;
+  const int rot_mode = rot_env >= 0 ? rot_env : ((stagger && Sk >= 16 * AT_KV) ? 1 : 0);
+  // bit 9: the persistent short-walk form (attn_fwd_p9_kernel) — whole key tiles, 4..32 of them, at least two walks per CU (the chip's 256: a
+  // shape rule, not a device query, so that the plan is a function of its arguments), walk from tile 0
+  if (attn_short_switch() != 0 && !one_walk && !rot_mode && Sk % AT_KV == 0 && Sk >= 4 * AT_KV && Sk <= 32 * AT_KV && nwg >= 512 && nwg < (1ull << 31)) return 0x200;
   const int64_t heads_in_flight = (int64_t)H * B < 8 ? (int64_t)H * B : 8;
   const bool mall_resident = heads_in_flight * Sk * (2 * AT_D * 2) <= (224ll << 20);
   const int map_mode = map_env >= 0 ? map_env : ((nwg >= 512 && mall_resident) ? 1 : 0);
-  const int rot_mode = rot_env >= 0 ? rot_env : ((stagger && Sk >= 16 * AT_KV) ? 1 : 0);
   return (map_mode ? 1 : 0) | (rot_mode ? 0x100 : 0);
 }
 
 template <int NW, int THR, bool PRESCALED>
 static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo, int64_t Sq, int64_t Sk,
-                          int H, float scale, hipStream_t st, bool stagger, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0, 0}) {
+                          int H, float scale, hipStream_t st, int flags, int B = 1, AttnBatch bs = AttnBatch{0, 0, 0, 0, 0}) {
+  const bool stagger = (flags & 2) != 0;
   // buffer ranges from a head's (and sequence's) first element: K rows of this sequence, the V^T blocks of its ceil(Sk/64) key tiles
   const int64_t kb = (Sk - 1) * ldk * 2 + AT_D * 2, vb = ((Sk + AT_KV - 1) / AT_KV) * (int64_t)AT_D * AT_KV * 2;
   X2V_REQUIRE(kb < (1ll << 32) - (int64_t)AT_KV * ldk * 2 && vb < (1ll << 32), X2V_E_SHAPE, "attn: K view / V^T head block spans >= 4 GiB");
@@ -738,7 +1122,22 @@ static int launch_attn_vt(const void* q, int64_t ldq, const void* k, int64_t ldk
   //   * the stagger of the walk (rot mode 1) was worth +1.3 % on the plain grid in 2-step runs and costs 0.9 % at sustained load
   //     (profiles/r04_call12_*); it changes the summation order per query block; opt-in per call (flag X2V_ATTN_VT_STAGGER), no driver sets it.
   // X2V_ATTN_MAP / X2V_ATTN_ROT force a mode (A/B runs).
-  const int plan = attn_vt_plan(Sq, Sk, H, B, stagger, NW * 32);
+  const int plan = attn_vt_plan(Sq, Sk, H, B, stagger, NW * 32, (flags & 4) != 0);
+  if (plan & 0x200) {
+    const int nqb = (int)((Sq + NW * 32 - 1) / (NW * 32));
+    const unsigned n_items = (unsigned)nqb * (unsigned)H * (unsigned)B;
+    const int64_t qbytes = (int64_t)(NW * 32 - 1) * ldq * 2 + AT_D * 2;
+    X2V_REQUIRE(qbytes < (1ll << 32), X2V_E_SHAPE, "attn: a 256-row q block spans >= 4 GiB");
+    auto kern = attn_fwd_p9_kernel<THR, PRESCALED>;
+    int rc = ensure_dynamic_lds((const void*)kern, 8 * AT_K_BYTES, "attn p9 attr");
+    if (rc != X2V_OK) return rc;
+    const unsigned cus = (unsigned)attn_cu_count();
+    hipLaunchKernelGGL(kern, dim3(n_items < cus ? n_items : cus), dim3(NW * 64), 8 * AT_K_BYTES, st, (const unsigned short*)q, ldq, (const unsigned short*)k, ldk,
+                       (const unsigned short*)vt, ldvt, (unsigned short*)o, ldo, Sq, (int)(Sk / AT_KV), scale * 1.4426950408889634f, (unsigned)kb, (unsigned)vb, bs, nqb, H,
+                       n_items);
+    X2V_LAUNCH_CHECK("attn p9 launch");
+    return X2V_OK;
+  }
   const int rot_mode = plan & 0x100;
   bs.xcd_remap = plan;
   auto kern = rot_mode ? attn_fwd_v9_kernel<NW, THR, PRESCALED, true> : attn_fwd_v9_kernel<NW, THR, PRESCALED, false>;
@@ -762,9 +1161,9 @@ extern "C" __attribute__((visibility("default"))) int x2v_transpose_heads_bf16(c
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_attn_vt_launch_plan(int64_t Sq, int64_t Sk, int H, int B, int flags) {
-  X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535 && B > 0 && B <= 65535 && (flags & ~3) == 0, X2V_E_SHAPE, "attn_vt_launch_plan: bad shape Sq=%lld Sk=%lld H=%d B=%d flags=%d",
+  X2V_REQUIRE(Sq > 0 && Sk > 0 && H > 0 && H <= 65535 && B > 0 && B <= 65535 && (flags & ~7) == 0, X2V_E_SHAPE, "attn_vt_launch_plan: bad shape Sq=%lld Sk=%lld H=%d B=%d flags=%d",
               (long long)Sq, (long long)Sk, H, B, flags);
-  return attn_vt_plan(Sq, Sk, H, B, (flags & 2) != 0, 8 * 32);
+  return attn_vt_plan(Sq, Sk, H, B, (flags & 2) != 0, 8 * 32, (flags & 4) != 0);
 }
 
 extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* o, int64_t ldo,
@@ -777,11 +1176,10 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt(const
               "attn_vt: rows must be 16-byte aligned, ldvt a multiple of 64");
   X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D, X2V_E_SHAPE, "attn_vt: token stride smaller than H*128");
   if (scale <= 0.f) scale = 0.08838834764831845f;
-  X2V_REQUIRE((flags & ~3) == 0, X2V_E_ARG, "attn_vt: flags = X2V_ATTN_VT_PRESCALED | X2V_ATTN_VT_STAGGER");
+  X2V_REQUIRE((flags & ~7) == 0, X2V_E_ARG, "attn_vt: flags = X2V_ATTN_VT_PRESCALED | X2V_ATTN_VT_STAGGER | X2V_ATTN_VT_ONE_WALK");
   hipStream_t st = (hipStream_t)stream;
-  const bool stagger = (flags & 2) != 0;
-  return (flags & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger)
-                     : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger);
+  return (flags & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, flags)
+                     : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, flags);
 }
 
 // B independent sequences in one launch (grid z): sequence b reads q / k / V^T and writes o at b * {q,k,vt,o}_bstride elements from the base
@@ -799,13 +1197,12 @@ extern "C" __attribute__((visibility("default"))) int x2v_attn_fwd_bf16_vt_batch
               X2V_E_ALIGN, "attn_vt_batched: rows must be 16-byte aligned, ldvt a multiple of 64, vt_bstride whole 64-key blocks");
   X2V_REQUIRE(ldq >= (int64_t)H * AT_D && ldk >= (int64_t)H * AT_D && ldo >= (int64_t)H * AT_D && ldvt >= (B - 1) * (vt_bstride / AT_D) + Sk, X2V_E_SHAPE,
               "attn_vt_batched: token stride smaller than H*128, or ldvt smaller than the stacked sequences");
-  X2V_REQUIRE((flags & ~3) == 0, X2V_E_ARG, "attn_vt_batched: flags = X2V_ATTN_VT_PRESCALED | X2V_ATTN_VT_STAGGER");
+  X2V_REQUIRE((flags & ~7) == 0, X2V_E_ARG, "attn_vt_batched: flags = X2V_ATTN_VT_PRESCALED | X2V_ATTN_VT_STAGGER | X2V_ATTN_VT_ONE_WALK");
   if (scale <= 0.f) scale = 0.08838834764831845f;
   const AttnBatch bs{q_bstride, k_bstride, vt_bstride, o_bstride, 0};
   hipStream_t st = (hipStream_t)stream;
-  const bool stagger = (flags & 2) != 0;
-  return (flags & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger, B, bs)
-                     : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, stagger, B, bs);
+  return (flags & 1) ? launch_attn_vt<8, 8, true>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, flags, B, bs)
+                     : launch_attn_vt<8, 8, false>(q, ldq, k, ldk, vt, ldvt, o, ldo, Sq, Sk, H, scale, st, flags, B, bs);
 }
 
 // variant: 0 = default (= 6); lazy-rescale threshold of the pipelined kernel: 4 = eager rescale (every tile), 5 = threshold 4, 6 = threshold 8

@@ -202,6 +202,7 @@ def layernorm(x, weight=None, bias=None, scale=None, shift=None, eps=1e-6, out=N
 
 ATTN_Q_PRESCALED = 0x100
 ATTN_STAGGER = 0x200  # x2v.h X2V_ATTN_VT_STAGGER: query block b starts its key walk (b mod 8) tiles in (an opt-in; wan.SELF_ATTN_STAGGER decides for the Wan drivers)
+ATTN_ONE_WALK = 0x400  # x2v.h X2V_ATTN_VT_ONE_WALK: never the persistent short-walk form (A/B runs, the bit-equality test of the two forms)
 ATTN_FAST = 12  # "ping-pong" kernel on a pre-transposed V (x2v_transpose_heads_bf16 + x2v_attn_fwd_bf16_vt); used with
 #                 ATTN_Q_PRESCALED by the fused block drivers.  attention() does the transposition itself for this variant.
 ATTN_PRESCALE = 1.4426950408889634 / math.sqrt(128.0)  # softmax scale * log2(e) for head_dim 128
@@ -422,12 +423,13 @@ def gemm_kernel_choice(M, N, K, ldx=None, ldw=None, fp8=False, with_form=False):
     return (rc & 0xff, bool(rc & 0x100)) if with_form else rc & 0xff
 
 
-def attn_vt_launch_plan(Sq, Sk, num_heads, batch=1, stagger=False):
-    """(xcd_remap, staggered_walk) that x2v_attn_fwd_bf16_vt(_batched) takes for this shape (x2v_attn_vt_launch_plan; host-only)."""
-    rc = _lib.x2v_attn_vt_launch_plan(Sq, Sk, num_heads, batch, 2 if stagger else 0)
+def attn_vt_launch_plan(Sq, Sk, num_heads, batch=1, stagger=False, one_walk=False, with_short=False):
+    """(xcd_remap, staggered_walk) that x2v_attn_fwd_bf16_vt(_batched) takes for this shape (x2v_attn_vt_launch_plan; host-only);
+    with_short: (xcd_remap, staggered_walk, persistent_short_walk)."""
+    rc = _lib.x2v_attn_vt_launch_plan(Sq, Sk, num_heads, batch, (2 if stagger else 0) | (4 if one_walk else 0))
     if rc < 0:
         raise X2VError(f"attn_vt_launch_plan: bad shape Sq={Sq} Sk={Sk} H={num_heads} B={batch}")
-    return bool(rc & 1), bool(rc & 0x100)
+    return (bool(rc & 1), bool(rc & 0x100), bool(rc & 0x200)) if with_short else (bool(rc & 1), bool(rc & 0x100))
 
 
 def mfma_probe(milliseconds=1500):
@@ -482,7 +484,7 @@ def attention(q, k, v, num_heads, head_dim=128, scale=0.0, out=None, variant=0, 
             raise X2VError(f"attention: vt must be the contiguous bf16 [H, ceil(Sk/64), 128, 64] tensor of transpose_heads, got {tuple(vt.shape)}")
         _check(
             _lib.x2v_attn_fwd_bf16_vt(_p(q2), q2.stride(0), _p(k2), k2.stride(0), _p(vt), vt.shape[1] * 64, _p(out2), out2.stride(0), Sq, Sk, num_heads, head_dim, scale,
-                                      (1 if (variant & ATTN_Q_PRESCALED) else 0) | (2 if (variant & ATTN_STAGGER) else 0), _stream()),
+                                      (1 if (variant & ATTN_Q_PRESCALED) else 0) | (2 if (variant & ATTN_STAGGER) else 0) | (4 if (variant & ATTN_ONE_WALK) else 0), _stream()),
             "attn_fwd_vt",
         )
         return out2

@@ -137,6 +137,17 @@ def test_attention_launch_plan_for_the_benchmark_shapes():
     assert lib.attn_vt_launch_plan(59528, 119000, 3) == (True, False)
     assert lib.attn_vt_launch_plan(20280, 20280, 12, stagger=True) == (True, True)
     assert lib.attn_vt_launch_plan(2560, 2560, 5) == (False, False)
+    # cross-attention over the 512-token text context (transformer_infer.py:424-455): the persistent short-walk form (bit 9) for 4..32 whole key tiles
+    # and >= 512 query blocks x heads; the 257 CLIP tokens of i2v (a partial tile), a 1182-tile self-attention walk and small launches keep one-walk workgroups
+    assert lib.attn_vt_launch_plan(75600, 512, 40, with_short=True) == (False, False, True)
+    assert lib.attn_vt_launch_plan(75648, 512, 40, batch=2, with_short=True) == (False, False, True)
+    assert lib.attn_vt_launch_plan(20280, 512, 12, with_short=True) == (False, False, True)
+    assert lib.attn_vt_launch_plan(9450, 512, 40, with_short=True) == (False, False, True)
+    assert lib.attn_vt_launch_plan(75600, 512, 40, one_walk=True, with_short=True)[2] is False
+    assert lib.attn_vt_launch_plan(75600, 257, 40, with_short=True)[2] is False
+    assert lib.attn_vt_launch_plan(75600, 192, 40, with_short=True)[2] is False
+    assert lib.attn_vt_launch_plan(75648, 75648, 40, with_short=True)[2] is False
+    assert lib.attn_vt_launch_plan(2048, 512, 12, with_short=True)[2] is False
     with pytest.raises(lib.X2VError):
         lib.attn_vt_launch_plan(0, 10, 1)
 

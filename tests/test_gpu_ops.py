@@ -189,6 +189,59 @@ def test_attention_vs_oracle(lib, Sq, Sk, H):
     assert e_ours <= 1.5 * e_ref + 1e-3, (e_ours, e_ref)
 
 
+def test_attention_persistent_short_walk(lib):
+    """Cross-attention's launch form (x2v_attn_fwd_bf16_vt, plan bit 9: 4..32 whole key tiles, >= 512 query blocks x heads): a workgroup walks a
+    range of (sequence, head, query block) items as one tile stream.  Against the ORACLE (torch_sdpa, attn_weight.py:229-239) at a size it finishes
+    in seconds, and bit for bit against the one-walk form (X2V_ATTN_VT_ONE_WALK, itself oracle-tested above) at the shapes the oracle cannot reach:
+    the minimum and maximum walk lengths, ragged last query blocks, ranges that cross heads (more heads than workgroup ranges and fewer), a
+    strided q / out view, the model's shape (75 600 x 512 x 40), q prescaled or not, and two stacked sequences in one launch."""
+    from oracle import wan_oracle as O
+
+    gen = torch.Generator().manual_seed(4242)
+    Sq, Sk, H = 3365, 512, 40  # 14 query blocks x 40 heads = 560 items; the last block of every head has 37 rows
+    assert lib.attn_vt_launch_plan(Sq, Sk, H, with_short=True) == (False, False, True)
+    assert lib.attn_vt_launch_plan(Sq, Sk, H, one_walk=True, with_short=True)[2] is False
+    q = torch.randn(Sq, H, 128, generator=gen).to(torch.bfloat16)
+    k = torch.randn(Sk, H, 128, generator=gen).to(torch.bfloat16)
+    v = torch.randn(Sk, H, 128, generator=gen).to(torch.bfloat16)
+    ref = O.sdpa(q, k, v)
+    got = lib.attention(dev(q), dev(k), dev(v), H, variant=lib.ATTN_FAST)
+    assert_bf16_close(got, ref, ulps=0.256, atol=8e-3, name="persistent short-walk form vs oracle")
+    f32 = O.attention_fp32(q, k, v)
+    e_ours, e_ref = (got.float().cpu() - f32).abs().max().item(), (ref.float() - f32).abs().max().item()
+    assert e_ours <= 1.5 * e_ref + 2e-3, (e_ours, e_ref)
+
+    gcu = torch.Generator(device="cuda").manual_seed(7)
+    for Sq, Sk, H, pre in [(3365, 512, 40, False), (20000, 256, 12, False), (20000, 320, 12, True), (5000, 2048, 30, True), (131072 + 5, 384, 1, False), (75600, 512, 40, False), (75600, 512, 40, True),
+                           (9450, 512, 40, True)]:
+        assert lib.attn_vt_launch_plan(Sq, Sk, H, with_short=True)[2], (Sq, Sk, H)
+        wide = torch.randn(Sq, H * 128 + 256, generator=gcu, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        q = wide[:, 128 : 128 + H * 128]  # token stride != H * 128
+        k = torch.randn(Sk, H * 128, generator=gcu, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        v = torch.randn(Sk, H * 128, generator=gcu, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        k[Sk // 2] *= 4.0  # a late dominant key: the lazy rescale branch fires inside the walk
+        vt = lib.transpose_heads(v, H)
+        flags = lib.ATTN_FAST | (lib.ATTN_Q_PRESCALED if pre else 0)
+        a = torch.full((Sq, H * 128 + 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+        b = torch.full_like(a, float("nan"))
+        lib.attention(q, k, None, H, out=a[:, : H * 128], variant=flags, vt=vt)
+        lib.attention(q, k, None, H, out=b[:, : H * 128], variant=flags | lib.ATTN_ONE_WALK, vt=vt)
+        assert torch.isfinite(a[:, : H * 128].float()).all(), (Sq, Sk, H)
+        assert torch.equal(a[:, : H * 128], b[:, : H * 128]), f"persistent vs one-walk form Sq={Sq} Sk={Sk} H={H} prescaled={pre}"
+        assert torch.isnan(a[:, H * 128 :].float()).all(), "columns behind the heads must not be written"
+    # two stacked sequences (the CFG pair) in one launch: sequence b's keys are the first Sk rows of its slot
+    Sp, Sk, H = 4096, 512, 40
+    q = torch.randn(2 * Sp, H * 128, generator=gcu, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    k = torch.randn(2 * Sp, H * 128, generator=gcu, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    v = torch.randn(2 * Sp, H * 128, generator=gcu, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    vt = lib.transpose_heads(v, H)
+    one = lib.attention_batched(q, k, vt, H, 2, Sp, Sk, one_launch=True)
+    for b in range(2):
+        rows = slice(b * Sp, (b + 1) * Sp)
+        sep = lib.attention(q[rows], k[rows][:Sk], v[rows][:Sk], H, variant=lib.ATTN_FAST | lib.ATTN_ONE_WALK)
+        assert torch.equal(one[rows], sep), f"stacked sequence {b}"
+
+
 def test_attention_properties_full_size(lib):
     """At the BASELINE config-2 sequence length (S = 20280, where the CPU oracle is too slow): softmax rows sum to 1
     (V = 1 → O = 1), identical keys → O = mean(V), and a dominant key → O = its V row (online-softmax rescale path)."""
