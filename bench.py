@@ -745,7 +745,7 @@ def main():
     traffic, traffic_note = None, "no PMC summary for this shape under profiles/"
     # PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py: this very command under --pmc FETCH_SIZE / WRITE_SIZE, the rows of this
     # kernel instantiation averaged per launch); the summary they wrote for THIS launch form is reported, never one of another form
-    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_attn_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), None)  # the newest round's passes
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_attn_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(q)), None)  # the newest round's passes
     if world == 1 and pmc_path is not None:
         with open(pmc_path) as fh:
             pmc = json.load(fh)

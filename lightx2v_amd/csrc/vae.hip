@@ -1102,15 +1102,21 @@ static int vae_prep_f16_impl(const float* x, void* y, int T, int Hh, int Ww, int
               X2V_E_ALIGN, "vae_prep_f16: 16-byte alignment (strides multiples of 8 halves, pixel stride >= the channels written)");
   const int64_t npix = (int64_t)T * Hh * Ww;
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 128) {
-    const int64_t blocks = std::min<int64_t>((npix + 7) / 8, 65536 * 4);
-    hipLaunchKernelGGL((vae_prep_kernel<32, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
+  auto launch = [&](auto lppc) {
+    constexpr int LPP = decltype(lppc)::value;
+    const int64_t blocks = std::min<int64_t>((npix + 256 / LPP - 1) / (256 / LPP), 65536 * 4);
+    hipLaunchKernelGGL((vae_prep_kernel<LPP, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
                        y_frame_stride, y_row_stride, y_px_stride, split);
-  } else {
-    const int64_t blocks = std::min<int64_t>((npix + 3) / 4, 65536 * 4);
-    hipLaunchKernelGGL((vae_prep_kernel<64, _Float16>), dim3((unsigned)blocks), dim3(256), 0, st, x, (_Float16*)y, npix, Hh, Ww, C, gamma, a, b, silu, upsample,
-                       y_frame_stride, y_row_stride, y_px_stride, split);
-  }
+  };
+  // lanes per pixel: a lane takes up to four 4-channel chunks LPP apart.  The decoder's widths are 3 x 2^n chunks (96 / 192 / 384 channels = 24 / 48 / 96):
+  // a third of them per pixel keeps every lane busy (the power-of-two choice below idles a quarter of each wave)
+  const int nch = C / 4;
+  static const bool thirds = [] { const char* e = getenv("X2V_VAE_PREP_POW2"); return e == nullptr || atoi(e) == 0; }();  // A/B: 1 = the power-of-two lane groups
+  if (thirds && nch == 24) launch(std::integral_constant<int, 8>{});
+  else if (thirds && nch == 48) launch(std::integral_constant<int, 16>{});
+  else if (thirds && nch == 96) launch(std::integral_constant<int, 32>{});
+  else if (C <= 128) launch(std::integral_constant<int, 32>{});
+  else launch(std::integral_constant<int, 64>{});
   X2V_LAUNCH_CHECK("vae_prep_f16 launch");
   return X2V_OK;
 }

@@ -144,6 +144,49 @@ def test_gemm_wan14b_rank_of_8_rows_vs_oracle(lib, K, N, epi):
         assert_bf16_close(res[rc], ref_r, ulps=1, atol=6e-3, bad_frac=2e-3, name=epi)
 
 
+def test_w8a8_operator_on_the_exchange_buffers_wan14b_rank_of_8(lib):
+    """The w8a8 operator class (mm_weight.py:236-245, :287-319) on an 8-GPU rank's Ulysses buffers at the Wan-14B dimensions, through the calls the
+    copy-free driver makes: `apply(x, out=3-D)` writes the seq->head send buffer [8, 9450, 640] from the epilogue of the continuous fp8 kernel
+    (all2all.py:29-33 without the transposing copy), `apply(3-D x, residual)` de-blocks the received head->seq buffer in its quantisation pass
+    (all2all.py:70-75) and multiplies row-major.  Both must carry the row-major operator's bits; the row-major result is checked against the oracle's
+    restated quantise + scaled-mm on a row sample; the form bit says which kernel ran."""
+    from lightx2v_amd.ops import MMWeightFp8Hip
+    from oracle import wan_oracle as O
+
+    M, nb, D = S_WAN // WORLD, WORLD, 5120
+    family, continuous = lib.gemm_kernel_choice(M, D, D, fp8=True, with_form=True)
+    assert (family, continuous) == (2, lib.switches()["X2V_GEMM_FP8_CONTINUOUS"] >= 1)
+    g = torch.Generator(device="cuda").manual_seed(20)
+    x = torch.randn(M, D, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(D, D, generator=g, device="cuda") / math.sqrt(D)).to(torch.bfloat16)
+    b = (torch.randn(D, generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+    mm = MMWeightFp8Hip("p.weight", "p.bias")
+    mm.config = {"weight_auto_quant": True}
+    mm.load({"p.weight": w, "p.bias": b})
+    row = mm.apply(x)
+    rows = sample_rows(M, 96, seed=3)
+    rc = rows.cuda()
+    ref = O.mm_fp8(x[rc].cpu(), mm.weight.cpu(), mm.weight_scale.cpu(), b.cpu())
+    assert_bf16_close(row[rc], ref, ulps=1, atol=2e-3, bad_frac=2e-3, name="w8a8 operator, rank-of-8 rows vs O.mm_fp8")
+    record(f"rank-of-8 w8a8 operator {M}x{D}x{D}", rel_l2=rel_l2(row[rc], ref))
+    # q / k / v: the send buffer, a strided view inside a poisoned allocation
+    buf = torch.full((nb, M + 2, D // nb), 7.0, dtype=torch.bfloat16, device="cuda")
+    mm.apply(x, out=buf[:, 1 : M + 1])
+    assert torch.equal(buf[:, 1 : M + 1].transpose(0, 1).reshape(M, D), row), "N-blocked y (y_cbw = 640) must carry the row-major operator's bits"
+    assert (buf[:, 0] == 7).all() and (buf[:, M + 1] == 7).all(), "rows around the blocks written"
+    # output projection: K-blocked x (the receive buffer) + gated residual
+    xb = x.view(M, nb, D // nb).transpose(0, 1).contiguous()
+    res = torch.randn(M, D, generator=g, device="cuda").to(torch.bfloat16)
+    gate = (torch.randn(1, D, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    r1, r2 = res.clone(), res.clone()
+    mm.apply(xb, epilogue=lib.EPI_RESIDUAL, resid=r1, gate=gate)
+    mm.apply(x, epilogue=lib.EPI_RESIDUAL, resid=r2, gate=gate)
+    assert torch.equal(r1, r2), "K-blocked x through the de-blocking quantisation pass must give the row-major operator's bits"
+    ref_r = res[rc].cpu()
+    ref_r.add_(ref * gate.cpu().squeeze(0))
+    assert_bf16_close(r1[rc], ref_r, ulps=1, atol=6e-3, bad_frac=2e-3, name="w8a8 o-projection + gate-residual")
+
+
 @pytest.mark.parametrize("rank", [0, 7])
 def test_rmsnorm_rope_blocked_wan14b_rank_of_8_vs_oracle(lib, rank):
     """x2v_rmsnorm_rope_blocked_bf16 as rank r of 8 calls it on Wan-14B 720p: 9 450 rows whose grid positions start at s0 = r x 9450 of the
