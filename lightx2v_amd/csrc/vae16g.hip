@@ -42,7 +42,8 @@ constexpr int G_HPS = 5;                                                        
 constexpr int G_W_OFF = 2 * G_H_BYTES;
 constexpr unsigned G_OOB = 0x80000000u;
 static_assert(4 * G_HP * 16 >= G_HROWS && 2 * G_HPS == G_HP, "piece counts");
-// NCB = cout blocks of 16 per workgroup: 6 (96 couts: every 3x3 convolution of the decoder's body) or 1 (the 3-channel head: fragment-read bound, but a third
+// NCB = cout blocks of 16 per workgroup: 6 (96 couts: every 3x3 convolution of the Wan decoder's body), 8 (128 couts = 8 x 8 accumulator tiles, the whole AGPR half:
+// the HunyuanVideo VAE's 128 / 256 / 512-channel convolutions; 64 MFMAs against 16 fragment reads per tap, LDS 152 KiB) or 1 (the 3-channel head: fragment-read bound, but a third
 // of the MFMAs of the 32-cout minimum of the 64-pixel kernel)
 template <int NCB>
 struct GCfg {
@@ -66,19 +67,24 @@ __device__ __forceinline__ void g_for(F&& f) {
 // The 192 accumulator registers are AGPRs addressed literally by the asm statements below (left to the register allocator the accumulators bounce between the
 // two halves of the file: 337 spills).  Every such statement names all of them as clobbered (gemm256s.hip: the round-3 incident).
 #define G_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
-template <int I>
+// HI: the 128-cout form (NCB = 8) holds 8 x 8 accumulator tiles = all 256 AGPRs; its statements name the upper 64 as well
+#define G_AGPRS_HI "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+template <int I, bool HI>
 __device__ __forceinline__ void g_mfma(const g_half8_t& wf, const g_half8_t& xf) {  // accumulator tile I = cb * 8 + pb is a[4 I : 4 I + 3]
-  asm volatile("v_mfma_f32_16x16x32_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(4 * I), "i"(4 * I + 3) : G_AGPRS);
+  if constexpr (HI) asm volatile("v_mfma_f32_16x16x32_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(4 * I), "i"(4 * I + 3) : G_AGPRS, G_AGPRS_HI);
+  else asm volatile("v_mfma_f32_16x16x32_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(wf), "v"(xf), "i"(4 * I), "i"(4 * I + 3) : G_AGPRS);
 }
-template <int R>
+template <int R, bool HI>
 __device__ __forceinline__ float g_acc_read() {
   float x;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R) : G_AGPRS);
+  if constexpr (HI) asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R) : G_AGPRS, G_AGPRS_HI);
+  else asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R) : G_AGPRS);
   return x;
 }
-template <int R>
+template <int R, bool HI>
 __device__ __forceinline__ void g_acc_zero() {
-  asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(R) : G_AGPRS);
+  if constexpr (HI) asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(R) : G_AGPRS, G_AGPRS_HI);
+  else asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(R) : G_AGPRS);
 }
 
 #ifndef X2V_G_BAR_SLOT
@@ -92,12 +98,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int Hp, int Cin, int Cout, int kt, int flags, int ncol, int tiles_x, int tiles_y, int kchunks) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  asm volatile("" ::: G_AGPRS);  // the accumulator half belongs to the asm statements of this kernel
+  constexpr bool HI = NCB > 6;
+  if constexpr (HI) asm volatile("" ::: G_AGPRS, G_AGPRS_HI);  // the accumulator half belongs to the asm statements of this kernel
+  else asm volatile("" ::: G_AGPRS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, g4 = lane >> 4;
   constexpr int G_WP = GCfg<NCB>::WP, G_W_BYTES = GCfg<NCB>::W_BYTES, NM = GCfg<NCB>::NM, NR = GCfg<NCB>::NR;
-  constexpr int BAR = NCB == 6 ? X2V_G_BAR_SLOT : NM - 2;
+  constexpr int BAR = NCB >= 6 ? X2V_G_BAR_SLOT : NM - 2;
   const int nslabs = kt * kchunks;
   const unsigned ntiles = (unsigned)T * (unsigned)tiles_y * (unsigned)tiles_x * (unsigned)ncol;
 
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   prologue_dma();
 
   for (;;) {
-    g_for<0, 32 * NCB>([&](auto rc) { g_acc_zero<decltype(rc)::value>(); });
+    g_for<0, 32 * NCB>([&](auto rc) { g_acc_zero<decltype(rc)::value, HI>(); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     g_for<0, NR>([&](auto qc) { G_READ(0, decltype(qc)::value, 0, 0, 0) });
@@ -234,10 +242,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           constexpr int NJ = J == 2 ? 0 : J + 1, NDH = J == 2 ? (DH + 1) % 3 : DH, NP = (J == 2 && DH == 2) ? (P ^ 1) : P;
           g_for<0, NM>([&](auto mc) {
             constexpr int m = decltype(mc)::value, cb = m >> 3, pb = m & 7;
-            g_mfma<cb * 8 + pb>(fw[SET][cb], fx[SET][pb]);
+            g_mfma<cb * 8 + pb, HI>(fw[SET][cb], fx[SET][pb]);
             // (reads, weight and halo pieces are issued unconditionally: behind the tile's last step they fetch nothing — masked pieces, stale fragments —
             //  which keeps the stream free of branches and the counted waits below the same constants for every step)
-            if constexpr (NCB == 6) {  // a read behind every second MFMA, a weight piece every 8 in the first tap, a halo piece every 8 in the second
+            if constexpr (NCB >= 6) {  // a read behind every second MFMA, a weight piece every 8 in the first tap, a halo piece every 8 in the second
               if constexpr ((m & 1) == 0 && (m >> 1) < NR) G_READ(SET ^ 1, m >> 1, NP, NDH, NJ)
               if constexpr (J == 0 && (m - 5) % 8 == 0 && (m - 5) / 8 >= 0 && (m - 5) / 8 < G_WP) G_DMA_W((m - 5) / 8, (DH + 2) % 3, wso, w_issue);
               if constexpr (J == 1 && DH < 2 && (m - 3) % 8 == 0 && (m - 3) / 8 >= 0 && (m - 3) / 8 < G_HPS) G_DMA_H(DH * G_HPS + (m - 3) / 8, P ^ 1, rx_n, xso_n, has_next);
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         g_for<0, NCB>([&](auto cbc) {
           constexpr int cb = decltype(cbc)::value, I = cb * 8 + pb;
-          float4 o = make_float4(g_acc_read<4 * I + 0>() + bv[cb].x, g_acc_read<4 * I + 1>() + bv[cb].y, g_acc_read<4 * I + 2>() + bv[cb].z, g_acc_read<4 * I + 3>() + bv[cb].w);
+          float4 o = make_float4(g_acc_read<4 * I + 0, HI>() + bv[cb].x, g_acc_read<4 * I + 1, HI>() + bv[cb].y, g_acc_read<4 * I + 2, HI>() + bv[cb].z, g_acc_read<4 * I + 3, HI>() + bv[cb].w);
           if (resid != nullptr) {
             o.x += rv[cb].x;
             o.y += rv[cb].y;
@@ -347,9 +355,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-// Shapes this kernel takes (the rest stays on vae_conv16h): Cout a multiple of 96 (96-cout tiles) or at most 16 (one 16-cout tile), Cin a multiple of 32, at
+// Shapes this kernel takes (the rest stays on vae_conv16h): Cout a multiple of 96 (96-cout tiles) or of 128 (128-cout tiles) or at most 16 (one 16-cout tile), Cin a multiple of 32, at
 // least half a tile wide.
-bool vae_conv16g_ok(int Ww, int Cin, int Cout) { return (Cout % 96 == 0 || Cout <= 16) && Cin % 32 == 0 && Ww >= 16; }
+bool vae_conv16g_ok(int Ww, int Cin, int Cout) { return (Cout % 96 == 0 || Cout % 128 == 0 || Cout <= 16) && Cin % 32 == 0 && Ww >= 16; }
 
 template <int NCB>
 static int launch_vconv16g(const void* xp, const void* cache, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y, int T, int Hh,
@@ -380,6 +388,7 @@ static int launch_vconv16g(const void* xp, const void* cache, int64_t fs, int64_
 int vae_conv16g_dispatch(const void* xp, const void* cache, int64_t fs, int64_t rs, int64_t ps, const void* w, int64_t wrs, const float* bias, const float* resid, float* y,
                          int T, int Hh, int Ww, int Cin, int Cout, int kt, int flags, int cin_zero_tail, hipStream_t st) {
   if (Cout % 96 == 0) return launch_vconv16g<6>(xp, cache, fs, rs, ps, w, wrs, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, cin_zero_tail, st);
+  if (Cout % 128 == 0) return launch_vconv16g<8>(xp, cache, fs, rs, ps, w, wrs, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, cin_zero_tail, st);
   return launch_vconv16g<1>(xp, cache, fs, rs, ps, w, wrs, bias, resid, y, T, Hh, Ww, Cin, Cout, kt, flags, cin_zero_tail, st);
 }
 

@@ -310,13 +310,15 @@ def test_vae_conv16_128x96_kernel_against_conv3d_and_the_other_kernels():
     order.  Shapes: ragged tiles in H and W (tile = 16 x 32 pixels), one to four cout tiles, kt 1 and 3 with a non-zero 2-frame cache, 2..12 32-channel
     slabs (odd and even counts: both halo buffers end a tile), residual, clamp, the zero-tail flag (288 channels in a 320-channel buffer: bit-identical
     with and without the flag), several tiles per workgroup (more tiles than CUs), and the one-cout-block form the decoder's 3-channel head takes
-    (Cout 3 and 16: weight rows beyond Cout masked, element-wise stores)."""
+    (Cout 3 and 16: weight rows beyond Cout masked, element-wise stores); and the 128-cout form of the same kernel (Cout % 128 == 0 and not a multiple of 96)."""
     from lightx2v_amd import lib
 
     g = torch.Generator().manual_seed(11)
     cached_runs = 0
     for (T, H, W, Cin, Cout, kt, tail) in [(2, 8, 32, 128, 96, 1, 0), (2, 9, 11, 64, 192, 3, 0), (1, 17, 40, 288, 96, 3, 32), (3, 33, 70, 96, 384, 3, 32), (2, 16, 64, 192, 288, 1, 0),
-                                           (9, 90, 160, 64, 96, 3, 0), (1, 17, 33, 64, 3, 3, 0), (2, 36, 70, 288, 3, 3, 32), (2, 9, 40, 128, 16, 1, 0)]:
+                                           (9, 90, 160, 64, 96, 3, 0), (1, 17, 33, 64, 3, 3, 0), (2, 36, 70, 288, 3, 3, 32), (2, 9, 40, 128, 16, 1, 0),
+                                           # the 128-cout form (8 x 8 accumulator tiles; the HunyuanVideo VAE's widths): one, two and four cout tiles
+                                           (2, 17, 40, 128, 128, 3, 0), (1, 33, 70, 256, 256, 1, 0), (2, 16, 64, 512, 256, 3, 0), (1, 9, 33, 64, 512, 1, 0)]:
         cp = (Cin + 63) // 64 * 64
         assert cp - Cin == tail
         x = torch.randn(kt - 1 + T, H, W, Cin, generator=g).half()  # the leading kt - 1 frames are the cache
