@@ -378,7 +378,7 @@ int x2v_vae_conv_f16(const void* xp, int64_t x_frame_stride, int64_t x_row_strid
 /* x2v_vae_conv_f16 with the causal convolution's feature cache (the reference's feat_cache entry, vae.py:16,199-214: the last kt - 1 input frames of the
  * previous chunk) in a buffer of its own: input frames 0 .. kt-2 are read from `cache` ([kt-1][H+2][W+2][Cin], xp's strides), the rest from xp, whose own
  * leading kt - 1 frames are not read — a frame buffer shared by several convolutions then needs no copy of the cache in front of it.  Only where
- * x2v_vae_conv_f16_cached_ok(...) == 1 (3x3 kernels with Cout % 96 == 0 or Cout <= 16: the 128-pixel kernel); bit-identical to x2v_vae_conv_f16 on a buffer
+ * x2v_vae_conv_f16_cached_ok(...) == 1 (3x3 kernels with Cout % 96 == 0, Cout % 128 == 0 or Cout <= 16: the 128-pixel kernel); bit-identical to x2v_vae_conv_f16 on a buffer
  * that carries the same frames. */
 int x2v_vae_conv_f16_cached(const void* xp, const void* cache, int64_t x_frame_stride, int64_t x_row_stride, int64_t x_px_stride, const void* w, int64_t w_row_stride,
                             const float* bias, const float* resid, float* y, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw, int flags, void* stream);
