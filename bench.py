@@ -457,6 +457,41 @@ def run_wan_vae_decode(latent_shape=(16, 21, 90, 160)):
     return rec
 
 
+def run_hunyuan_vae_decode(latent_shape=(1, 16, 33, 90, 160)):
+    """The HunyuanVideo VAE's tiled decode of config #5's latent (720p x 129 frames), fp16 convolution operands as the reference runs it
+    (autoencoder_kl_causal_3d.py:347-518: spatial + temporal tiles with blends).  One decode, timed with its first-use allocations (the tiles reuse
+    their buffers from the second tile on); the 16-bit convolution launches' algorithmic FLOPs are counted on the way."""
+    from lightx2v_amd import hunyuan_vae, lib, synth
+
+    cfg = synth.HUNYUAN_VAE_CFG
+    m = hunyuan_vae.VideoEncoderKLCausal3DModel(synth.synth_hunyuan_vae_weights(cfg, seed=0), cfg, conv16=True)
+    z = (torch.randn(*latent_shape, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    flops = [0.0]
+    orig16 = lib.vae_conv16
+
+    def counted16(xp, strides, weight, out, T, H, W, **kw):
+        flops[0] += 2.0 * T * H * W * weight.shape[0] * weight.shape[4] * weight.shape[1] * weight.shape[2] * weight.shape[3]
+        return orig16(xp, strides, weight, out, T, H, W, **kw)
+
+    lib.vae_conv16 = counted16
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = m.decode(z)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        lib.vae_conv16 = orig16
+    assert torch.isfinite(out).all(), "non-finite VAE output (hunyuan)"
+    rec = {"workload": f"hunyuan_vae_decode z{list(latent_shape)} -> {list(out.shape)}", "conv_operands": "fp16 (the reference's precision)", "decode_s": dt,
+           "conv16_tflop": flops[0] / 1e12, "roofline": {"kernel": "x2v::vae_conv16g_kernel<8> (the 16-bit halo-tiled 3x3x3 convolutions, 128 pixels x 128 couts per wave)",
+                                                         "bound": "mfma", "achieved": flops[0] / dt / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                         "frac": flops[0] / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, "note": "whole-decode average: numerator = the 16-bit convolution launches' FLOPs only"}}
+    del m, out, z
+    torch.cuda.empty_cache()
+    return rec
+
+
 def other_configs(headline_ms_per_step, frames, infer_steps):
     """BASELINE.json's other single-GPU configurations and the VAE decode, run by the driver's command behind the headline steps (frames/s
     "both with and without VAE"; the reference runs the decode after the loop, default_runner.py:202-221).  None of it enters `value`."""
@@ -464,7 +499,8 @@ def other_configs(headline_ms_per_step, frames, infer_steps):
     for key, fn in (("config2_wan1.3b_480px49f", lambda: run_wan_config("wan1.3b_480px49f", 2, 1)),
                     ("config4_wan14b_w8a8_distill_720px81f", lambda: run_wan_config("wan14b_720px81f", 2, 1, fp8=True, distill=True)),
                     ("config5_hunyuan13b_720px129f_1gpu", lambda: run_hunyuan_config("hunyuan13b_720px129f", 1, 1)),
-                    ("wan_vae_decode_720px81f", run_wan_vae_decode)):
+                    ("wan_vae_decode_720px81f", run_wan_vae_decode),
+                    ("hunyuan_vae_decode_720px129f", run_hunyuan_vae_decode)):
         t0 = time.perf_counter()
         try:
             out[key] = fn()
@@ -479,6 +515,10 @@ def other_configs(headline_ms_per_step, frames, infer_steps):
         c4 = out["config4_wan14b_w8a8_distill_720px81f"]
         if "denoise_loop_s" in c4:
             c4["end_to_end_with_vae_s"] = c4["denoise_loop_s"] + dec
+    c5, dec5 = out["config5_hunyuan13b_720px129f_1gpu"], out["hunyuan_vae_decode_720px129f"].get("decode_s")
+    if "denoise_loop_s" in c5 and dec5 is not None:
+        c5["end_to_end_with_vae_s"] = c5["denoise_loop_s"] + dec5
+        c5["frames_per_s_with_vae"] = c5["frames"] / c5["end_to_end_with_vae_s"]
     return out
 
 

@@ -9,10 +9,11 @@ run() { name=$1; shift; t0=$(date +%s); "$@"; echo "$name rc=$? ($(( $(date +%s)
 for m in probe misc norm rope gemm attn fp8 conv; do run "check_$m" timeout 200 tools/x2v_check $m > "$OUT/check_$m.log" 2>&1; tail -1 "$OUT/check_$m.log" >> "$OUT/summary.txt"; done
 run pytest timeout 1500 python -m pytest tests -m gpu -q --timeout 900 --durations=12 > "$OUT/pytest.log" 2>&1; tail -18 "$OUT/pytest.log" | cut -c1-200 >> "$OUT/summary.txt"; cp gpurun_out/parity_summary.jsonl "$OUT/" 2>/dev/null
 run smoke timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" >> "$OUT/summary.txt"
-# the DRIVER's exact command (BENCH_rNN.json is produced by it: 25 sustained steps at the 1400 W cap, not the 3-step default) — VERDICT r3 #3-i
+# the DRIVER's exact command (BENCH_rNN.json is produced by it: 25 sustained steps at the 1400 W cap, not the 3-step default)
 run bench_driver_command timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_command.json" 2> "$OUT/bench_driver_command.err"; cat "$OUT/bench_driver_command.json" >> "$OUT/summary.txt"
 run bench_default timeout 900 python bench.py --no-cpu-baseline > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cat "$OUT/bench_default.json" >> "$OUT/summary.txt"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err"); echo "prof rc=$?" | tee -a "$OUT/summary.txt"
+# kernel stats of the headline leg alone: the other_configs legs launch the same kernel instantiations and would mix into the per-kernel averages
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-other-configs > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err"); echo "prof rc=$?" | tee -a "$OUT/summary.txt"
 find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 run bench13 timeout 600 python bench.py --workload wan1.3b_480px49f --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench13.json" 2> "$OUT/bench13.err"; cat "$OUT/bench13.json" >> "$OUT/summary.txt"
 run bench_fp8_distill timeout 600 python bench.py --fp8 --distill --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench14_fp8_distill.json" 2> "$OUT/bench14_fp8_distill.err"; cat "$OUT/bench14_fp8_distill.json" >> "$OUT/summary.txt"
@@ -20,6 +21,7 @@ run gemm_vs_hipblaslt timeout 300 python tools/gemm_vs_hipblaslt.py > "$OUT/gemm
 run hunyuan timeout 600 python tools/hunyuan_bench.py > "$OUT/hunyuan13b.json" 2> "$OUT/hunyuan13b.err"; cat "$OUT/hunyuan13b.json" >> "$OUT/summary.txt"
 run e2e_13b timeout 300 python tools/e2e.py --workload wan1.3b_480px49f --steps 50 > "$OUT/e2e_wan13b_480p.json" 2> "$OUT/e2e13.err"; cat "$OUT/e2e_wan13b_480p.json" >> "$OUT/summary.txt"
 run e2e_fp8_distill timeout 400 python tools/e2e.py --fp8 --distill > "$OUT/e2e_wan14b_fp8_distill.json" 2> "$OUT/e2e_fp8.err"; cat "$OUT/e2e_wan14b_fp8_distill.json" >> "$OUT/summary.txt"
+run vae_hunyuan timeout 400 python tools/hunyuan_vae_bench.py --full > "$OUT/vae_hunyuan_720p129f.json" 2> "$OUT/vae_hunyuan.err"; cat "$OUT/vae_hunyuan_720p129f.json" >> "$OUT/summary.txt"
 run vae_wan_split timeout 300 python tools/vae_bench.py --latent 16,21,90,160 --split > "$OUT/vae_wan_720p81f_split.json" 2> "$OUT/vae_wan.err"; cat "$OUT/vae_wan_720p81f_split.json" >> "$OUT/summary.txt"
 # attention kernel generations, same box (tools/build_attn_v8_variant.sh must have been run before the call: the variant library travels with the snapshot)
 if [ -f tools/probes/ab/attn_r3/libx2v_hip.so ] && [ "${ATTN_AB:-1}" = "1" ]; then
