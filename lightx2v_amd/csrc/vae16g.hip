@@ -43,7 +43,8 @@ constexpr int G_W_OFF = 2 * G_H_BYTES;
 constexpr unsigned G_OOB = 0x80000000u;
 static_assert(4 * G_HP * 16 >= G_HROWS && 2 * G_HPS == G_HP, "piece counts");
 // NCB = cout blocks of 16 per workgroup: 6 (96 couts: every 3x3 convolution of the Wan decoder's body), 8 (128 couts = 8 x 8 accumulator tiles, the whole AGPR half:
-// the HunyuanVideo VAE's 128 / 256 / 512-channel convolutions; 64 MFMAs against 16 fragment reads per tap, LDS 152 KiB) or 1 (the 3-channel head: fragment-read bound, but a third
+// the HunyuanVideo VAE's 128 / 256 / 512-channel convolutions; 64 MFMAs against 16 fragment reads per tap, LDS 152 KiB; hipcc spills 28 of the tile-invariant address
+// registers of this instantiation — stored once in front of the tile loop, reloaded between tiles, none inside the MFMA stream: `hipcc -S`, scratch_* only outside it) or 1 (the 3-channel head: fragment-read bound, but a third
 // of the MFMAs of the 32-cout minimum of the 64-pixel kernel)
 template <int NCB>
 struct GCfg {
